@@ -1,0 +1,128 @@
+/* lcgan_hip.h -- C ABI of liblcgan_hip.so: the MI355X (gfx950) kernels behind the LC-GAN G+D training step.
+ *
+ * The reference (rakutentech/lcgan) has no FFI: its hot path is Python calling PyTorch ATen.  This header is
+ * therefore the boundary a maintainer would bind from Python (ctypes stubs: INTEGRATION.md; the in-tree
+ * binding is lcgan_amd/_lib.py).  Every entry point names the reference call it replaces
+ * (file:line in the reference checkout).
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers; the caller owns every buffer
+ *     (outputs and workspaces are allocated by the caller); `stream` is a hipStream_t passed as void*.
+ *   - return value: 0 = launched, -1 = invalid argument, -2 = HIP launch error.  Nothing synchronises.
+ *   - feature maps are NHWC ([B][H][W][C], C a multiple of 8; logical channels <= C, padding channels are 0),
+ *     element type `dtype`: 0 = f32 ("parity mode": bf16x3 split MFMA, ~fp32 accuracy), 1 = bf16.
+ *   - per-sample channel vectors (styles, demodulation) are f32 [B][C] with the alloc width of the tensor
+ *     they scale.  Images crossing the module boundary are f32 NCHW [B][3][H][W].
+ *   - act: 0 none, 1 leaky_relu(0.2), 2 tanh;  out = act(v) * gain.
+ */
+#ifndef LCGAN_HIP_H
+#define LCGAN_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- convolution family (bf16 MFMA implicit GEMM) --------------------------------------------------------
+ * replaces F.conv2d custom_layers.py:41,43,83 ; F.conv_transpose2d custom_layers.py:78 ; EqualizedWeight
+ * scaling custom_layers.py:10,14 ; modulation/demodulation custom_layers.py:62-68 ; and their autograd. */
+
+/* w [A][Bc][k][k] f32 (reference layout) -> wp_hi/wp_lo bf16 [k*k][N][Kpad], N = transpose ? Bc : A,
+ * Kpad = roundup32(transpose ? A : Bc); wp_lo (the bf16 residual, needed for dtype 0) and wsq [A][Bc]
+ * (= sum_taps (scale*w)^2, the demodulation statistic) may be NULL. */
+int lcgan_conv_weight_prep(const float* w, int A, int Bc, int k, float scale, int transpose,
+                           void* wp_hi, void* wp_lo, float* wsq, void* stream);
+/* gw[a][b][t] = scale*gwp[t][a][b] + 2 scale^2 w[a][b][t] gwsq[a][b]  (w, gwsq may be NULL);
+ * transposed != 0 reads gwp as [t][Bc][A] (weight gradient of the transposed convolution) */
+int lcgan_conv_wgrad_unprep(const float* gwp, int A, int Bc, int k, float scale, int transposed, const float* w,
+                            const float* gwsq, float* gw, void* stream);
+/* y = act(post[b,n] * conv_{k,stride,pad=k/2}(pre[b,c] * x, wp) + bias[n]*bias_scale) * gain + residual */
+int lcgan_conv_fwd(const void* x, const void* wp_hi, const void* wp_lo, void* y,
+                   int B, int Hin, int Win, int Cin, int Cout, int N, int k, int stride,
+                   const float* pre, const float* post, const float* bias, float bias_scale,
+                   int act, float gain, const void* residual, int dtype, void* stream);
+/* adjoint of lcgan_conv_fwd w.r.t. x (weights from weight_prep(transpose=1)); stride 2 == the x2 transposed
+ * convolution of ModulatedConv2d(up=2): output [B][Hg*stride][Wg*stride][Cout]. */
+int lcgan_conv_bwd_data(const void* g, const void* wpT_hi, const void* wpT_lo, void* gx,
+                        int B, int Hg, int Wg, int Cg, int Cout, int N, int k, int stride,
+                        const float* pre, const float* post, const float* bias, float bias_scale,
+                        int act, float gain, const void* residual, int dtype, void* stream);
+/* gwp[t][a][c] += sum_{b,i,j} (pre_g g)[b,i,j,a] (pre_x x)[b,i*stride+ky-pad,j*stride+kx-pad,c]; gwp f32, zeroed by caller */
+int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
+                     int B, int Hx, int Wx, int Cx, int Hg, int Wg, int Cg, int A, int Bc, int k, int stride,
+                     const float* pre_x, const float* pre_g, int dtype, void* stream);
+
+/* ---- stencils / elementwise (HBM-bound) -------------------------------------------------------------------
+ * box filter F.avg_pool2d(3,1,1) custom_layers.py:136-138,196-198 fused with leaky_relu*gain / tanh (:150-155,:205-206) */
+int lcgan_box3_act(const void* x, void* y, int B, int H, int W, int C, int act, float gain, int dtype, void* stream);
+int lcgan_box3_act_bwd(const void* gy, const void* y, void* gx, int B, int H, int W, int C, int act, float gain, int dtype, void* stream);
+/* F.interpolate(x2, nearest) + box filter (+ residual), custom_layers.py:146-147,159 ; x [B,H,W,C] -> y [B,2H,2W,C] */
+int lcgan_up2box(const void* x, const void* residual, void* y, int B, int H, int W, int C, int dtype, void* stream);
+int lcgan_up2box_bwd(const void* gy, void* gx, int B, int H, int W, int C, int dtype, void* stream);
+/* F.avg_pool2d(2,2) custom_layers.py:202 ; H, W are the LARGE (input-side) extents in both calls */
+int lcgan_avgpool2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+int lcgan_avgpool2_bwd(const void* gy, void* gx, int B, int H, int W, int C, int dtype, void* stream);
+/* gz = gy*act'(y) (y = saved OUTPUT); gbias[c] += sum gz; gdq[b,c] += sum_p gz*(act^-1(y/gain) - bias[c]*bias_scale) */
+int lcgan_act_bwd_reduce(const void* gy, const void* y, void* gz, const float* bias, float bias_scale,
+                         float* gbias, float* gdq, int B, int HW, int C, int Clog, int act, float gain, int dtype, void* stream);
+/* style gradient: gs[b,c] += sum_p x*u ; u <- s[b,c]*u in place   (autograd of custom_layers.py:62-64) */
+int lcgan_scale_reduce(void* u, const void* x, const float* s, float* gs, int B, int HW, int C, int dtype, void* stream);
+/* bicubic feature warp: get_coordinates + grid_sample(bicubic, zeros, align_corners=False), custom_layers.py:127-134,162-165
+ * flow [B,H,W,8] (ch 0 = x, ch 1 = y); gx32 is f32 and must be zero on entry (float atomics) */
+int lcgan_warp_fwd(const void* x, const void* flow, void* y, int B, int H, int W, int C, float scale, int dtype, void* stream);
+int lcgan_warp_bwd(const void* gy, const void* x, const void* flow, float* gx32, void* gflow,
+                   int B, int H, int W, int C, float scale, int dtype, void* stream);
+int lcgan_cast_from_f32(const float* src, void* dst, long long n, int dtype, void* stream);
+/* MinibatchStdLayer custom_layers.py:243-256 (G = min(8,N), strided groups); x [N][HW][C] -> y [N][HW][Cy], Cy > C */
+int lcgan_mbstd_fwd(const void* x, void* y, int N, int G, int HW, int C, int Cy, int dtype, void* stream);
+int lcgan_mbstd_bwd(const void* gy, const void* x, void* gx, int N, int G, int HW, int C, int Cy, int dtype, void* stream);
+int lcgan_mbstd_bwd2(const void* v, const void* gy, const void* x, void* ggy, void* gx2,
+                     int N, int G, int HW, int C, int Cy, int dtype, void* stream);
+/* 1x1 convs touching the f32 NCHW image: fromRGB cnn.py:20-21, toRGB custom_layers.py:175,181; w f32 [Bw][3][C] */
+int lcgan_rgb_expand(const float* img, const float* w, const float* bias, float bias_scale, void* y,
+                     int B, int HW, int C, int Clog, int per_sample, int act, float gain, int dtype, void* stream);
+int lcgan_rgb_reduce(const void* x, const float* w, const float* bias, float bias_scale, float* img,
+                     int B, int HW, int C, int per_sample, int dtype, void* stream);
+int lcgan_rgb_wgrad(const float* img, const void* feat, float* gw, int B, int HW, int C, int per_sample, int dtype, void* stream);
+/* layout converts at the NCHW f32 boundary (const input cnn.py:106, flatten custom_layers.py:232 / cnn.py:39) */
+int lcgan_nchw_to_nhwc(const float* src, void* dst, int B, int HW, int C, int Clog, int bcast, int dtype, void* stream);
+int lcgan_nhwc_to_nchw(const void* src, float* dst, int B, int HW, int C, int Clog, int reduce, int dtype, void* stream);
+
+/* ---- small f32 linears: EqualizedLinear custom_layers.py:24-25 (+ autograd) ------------------------------- */
+int lcgan_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int I, int O,
+                     float scale, float bias_scale, int act, float gain, void* stream);
+int lcgan_linear_bwd_data(const float* gy, const float* w, float* gx, int M, int I, int O, float scale, void* stream); /* gx zeroed by caller */
+int lcgan_linear_wgrad(const float* gy, const float* x, float* gw, int M, int I, int O, float scale, void* stream);
+int lcgan_colsum(const float* gy, float* gb, int M, int O, float scale, void* stream);
+int lcgan_act_bwd_f32(const float* gy, const float* y, float* gz, long long n, int act, float gain, void* stream);
+/* demodulation statistic custom_layers.py:67 : d[b,o] = rsqrt(sum_c s^2 wsq[o,c] + eps), d is [B][Os] */
+int lcgan_demod_fwd(const float* s, const float* wsq, float* d, int B, int C, int O, int Os, float eps, void* stream);
+int lcgan_demod_bwd(const float* gdq, const float* d, const float* s, const float* wsq, float* gs, float* gwsq,
+                    int B, int C, int O, int Os, void* stream);
+
+/* ---- losses: worker.py:156-157,191 (BCE with logits), loss.py:9-15 (contrastive), cnn.py:40-41 (normalize),
+ *      worker.py:207-209 (L1 sparsity, pw=1), loss.py:20-23 (R1 square sum, pw=2) ---------------------------- */
+int lcgan_bce_fwd(const float* logit, int n, int target_one, float* out, void* stream);
+int lcgan_bce_bwd(const float* logit, int n, int target_one, const float* gout, float* g, void* stream);
+int lcgan_contrastive_fwd(const float* a, const float* p, const float* n, int B, int D, float tau, float* tsave, float* out, void* stream);
+int lcgan_contrastive_bwd(const float* a, const float* p, const float* n, const float* tsave, const float* gout,
+                          int B, int D, float tau, float* ga, float* gp, float* gn, void* stream);
+int lcgan_l2norm_fwd(const float* x, float* y, float* nsave, int B, int D, float eps, void* stream);
+int lcgan_l2norm_bwd(const float* gy, const float* y, const float* nsave, float* gx, int B, int D, void* stream);
+int lcgan_powsum(const float* x, long long n, int pw, float coef, float* out, void* stream);          /* out zeroed by caller */
+int lcgan_powsum_bwd(const float* x, long long n, int pw, float coef, const float* gout, float* g, void* stream);
+/* cnn.py:95-97 */
+int lcgan_avg_latent(const float* w, float* avg, int B, int D, float beta, void* stream);
+
+/* ---- multi-tensor optimiser kernels: torch.optim.Adam worker.py:98-110 (op 0), Ema.update ema.py:19-32 (op 1),
+ *      gradient bucket pack for the RCCL all-reduce that replaces DDP's reducer worker.py:88-96 (op 2) -------- */
+int lcgan_multi_tensor(const void* descs, const int* chunk_tensor, const int* chunk_index, int n_chunks, int op,
+                       float a0, float a1, float a2, double total_elems, void* stream);
+
+/* ---- per-launch HIP-event profiling (bench.py roofline) ---------------------------------------------------- */
+int lcgan_prof_enable(int on);
+int lcgan_prof_collect(double* out_ms, double* out_flops, double* out_bytes, long long* out_count);
+int lcgan_prof_active(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,117 @@
+"""Generator / Discriminator of LC-GAN on the MI355X HIP kernels -- drop-in for the reference's `cnn.py`:
+same constructor (`args` namespace), forward signatures, attribute names and state_dict layout (cnn.py:7-115).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import config, ops
+from . import kernels as KM
+from .custom_layers import (DiscriminatorBlock, DiscriminatorEpilogue, EqualizedConv2d, MappingNetwork, ProjectionHead,
+                            SynthesisBlock, ToRGBBlock)
+from .kernels import ACT_LRELU
+
+
+def _base_nf(res: int) -> int:
+    return 32 if res == 1024 else 64 if res == 512 else 128       # cnn.py:17, :54
+
+
+class Discriminator(torch.nn.Module):
+    """reference cnn.py:7-43.  forward(image [B,3,R,R] f32, get_embedding_features) -> (logit [B,1], geo [B,P] | None, app | None)"""
+
+    def __init__(self, args):
+        super().__init__()
+        self.img_resolution = args.img_resolution
+        self.last_block_resolution = 4
+        self.log_last_block_resolution = int(np.log2(self.last_block_resolution))
+        self.num_blocks = int(np.log2(self.img_resolution)) - self.log_last_block_resolution
+        self.geo_projection_dim = args.geo_projection_dim
+        self.app_projection_dim = args.app_projection_dim
+        self.max_nf = 512
+        self.base_nf = _base_nf(self.img_resolution)
+
+        blocks = [EqualizedConv2d(3, self.base_nf, kernel_size=1), nn.LeakyReLU(0.2)]
+        out_features = self.base_nf
+        for i in range(self.num_blocks):
+            in_features = min(self.base_nf * (2 ** i), self.max_nf)
+            out_features = min(self.base_nf * (2 ** (i + 1)), self.max_nf)
+            blocks += [DiscriminatorBlock(in_features, out_features, skip=True)]
+        self.shared_model = nn.Sequential(*blocks)       # children order [conv1x1, LeakyReLU, block...] is relied on by freezeD (worker.py:128-131)
+        self.discriminator_epilogue = DiscriminatorEpilogue(out_features, resolution=self.last_block_resolution, mbstd_group_size=8)
+        self.logit_mapper = ProjectionHead([out_features, 1])
+        self.projection_header1 = ProjectionHead([out_features * 16, out_features * 4, out_features, self.geo_projection_dim])
+        self.projection_header2 = ProjectionHead([out_features * 16, out_features * 4, out_features, self.app_projection_dim])
+
+    def forward(self, image, get_embedding_features=False):
+        mods = list(self.shared_model)
+        h = mods[0].forward_rgb(image.float(), ACT_LRELU, 1.0)          # 1x1 conv + LeakyReLU fused (cnn.py:20-21)
+        for blk in mods[2:]:
+            h = blk(h)
+        logit = self.logit_mapper(self.discriminator_epilogue(h))
+        geometry_embedding = None
+        appearance_embedding = None
+        if get_embedding_features:
+            x = ops.ToNCHWFn.apply(h, h.shape[-1]).flatten(1)            # h.flatten(1) in NCHW order (cnn.py:39)
+            geometry_embedding = ops.L2NormalizeFn.apply(self.projection_header1(x))
+            appearance_embedding = ops.L2NormalizeFn.apply(self.projection_header2(x))
+        return logit, geometry_embedding, appearance_embedding
+
+
+class Generator(torch.nn.Module):
+    """reference cnn.py:46-115.  forward(rand_noise1 [B,geo_noise], rand_noise2 [B,app_noise], w_psi=-1) -> [B,3,R,R] f32"""
+
+    def __init__(self, args):
+        super().__init__()
+        self.img_resolution = args.img_resolution
+        self.first_block_resolution = 4
+        self.log_first_block_resolution = int(np.log2(self.first_block_resolution))
+        self.num_blocks = int(np.log2(self.img_resolution)) - self.log_first_block_resolution
+        self.max_nf = 512
+        self.base_nf = _base_nf(self.img_resolution)
+
+        self.geo_latent_dim = args.geo_latent_dim
+        self.app_latent_dim = args.app_latent_dim
+        self.geo_noise_dim = args.geo_noise_dim
+        self.app_noise_dim = args.app_noise_dim
+        self.max_flow_scale = args.max_flow_scale
+
+        self.w_avg_beta = 0.998
+        self.register_buffer("avg_latent1", torch.zeros([self.geo_latent_dim]))
+        self.register_buffer("avg_latent2", torch.zeros([self.app_latent_dim]))
+
+        geometry_channels = [self.geo_noise_dim] + [self.geo_latent_dim] * 12                                    # cnn.py:66-68
+        appearance_channels = [self.app_noise_dim, self.app_latent_dim // 4, self.app_latent_dim // 2] + [self.app_latent_dim] * 10   # :70-72
+        self.geometry_mapping = MappingNetwork(geometry_channels)
+        self.appearance_mapping = MappingNetwork(appearance_channels)
+        self.const = torch.nn.Parameter(torch.randn([self.max_nf, self.first_block_resolution, self.first_block_resolution]))
+        blocks = []
+        in_features = self.max_nf
+        out_features, out_resolution = in_features, self.first_block_resolution
+        for i in range(self.num_blocks):
+            out_features = min(self.base_nf * 2 ** (self.num_blocks - i - 1), self.max_nf)
+            out_resolution = 2 ** (self.log_first_block_resolution + 1 + i)
+            blocks += [SynthesisBlock(in_features, out_features, self.geo_latent_dim, self.app_latent_dim, out_resolution,
+                                      self.max_flow_scale, use_noise=False)]
+            in_features = out_features
+        self.model = nn.Sequential(*blocks)
+        self.rgb_layer = ToRGBBlock(out_features, 3, self.app_latent_dim, out_resolution, use_noise=False)
+
+    def forward(self, rand_noise1, rand_noise2, w_psi=-1.0):
+        batch_size = rand_noise1.size(0)
+        geometry_code = self.geometry_mapping(rand_noise1.float())
+        appearance_code = self.appearance_mapping(rand_noise2.float())
+
+        if w_psi <= 0:                                   # running latent means (cnn.py:95-97), one tiny kernel each
+            KM.K.avg_latent(geometry_code.detach(), self.avg_latent1, self.w_avg_beta)
+            KM.K.avg_latent(appearance_code.detach(), self.avg_latent2, self.w_avg_beta)
+        if w_psi > 0.0:                                  # truncation trick (cnn.py:99-101), inference only
+            geometry_code = self.avg_latent1.lerp(geometry_code, w_psi)
+            appearance_code = self.avg_latent2.lerp(appearance_code, w_psi)
+
+        # every block receives the SAME latents (the reference repeats them, cnn.py:103-104): pass them without copies
+        x = ops.ConstInputFn.apply(self.const, batch_size, config.feature_dtype())     # cnn.py:106
+        for block in self.model:
+            x = block(x, (geometry_code,), (appearance_code, appearance_code))
+        return self.rgb_layer(x, (appearance_code, appearance_code))

@@ -1,0 +1,606 @@
+// Implicit-GEMM convolution family for gfx950 (CDNA4): forward / data-gradient / weight-gradient of the
+// k in {1,3}, stride in {1,2} convolutions of LC-GAN's generator and discriminator, NHWC activations,
+// bf16 MFMA (v_mfma_f32_32x32x16_bf16) with fp32 accumulation.
+//
+// Replaces the ATen calls of the reference:  F.conv2d custom_layers.py:41,43,83 ; F.conv_transpose2d :78 ;
+// and their autograd derivatives (convolution_backward, incl. the double-backward used by loss.py:28-33).
+//
+//  * One "NT" kernel (conv_igemm_kernel) serves conv forward (stride 1/2), the data gradient of a stride-1
+//    conv (flipped taps, transposed weights) and -- through four sub-pixel phases with 1/2/2/4 taps --
+//    the data gradient of a stride-2 conv == the x2 transposed convolution of ModulatedConv2d(up=2).
+//    Geometry is a tap table (dy, dx, weight-tap) per phase; the M index walks (b, i, j) of an Hm x Wm grid.
+//  * Style modulation is folded in as a per-(sample, in-channel) pre-scale applied while the A tile is staged
+//    and a per-(sample, out-channel) demodulation post-scale in the epilogue, so the per-sample weights the
+//    reference materialises ([B,Co,Ci,3,3], custom_layers.py:62-72) never exist.
+//  * Epilogue fuses demod, bias, leaky-ReLU, gain and a residual add.
+//  * fp32 feature maps (parity mode) run the same MFMA path with a hi/lo bf16 split of both operands
+//    (3 MFMAs per product, ~2^-16 relative error) -- NSPLIT == 3.
+//  * conv_wgrad_kernel reduces over positions: operands are staged row-major ([position][channel]) and read
+//    with ds_read_b64_tr_b16 so no transpose pass is needed; split-K partials are combined with fp32 atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDS_ROW = 40;               // bf16 per staged row: 32 + 8 pad (80 B stride: conflict-free ds_read_b128)
+constexpr int TILE = BM * LDS_ROW;        // elements per staged operand tile
+
+struct TapTable { int n; int dy[9]; int dx[9]; int wt[9]; };
+
+struct ConvArgs {
+  const void* x; const __bf16* w_hi; const __bf16* w_lo; void* y;
+  const float* pre; const float* post; const float* bias; const void* residual;
+  int B, Hin, Win, Cin;
+  int Hout, Wout, Cout;
+  int Hm, Wm, M;
+  int N, Kpad, kc_per_tap;
+  int in_mul, out_mul;
+  int pre_stride, post_stride;
+  float bias_scale, gain; int act;
+  TapTable taps[4];
+};
+
+__device__ __forceinline__ bf16x8 to_bf16x8(const F8& f) {
+  bf16x8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = (__bf16)f.v[i];
+  return r;
+}
+__device__ __forceinline__ bf16x8 residual_bf16x8(const F8& f, const bf16x8& hi) {
+  bf16x8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = (__bf16)(f.v[i] - (float)hi[i]);
+  return r;
+}
+__device__ __forceinline__ bf16x8 zero_bf16x8() {
+  bf16x8 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = (__bf16)0.f;
+  return r;
+}
+
+template <typename T, int NSPLIT>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = (NSPLIT == 3) ? 4 : 2;            // operand tiles per stage: A_hi, B_hi, (A_lo, B_lo)
+  __bf16* lds = (__bf16*)smem;
+  int* row_off = (int*)(smem + 2 * NT * TILE * sizeof(__bf16));
+  int* row_b = row_off + BM;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, phase = blockIdx.z;
+  const TapTable& tt = a.taps[phase];
+  const int HWm = a.Hm * a.Wm;
+  const T* __restrict__ x = (const T*)a.x;
+
+  // ---- loader bookkeeping: each thread stages rows (lrow, lrow+64), 8 channels at lvec*8 ---------------
+  const int lrow = tid >> 2, lvec = tid & 3;
+  int lb[2], liy[2], lix[2];
+  bool lvalid[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + lrow + 64 * i;
+    lvalid[i] = m < a.M;
+    const int mm = lvalid[i] ? m : 0;
+    const int b = mm / HWm, rem = mm - b * HWm;
+    const int iy = rem / a.Wm, ix = rem - iy * a.Wm;
+    lb[i] = b; liy[i] = iy * a.in_mul; lix[i] = ix * a.in_mul;
+    if (lvec == 0) {
+      const int oy = iy * a.out_mul + (phase >> 1), ox = ix * a.out_mul + (phase & 1);
+      row_off[lrow + 64 * i] = lvalid[i] ? ((b * a.Hout + oy) * a.Wout + ox) : -1;
+      row_b[lrow + 64 * i] = b;
+    }
+  }
+
+  F8 ra[2];
+  bf16x8 rb_hi[2], rb_lo[2];
+
+  auto gload = [&](int q) {
+    const int tap = q / a.kc_per_tap;
+    const int c0 = (q - tap * a.kc_per_tap) * BK + lvec * 8;
+    const int dy = tt.dy[tap], dx = tt.dx[tap], wt = tt.wt[tap];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int iy = liy[i] + dy, ix = lix[i] + dx;
+      const bool ok = lvalid[i] && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win && c0 < a.Cin;
+      if (ok) {
+        ra[i] = Feat<T>::load(x + ((size_t)(lb[i] * a.Hin + iy) * a.Win + ix) * a.Cin + c0);
+        if (a.pre) {
+          const float* ps = a.pre + (size_t)lb[i] * a.pre_stride + c0;
+          const f32x4 p0 = *(const f32x4*)ps, p1 = *(const f32x4*)(ps + 4);
+          ra[i].v[0] *= p0[0]; ra[i].v[1] *= p0[1]; ra[i].v[2] *= p0[2]; ra[i].v[3] *= p0[3];
+          ra[i].v[4] *= p1[0]; ra[i].v[5] *= p1[1]; ra[i].v[6] *= p1[2]; ra[i].v[7] *= p1[3];
+        }
+      } else {
+        ra[i] = f8_zero();
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int n = n0 + lrow + 64 * i;
+      if (n < a.N) {
+        const size_t off = ((size_t)wt * a.N + n) * a.Kpad + c0;
+        rb_hi[i] = *(const bf16x8*)(a.w_hi + off);
+        if (NSPLIT == 3) rb_lo[i] = *(const bf16x8*)(a.w_lo + off);
+      } else {
+        rb_hi[i] = zero_bf16x8();
+        if (NSPLIT == 3) rb_lo[i] = zero_bf16x8();
+      }
+    }
+  };
+
+  auto sstore = [&](int buf) {
+    __bf16* base = lds + buf * NT * TILE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int o = (lrow + 64 * i) * LDS_ROW + lvec * 8;
+      const bf16x8 hi = to_bf16x8(ra[i]);
+      *(bf16x8*)(base + o) = hi;
+      *(bf16x8*)(base + TILE + o) = rb_hi[i];
+      if (NSPLIT == 3) {
+        *(bf16x8*)(base + 2 * TILE + o) = residual_bf16x8(ra[i], hi);
+        *(bf16x8*)(base + 3 * TILE + o) = rb_lo[i];
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto compute = [&](int buf) {
+    const __bf16* A = lds + buf * NT * TILE;
+    const __bf16* Bt = A + TILE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int koff = ks * 16 + (lane >> 5) * 8;
+      bf16x8 ah[2], bh[2], al[2], bl[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int o = (wm * 64 + mi * 32 + (lane & 31)) * LDS_ROW + koff;
+        ah[mi] = *(const bf16x8*)(A + o);
+        if (NSPLIT == 3) al[mi] = *(const bf16x8*)(A + 2 * TILE + o);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int o = (wn * 64 + ni * 32 + (lane & 31)) * LDS_ROW + koff;
+        bh[ni] = *(const bf16x8*)(Bt + o);
+        if (NSPLIT == 3) bl[ni] = *(const bf16x8*)(Bt + 2 * TILE + o);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          if (NSPLIT == 3) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+          }
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+  };
+
+  // ---- main loop: register-staged double buffering, one barrier per K chunk ---------------------------
+  const int nq = tt.n * a.kc_per_tap;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int q = 0; q < nq; ++q) {
+    const int cur = q & 1;
+    if (q + 1 < nq) gload(q + 1);
+    compute(cur);
+    if (q + 1 < nq) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: demod * acc + bias -> act * gain (+ residual) -----------------------------------------
+  T* __restrict__ y = (T*)a.y;
+  const T* __restrict__ res = (const T*)a.residual;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
+      const bool nalloc = n < a.Cout, nlog = n < a.N;
+      const float bv = (a.bias && nlog) ? a.bias[n] * a.bias_scale : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int ro = row_off[row];
+        if (ro < 0 || !nalloc) continue;
+        float v = acc[mi][ni][r];
+        if (a.post) v *= a.post[(size_t)row_b[row] * a.post_stride + n];   // post is [B][Cout] (alloc width)
+        v += bv;
+        v = act_fwd(v, a.act) * a.gain;
+        const size_t off = (size_t)ro * a.Cout + n;
+        if (res) v += Feat<T>::ld1(res + off);
+        Feat<T>::st1(y + off, v);
+      }
+    }
+}
+
+// =========================================================================================================
+// weight gradient
+// =========================================================================================================
+constexpr int WG_ROW = 160;                 // bf16 per staged position row: 128 channels + 32 pad (320 B stride)
+constexpr int WG_TILE = 32 * WG_ROW;
+
+struct WgradArgs {
+  const void* x; const void* g; float* gwp;
+  const float* pre_x; const float* pre_g;
+  int B, Hx, Wx, Cx, Hm, Wm, Cg, A, Bc, M;
+  int stride, k, pad;
+  int chunks_per_split, nsplit, nchunks;
+};
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int row0, int col) {
+  // 8 reduction rows (row0 .. row0+7) x this lane's column, via two transposed 4x16 block reads.
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + row0 * WG_ROW + col));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + (row0 + 4) * WG_ROW + col));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <typename T, int NSPLIT>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = (NSPLIT == 3) ? 4 : 2;            // G_hi, X_hi, (G_lo, X_lo)
+  __bf16* lds = (__bf16*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int a0 = blockIdx.x * 128, c0 = blockIdx.y * 128;
+  const int tap = blockIdx.z / a.nsplit, split = blockIdx.z - tap * a.nsplit;
+  const int ky = tap / a.k, kx = tap - ky * a.k;
+  const int q_begin = split * a.chunks_per_split;
+  const int q_end = min(q_begin + a.chunks_per_split, a.nchunks);
+  if (q_begin >= q_end) return;                                  // uniform per block
+  const int HWm = a.Hm * a.Wm;
+  const T* __restrict__ x = (const T*)a.x;
+  const T* __restrict__ g = (const T*)a.g;
+
+  const int lpos = tid >> 4, lvec = tid & 15;                    // positions lpos, lpos+16; channels lvec*8
+  F8 rg[2], rx[2];
+
+  auto gload = [&](int q) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = q * 32 + lpos + 16 * i;
+      rg[i] = f8_zero(); rx[i] = f8_zero();
+      if (m < a.M) {
+        const int b = m / HWm, rem = m - b * HWm;
+        const int iy = rem / a.Wm, ix = rem - iy * a.Wm;
+        const int ca = a0 + lvec * 8;
+        if (ca < a.Cg) {
+          rg[i] = Feat<T>::load(g + ((size_t)(b * a.Hm + iy) * a.Wm + ix) * a.Cg + ca);
+          if (a.pre_g) {
+            const float* ps = a.pre_g + (size_t)b * a.Cg + ca;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rg[i].v[j] *= ps[j];
+          }
+        }
+        const int yy = iy * a.stride + ky - a.pad, xx = ix * a.stride + kx - a.pad;
+        const int cc = c0 + lvec * 8;
+        if ((unsigned)yy < (unsigned)a.Hx && (unsigned)xx < (unsigned)a.Wx && cc < a.Cx) {
+          rx[i] = Feat<T>::load(x + ((size_t)(b * a.Hx + yy) * a.Wx + xx) * a.Cx + cc);
+          if (a.pre_x) {
+            const float* ps = a.pre_x + (size_t)b * a.Cx + cc;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rx[i].v[j] *= ps[j];
+          }
+        }
+      }
+    }
+  };
+  auto sstore = [&](int buf) {
+    __bf16* base = lds + buf * NT * WG_TILE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int o = (lpos + 16 * i) * WG_ROW + lvec * 8;
+      const bf16x8 gh = to_bf16x8(rg[i]), xh = to_bf16x8(rx[i]);
+      *(bf16x8*)(base + o) = gh;
+      *(bf16x8*)(base + WG_TILE + o) = xh;
+      if (NSPLIT == 3) {
+        *(bf16x8*)(base + 2 * WG_TILE + o) = residual_bf16x8(rg[i], gh);
+        *(bf16x8*)(base + 3 * WG_TILE + o) = residual_bf16x8(rx[i], xh);
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transposed-read lane geometry (ds_read_b64_tr_b16): within each 16-lane group lane 4q+p addresses
+  // row q, columns 4p..4p+3 of a 4x16 block and lane i receives column i.
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int trow = 8 * (g16 >> 1) + (i16 >> 2);                  // + 16*ks (+4 for the second read)
+  const int tcol = 16 * (g16 & 1) + 4 * (i16 & 3);               // + sub-tile column base
+
+  auto compute = [&](int buf) {
+    const __bf16* G = lds + buf * NT * WG_TILE;
+    const __bf16* X = G + WG_TILE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah[2], bh[2], al[2], bl[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        ah[mi] = tr_frag(G, ks * 16 + trow, wm * 64 + mi * 32 + tcol);
+        if (NSPLIT == 3) al[mi] = tr_frag(G + 2 * WG_TILE, ks * 16 + trow, wm * 64 + mi * 32 + tcol);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        bh[ni] = tr_frag(X, ks * 16 + trow, wn * 64 + ni * 32 + tcol);
+        if (NSPLIT == 3) bl[ni] = tr_frag(X + 2 * WG_TILE, ks * 16 + trow, wn * 64 + ni * 32 + tcol);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          if (NSPLIT == 3) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+          }
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+  };
+
+  gload(q_begin);
+  sstore(0);
+  __syncthreads();
+  for (int q = q_begin; q < q_end; ++q) {
+    const int cur = (q - q_begin) & 1;
+    if (q + 1 < q_end) gload(q + 1);
+    compute(cur);
+    if (q + 1 < q_end) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int cc = c0 + wn * 64 + ni * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int aa = a0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (aa < a.A && cc < a.Bc) atomicAdd(a.gwp + ((size_t)tap * a.A + aa) * a.Bc + cc, acc[mi][ni][r]);
+      }
+    }
+}
+
+// =========================================================================================================
+// weight layout kernels
+// =========================================================================================================
+// w [A][Bc][kk] fp32 (reference layout, custom_layers.py:32,55)  ->  wp [kk][N][Kpad] bf16 (hi, lo), scaled.
+//   transpose == 0: N = A,  reduction channel = Bc   (forward conv)
+//   transpose == 1: N = Bc, reduction channel = A    (data gradient / transposed conv)
+__global__ void prep_weight_kernel(const float* __restrict__ w, int A, int Bc, int kk, float scale, int transpose,
+                                   __bf16* __restrict__ hi, __bf16* __restrict__ lo, int N, int Kc, int Kpad) {
+  const size_t total = (size_t)kk * N * Kpad;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % Kpad);
+    const int n = (int)((idx / Kpad) % N);
+    const int t = (int)(idx / ((size_t)Kpad * N));
+    float v = 0.f;
+    if (c < Kc) {
+      const int aa = transpose ? c : n, bb = transpose ? n : c;
+      v = w[((size_t)aa * Bc + bb) * kk + t] * scale;
+    }
+    const __bf16 h = (__bf16)v;
+    hi[idx] = h;
+    if (lo) lo[idx] = (__bf16)(v - (float)h);
+  }
+}
+
+// wsq[a][b] = sum_t (scale * w[a][b][t])^2      (demodulation statistic, custom_layers.py:67)
+__global__ void wsq_kernel(const float* __restrict__ w, int AB, int kk, float scale, float* __restrict__ wsq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= AB) return;
+  float s = 0.f;
+  for (int t = 0; t < kk; ++t) { const float v = w[(size_t)i * kk + t] * scale; s += v * v; }
+  wsq[i] = s;
+}
+
+// gw[a][b][t] = scale * gwp[t][a][b] + 2 * scale^2 * w[a][b][t] * gwsq[a][b]
+// transposed != 0: gwp is [t][Bc][A] (weight gradient of the transposed convolution, whose low-res operand carries the
+// parameter's SECOND axis): gw[a][b][t] = scale * gwp[t][b][a] + ...
+__global__ void unprep_wgrad_kernel(const float* __restrict__ gwp, int A, int Bc, int kk, float scale, int transposed,
+                                    const float* __restrict__ w, const float* __restrict__ gwsq, float* __restrict__ gw) {
+  const size_t total = (size_t)A * Bc * kk;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int t = (int)(idx % kk);
+    const size_t ab = idx / kk;
+    const int b = (int)(ab % Bc), aa = (int)(ab / Bc);
+    const size_t src = transposed ? ((size_t)t * Bc + b) * A + aa : (size_t)t * A * Bc + ab;
+    float v = gwp[src] * scale;
+    if (gwsq) v += 2.f * scale * scale * w[idx] * gwsq[ab];
+    gw[idx] = v;
+  }
+}
+
+template <typename T, int NS>
+int launch_igemm(const ConvArgs& a, int nphase, hipStream_t s) {
+  constexpr int NT = (NS == 3) ? 4 : 2;
+  const size_t smem = 2 * NT * TILE * sizeof(__bf16) + 2 * BM * sizeof(int);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)conv_igemm_kernel<T, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  dim3 grid(cdiv(a.M, BM), cdiv(a.Cout, BN), nphase);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, NS>), grid, dim3(256), smem, s, a);
+  return launch_status();
+}
+
+int dispatch_igemm(const ConvArgs& a, int nphase, int dtype, hipStream_t s) {
+  if (dtype == DT_BF16) return launch_igemm<__bf16, 1>(a, nphase, s);
+  if (dtype == DT_F32) return launch_igemm<float, 3>(a, nphase, s);
+  return LCGAN_EINVAL;
+}
+
+}  // namespace
+
+// =========================================================================================================
+// C ABI (declared in include/lcgan_hip.h)
+// =========================================================================================================
+extern "C" {
+
+int lcgan_conv_weight_prep(const float* w, int A, int Bc, int k, float scale, int transpose,
+                           void* wp_hi, void* wp_lo, float* wsq, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (k != 1 && k != 3) return LCGAN_EINVAL;
+  const int kk = k * k, N = transpose ? Bc : A, Kc = transpose ? A : Bc, Kpad = (Kc + 31) / 32 * 32;
+  ProfScope p(KID_WEIGHT_PREP, 0, (double)A * Bc * kk * 8, s);
+  const size_t total = (size_t)kk * N * Kpad;
+  hipLaunchKernelGGL(prep_weight_kernel, dim3((unsigned)min((size_t)4096, (total + 255) / 256)), dim3(256), 0, s,
+                     w, A, Bc, kk, scale, transpose, (__bf16*)wp_hi, (__bf16*)wp_lo, N, Kc, Kpad);
+  if (wsq) hipLaunchKernelGGL(wsq_kernel, dim3(cdiv((long long)A * Bc, 256)), dim3(256), 0, s, w, A * Bc, kk, scale, wsq);
+  return launch_status();
+}
+
+int lcgan_conv_wgrad_unprep(const float* gwp, int A, int Bc, int k, float scale, int transposed, const float* w,
+                            const float* gwsq, float* gw, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int kk = k * k;
+  ProfScope p(KID_WEIGHT_PREP, 0, (double)A * Bc * kk * 8, s);
+  const size_t total = (size_t)A * Bc * kk;
+  hipLaunchKernelGGL(unprep_wgrad_kernel, dim3((unsigned)min((size_t)4096, (total + 255) / 256)), dim3(256), 0, s,
+                     gwp, A, Bc, kk, scale, transposed, w, gwsq, gw);
+  return launch_status();
+}
+
+// Forward convolution  y[b,ho,wo,n] = act(post[b,n] * sum_{t,c} pre[b,c] x[b, ho*stride+ky-pad, wo*stride+kx-pad, c] wp[t][n][c]
+//                                        + bias[n]*bias_scale) * gain + residual
+// x: [B,Hin,Win,Cin]  wp: lcgan_conv_weight_prep(transpose=0)  y: [B,Hout,Wout,Cout], Hout = ceil(Hin/stride)
+int lcgan_conv_fwd(const void* x, const void* wp_hi, const void* wp_lo, void* y,
+                   int B, int Hin, int Win, int Cin, int Cout, int N, int k, int stride,
+                   const float* pre, const float* post, const float* bias, float bias_scale,
+                   int act, float gain, const void* residual, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || (Cin & 7) || (Cout & 7) || N > Cout) return LCGAN_EINVAL;
+  if (dtype == DT_F32 && !wp_lo) return LCGAN_EINVAL;
+  ConvArgs a = {};
+  a.x = x; a.w_hi = (const __bf16*)wp_hi; a.w_lo = (const __bf16*)wp_lo; a.y = y;
+  a.pre = pre; a.post = post; a.bias = bias; a.residual = residual;
+  a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin;
+  a.Hout = (Hin + stride - 1) / stride; a.Wout = (Win + stride - 1) / stride; a.Cout = Cout;
+  a.Hm = a.Hout; a.Wm = a.Wout;
+  const long long M = (long long)B * a.Hm * a.Wm;
+  if (M <= 0 || M >= (1ll << 31) || (long long)B * Hin * Win >= (1ll << 31)) return LCGAN_EINVAL;
+  a.M = (int)M; a.N = N; a.Kpad = (Cin + 31) / 32 * 32; a.kc_per_tap = a.Kpad / BK;
+  a.in_mul = stride; a.out_mul = 1; a.pre_stride = Cin; a.post_stride = Cout;
+  a.bias_scale = bias_scale; a.gain = gain; a.act = act;
+  const int pad = k / 2;
+  TapTable& t = a.taps[0];
+  t.n = k * k;
+  for (int ky = 0; ky < k; ++ky)
+    for (int kx = 0; kx < k; ++kx) { const int i = ky * k + kx; t.dy[i] = ky - pad; t.dx[i] = kx - pad; t.wt[i] = i; }
+  ProfScope p(KID_CONV_IGEMM, 2.0 * M * N * Cin * k * k, 0, s);
+  return dispatch_igemm(a, 1, dtype, s);
+}
+
+// Data gradient of the convolution above == transposed convolution:
+//   gx[b,h,w,n] = act(post[b,n] * sum_{t,c} pre[b,c] g[b,(h+pad-ky)/stride,(w+pad-kx)/stride,c] wpT[t][n][c] + bias) * gain + residual
+// g: [B,Hg,Wg,Cg] (the conv's output grid)  wpT: lcgan_conv_weight_prep(transpose=1)  gx: [B,Hg*stride,Wg*stride,Cout]
+// stride 2 runs as 4 sub-pixel phases with 1/2/2/4 taps (== F.conv_transpose2d(stride=2, padding=1, output_padding=1)).
+int lcgan_conv_bwd_data(const void* g, const void* wpT_hi, const void* wpT_lo, void* gx,
+                        int B, int Hg, int Wg, int Cg, int Cout, int N, int k, int stride,
+                        const float* pre, const float* post, const float* bias, float bias_scale,
+                        int act, float gain, const void* residual, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || (Cg & 7) || (Cout & 7) || N > Cout) return LCGAN_EINVAL;
+  if (stride == 2 && k != 3) return LCGAN_EINVAL;
+  if (dtype == DT_F32 && !wpT_lo) return LCGAN_EINVAL;
+  ConvArgs a = {};
+  a.x = g; a.w_hi = (const __bf16*)wpT_hi; a.w_lo = (const __bf16*)wpT_lo; a.y = gx;
+  a.pre = pre; a.post = post; a.bias = bias; a.residual = residual;
+  a.B = B; a.Hin = Hg; a.Win = Wg; a.Cin = Cg;
+  a.Hout = Hg * stride; a.Wout = Wg * stride; a.Cout = Cout;
+  a.Hm = Hg; a.Wm = Wg;
+  const long long M = (long long)B * a.Hm * a.Wm;
+  if (M <= 0 || (long long)B * a.Hout * a.Wout >= (1ll << 31)) return LCGAN_EINVAL;
+  a.M = (int)M; a.N = N; a.Kpad = (Cg + 31) / 32 * 32; a.kc_per_tap = a.Kpad / BK;
+  a.in_mul = 1; a.out_mul = stride; a.pre_stride = Cg; a.post_stride = Cout;
+  a.bias_scale = bias_scale; a.gain = gain; a.act = act;
+  const int pad = k / 2;
+  int nphase = 1;
+  double taps_total = k * k;
+  if (stride == 1) {
+    TapTable& t = a.taps[0];
+    t.n = k * k;
+    for (int ky = 0; ky < k; ++ky)
+      for (int kx = 0; kx < k; ++kx) { const int i = ky * k + kx; t.dy[i] = pad - ky; t.dx[i] = pad - kx; t.wt[i] = i; }
+  } else {
+    // output row 2i+ph receives tap ky iff (2i+ph+1-ky) is even; source row (2i+ph+1-ky)/2 = i + (ph+1-ky)/2
+    nphase = 4;
+    for (int ph = 0; ph < 2; ++ph)
+      for (int pw = 0; pw < 2; ++pw) {
+        TapTable& t = a.taps[ph * 2 + pw];
+        t.n = 0;
+        for (int ky = 0; ky < 3; ++ky) {
+          if ((ph + 1 - ky) & 1) continue;
+          for (int kx = 0; kx < 3; ++kx) {
+            if ((pw + 1 - kx) & 1) continue;
+            t.dy[t.n] = (ph + 1 - ky) / 2; t.dx[t.n] = (pw + 1 - kx) / 2; t.wt[t.n] = ky * 3 + kx; ++t.n;
+          }
+        }
+      }
+    taps_total = 9.0 / 4.0;   // average taps per output pixel
+  }
+  ProfScope p(KID_CONV_IGEMM, 2.0 * (double)B * a.Hout * a.Wout * N * Cg * taps_total, 0, s);
+  return dispatch_igemm(a, nphase, dtype, s);
+}
+
+// Weight gradient: gwp[t][a][c] += sum_{b,i,j} (pre_g[b,a] g[b,i,j,a]) * (pre_x[b,c] x[b, i*stride+ky-pad, j*stride+kx-pad, c])
+// x: [B,Hx,Wx,Cx] (the conv's input side), g: [B,Hg,Wg,Cg] (the conv's output side); gwp fp32 [k*k][A][Bc], must be zeroed.
+int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
+                     int B, int Hx, int Wx, int Cx, int Hg, int Wg, int Cg, int A, int Bc, int k, int stride,
+                     const float* pre_x, const float* pre_g, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || (Cx & 7) || (Cg & 7) || A > Cg || Bc > Cx) return LCGAN_EINVAL;
+  WgradArgs a = {};
+  a.x = x; a.g = g; a.gwp = gwp; a.pre_x = pre_x; a.pre_g = pre_g;
+  a.B = B; a.Hx = Hx; a.Wx = Wx; a.Cx = Cx; a.Hm = Hg; a.Wm = Wg; a.Cg = Cg; a.A = A; a.Bc = Bc;
+  const long long M = (long long)B * Hg * Wg;
+  if (M <= 0 || M >= (1ll << 31)) return LCGAN_EINVAL;
+  a.M = (int)M; a.stride = stride; a.k = k; a.pad = k / 2;
+  a.nchunks = cdiv(M, 32);
+  const int tiles = cdiv(A, 128) * cdiv(Bc, 128) * k * k;
+  int nsplit = (2048 + tiles - 1) / tiles;                       // aim at ~2048 workgroups
+  nsplit = max(1, min(nsplit, a.nchunks / 8 > 0 ? a.nchunks / 8 : 1));
+  a.chunks_per_split = cdiv(a.nchunks, nsplit);
+  a.nsplit = cdiv(a.nchunks, a.chunks_per_split);
+  dim3 grid(cdiv(A, 128), cdiv(Bc, 128), k * k * a.nsplit);
+  ProfScope p(KID_CONV_WGRAD, 2.0 * M * A * Bc * k * k, 0, s);
+  if (dtype == DT_BF16) {
+    const size_t smem = 2 * 2 * WG_TILE * sizeof(__bf16);
+    hipLaunchKernelGGL((conv_wgrad_kernel<__bf16, 1>), grid, dim3(256), smem, s, a);
+  } else if (dtype == DT_F32) {
+    const size_t smem = 2 * 4 * WG_TILE * sizeof(__bf16);
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute((const void*)conv_wgrad_kernel<float, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_kernel<float, 3>), grid, dim3(256), smem, s, a);
+  } else {
+    return LCGAN_EINVAL;
+  }
+  return launch_status();
+}
+
+}  // extern "C"

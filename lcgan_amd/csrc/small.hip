@@ -1,0 +1,396 @@
+// Latency-class kernels of the LC-GAN step for gfx950: small-M fp32 linear layers (style affines, mapping MLPs,
+// discriminator epilogue and projection heads), demodulation statistics, loss reductions, and the multi-tensor
+// Adam / EMA / gradient-pack kernels.
+//
+// Reference ops replaced (file:line in /root/reference):
+//   linear_*      F.linear in EqualizedLinear                         custom_layers.py:24-25 (+ autograd)
+//   demod_*       rsqrt(sum (w*s)^2 + eps)                            custom_layers.py:67
+//   bce / contrastive / l2norm / abs_sum / sumsq                      worker.py:156-157,191,207-209 ; loss.py:9-24 ; cnn.py:40-41
+//   adam          torch.optim.Adam(betas=(0,0.99), eps=1e-8)          worker.py:98-110
+//   ema           Ema.update                                          ema.py:19-32
+//   avg_latent    truncation-trick running mean                       cnn.py:95-97
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int MT = 32;     // rows of the small-M GEMMs handled per block
+
+// y[m,o] = act(scale * sum_i x[m,i] w[o,i] + bias[o]*bias_scale) * gain     one wave per output column o
+__global__ __launch_bounds__(TPB) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          int M, int I, int O, float scale, float bias_scale, int act, float gain) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int o = blockIdx.x * 4 + wid, m0 = blockIdx.y * MT;
+  if (o >= O) return;
+  const int mc = min(MT, M - m0);
+  float acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+  const float* wr = w + (size_t)o * I;
+  for (int i = lane; i < I; i += 64) {
+    const float wv = wr[i];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+      if (m < mc) acc[m] += x[(size_t)(m0 + m) * I + i] * wv;
+  }
+  const float bv = bias ? bias[o] * bias_scale : 0.f;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    if (m < mc) {
+      const float t = wave_sum(acc[m]);
+      if (lane == 0) y[(size_t)(m0 + m) * O + o] = act_fwd(t * scale + bv, act) * gain;
+    }
+  }
+}
+
+// gx[m,i] += scale * sum_{o in chunk} gy[m,o] w[o,i]         (gx zeroed by the caller; fp32 atomics across O chunks)
+__global__ __launch_bounds__(TPB) void linear_bwd_data_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                               float* __restrict__ gx, int M, int I, int O, float scale, int ochunk) {
+  const int i = blockIdx.x * TPB + threadIdx.x, m0 = blockIdx.y * MT;
+  const int o0 = blockIdx.z * ochunk, o1 = min(o0 + ochunk, O);
+  if (i >= I) return;
+  const int mc = min(MT, M - m0);
+  float acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+  for (int o = o0; o < o1; ++o) {
+    const float wv = w[(size_t)o * I + i];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+      if (m < mc) acc[m] += gy[(size_t)(m0 + m) * O + o] * wv;
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+    if (m < mc) atomicAdd(gx + (size_t)(m0 + m) * I + i, acc[m] * scale);
+}
+
+// gw[o,i] = scale * sum_m gy[m,o] x[m,i]
+__global__ __launch_bounds__(TPB) void linear_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                            float* __restrict__ gw, int M, int I, int O, float scale) {
+  const int i = blockIdx.x * TPB + threadIdx.x, o = blockIdx.y;
+  if (i >= I) return;
+  float acc = 0.f;
+  for (int m = 0; m < M; ++m) acc += gy[(size_t)m * O + o] * x[(size_t)m * I + i];
+  gw[(size_t)o * I + i] = acc * scale;
+}
+
+// gb[o] = bias_scale * sum_m gy[m,o]
+__global__ void colsum_kernel(const float* __restrict__ gy, float* __restrict__ gb, int M, int O, float scale) {
+  const int o = blockIdx.x * TPB + threadIdx.x;
+  if (o >= O) return;
+  float acc = 0.f;
+  for (int m = 0; m < M; ++m) acc += gy[(size_t)m * O + o];
+  gb[o] = acc * scale;
+}
+
+// gz = gy * act'(y)   on fp32 vectors
+__global__ void act_bwd_f32_kernel(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ gz,
+                                   long long n, int act, float gain) {
+  const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) gz[i] = gy[i] * act_grad_from_out(y[i], act, gain);
+}
+
+// d[b,o] = rsqrt(sum_c s[b,c]^2 wsq[o,c] + eps)       one wave per (b,o); d is [B][Os] (Os >= O alloc stride)
+__global__ void demod_fwd_kernel(const float* __restrict__ s, const float* __restrict__ wsq, float* __restrict__ d,
+                                 int B, int C, int O, int Os, float eps) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int o = blockIdx.x * 4 + wid, b = blockIdx.y;
+  if (o >= O) return;
+  float acc = 0.f;
+  for (int c = lane; c < C; c += 64) { const float sv = s[(size_t)b * C + c]; acc += sv * sv * wsq[(size_t)o * C + c]; }
+  acc = wave_sum(acc);
+  if (lane == 0) d[(size_t)b * Os + o] = rsqrtf(acc + eps);
+}
+// gq[b,o] = -0.5 * gdq[b,o] * d[b,o]^2 ;  gs[b,c] += 2 s[b,c] sum_o gq[b,o] wsq[o,c]
+__global__ void demod_bwd_s_kernel(const float* __restrict__ gdq, const float* __restrict__ d, const float* __restrict__ s,
+                                   const float* __restrict__ wsq, float* __restrict__ gs, int B, int C, int O, int Os) {
+  const int c = blockIdx.x * TPB + threadIdx.x, b = blockIdx.y;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int o = 0; o < O; ++o) {
+    const float dv = d[(size_t)b * Os + o];
+    acc += -0.5f * gdq[(size_t)b * Os + o] * dv * dv * wsq[(size_t)o * C + c];
+  }
+  gs[(size_t)b * C + c] += 2.f * s[(size_t)b * C + c] * acc;
+}
+// gwsq[o,c] = sum_b gq[b,o] s[b,c]^2
+__global__ void demod_bwd_w_kernel(const float* __restrict__ gdq, const float* __restrict__ d, const float* __restrict__ s,
+                                   float* __restrict__ gwsq, int B, int C, int O, int Os) {
+  const int c = blockIdx.x * TPB + threadIdx.x, o = blockIdx.y;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float dv = d[(size_t)b * Os + o], sv = s[(size_t)b * C + c];
+    acc += -0.5f * gdq[(size_t)b * Os + o] * dv * dv * sv * sv;
+  }
+  gwsq[(size_t)o * C + c] = acc;
+}
+
+// ---- single-block loss kernels ---------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum256(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ float softplusf(float t) { return t > 20.f ? t : log1pf(expf(t)); }
+__device__ __forceinline__ float sigmoidf(float t) { return 1.f / (1.f + expf(-t)); }
+
+// out = mean_i softplus(sign * logit_i), sign = -1 for target 1, +1 for target 0   (BCE with logits)
+__global__ void bce_fwd_kernel(const float* __restrict__ logit, int n, float sign, float* __restrict__ out) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += TPB) acc += softplusf(sign * logit[i]);
+  const float t = block_sum256(acc, sh);
+  if (threadIdx.x == 0) out[0] = t / (float)n;
+}
+__global__ void bce_bwd_kernel(const float* __restrict__ logit, int n, float sign, const float* __restrict__ gout,
+                               float* __restrict__ g) {
+  const int i = blockIdx.x * TPB + threadIdx.x;
+  if (i < n) g[i] = gout[0] * sign * sigmoidf(sign * logit[i]) / (float)n;
+}
+
+// loss = mean_b softplus((a.n - a.p) / tau)   ; t[b] saved for backward
+__global__ void contrastive_fwd_kernel(const float* __restrict__ a, const float* __restrict__ p, const float* __restrict__ n,
+                                       int B, int D, float tau, float* __restrict__ tsave, float* __restrict__ out) {
+  __shared__ float sh[4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float acc = 0.f;
+  for (int b = wid; b < B; b += 4) {
+    float dp = 0.f, dn = 0.f;
+    for (int j = lane; j < D; j += 64) { const float av = a[(size_t)b * D + j]; dp += av * p[(size_t)b * D + j]; dn += av * n[(size_t)b * D + j]; }
+    dp = wave_sum(dp); dn = wave_sum(dn);
+    const float t = (dn - dp) / tau;
+    if (lane == 0) { tsave[b] = t; acc += softplusf(t); }
+  }
+  const float tot = block_sum256(acc, sh);
+  if (threadIdx.x == 0) out[0] = tot / (float)B;
+}
+__global__ void contrastive_bwd_kernel(const float* __restrict__ a, const float* __restrict__ p, const float* __restrict__ n,
+                                       const float* __restrict__ tsave, const float* __restrict__ gout, int B, int D, float tau,
+                                       float* __restrict__ ga, float* __restrict__ gp, float* __restrict__ gn) {
+  const int idx = blockIdx.x * TPB + threadIdx.x;
+  if (idx >= B * D) return;
+  const int b = idx / D;
+  const float k = gout[0] * sigmoidf(tsave[b]) / ((float)B * tau);
+  ga[idx] = k * (n[idx] - p[idx]);
+  gp[idx] = -k * a[idx];
+  gn[idx] = k * a[idx];
+}
+
+// y = x / max(||x||_2, eps) per row ; norm saved
+__global__ void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ nsave, int B, int D, float eps) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float acc = 0.f;
+  for (int j = lane; j < D; j += 64) { const float v = x[(size_t)b * D + j]; acc += v * v; }
+  const float nr = fmaxf(sqrtf(wave_sum(acc)), eps);
+  for (int j = lane; j < D; j += 64) y[(size_t)b * D + j] = x[(size_t)b * D + j] / nr;
+  if (lane == 0) nsave[b] = nr;
+}
+__global__ void l2norm_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ nsave,
+                                  float* __restrict__ gx, int B, int D) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float acc = 0.f;
+  for (int j = lane; j < D; j += 64) acc += gy[(size_t)b * D + j] * y[(size_t)b * D + j];
+  acc = wave_sum(acc);
+  const float inv = 1.f / nsave[b];
+  for (int j = lane; j < D; j += 64) gx[(size_t)b * D + j] = (gy[(size_t)b * D + j] - y[(size_t)b * D + j] * acc) * inv;
+}
+
+// out += coef * sum |x|^pw (pw = 1: abs, 2: square), multi-block with one atomic per block (out zeroed by the caller)
+__global__ void powsum_kernel(const float* __restrict__ x, long long n, int pw, float coef, float* __restrict__ out) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) {
+    const float v = x[i];
+    acc += pw == 1 ? fabsf(v) : v * v;
+  }
+  const float t = block_sum256(acc, sh);
+  if (threadIdx.x == 0) atomicAdd(out, t * coef);
+}
+// g = gout * coef * (pw == 1 ? sign(x) : 2 x)
+__global__ void powsum_bwd_kernel(const float* __restrict__ x, long long n, int pw, float coef, const float* __restrict__ gout,
+                                  float* __restrict__ g) {
+  const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const float v = x[i];
+  g[i] = gout[0] * coef * (pw == 1 ? (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f)) : 2.f * v);
+}
+
+// avg[d] <- mean_b w[b,d] + beta * (avg[d] - mean_b w[b,d])
+__global__ void avg_latent_kernel(const float* __restrict__ w, float* __restrict__ avg, int B, int D, float beta) {
+  const int d = blockIdx.x * TPB + threadIdx.x;
+  if (d >= D) return;
+  float m = 0.f;
+  for (int b = 0; b < B; ++b) m += w[(size_t)b * D + d];
+  m /= (float)B;
+  avg[d] = m + beta * (avg[d] - m);
+}
+
+// ---- multi-tensor kernels: one launch walks a device table of tensors in 64K-element chunks ----------------
+struct MTDesc { void* p0; void* p1; void* p2; void* p3; long long n; float f0; float f1; };
+constexpr int MT_CHUNK = 65536;
+#define MT_ADAM 0
+#define MT_EMA 1
+#define MT_PACK 2
+
+__global__ __launch_bounds__(TPB) void multi_tensor_kernel(const MTDesc* __restrict__ descs, const int* __restrict__ chunk_tensor,
+                                                            const int* __restrict__ chunk_index, int op,
+                                                            float a0, float a1, float a2) {
+  const int t = chunk_tensor[blockIdx.x];
+  const MTDesc d = descs[t];
+  const long long base = (long long)chunk_index[blockIdx.x] * MT_CHUNK;
+  const long long end = min(base + MT_CHUNK, d.n);
+  if (op == MT_ADAM) {         // a0 = beta1, a1 = beta2, a2 = eps ; f0 = lr / bias_correction1, f1 = 1 / sqrt(bias_correction2)
+    float* p = (float*)d.p0; const float* g = (const float*)d.p1; float* m = (float*)d.p2; float* v = (float*)d.p3;
+    for (long long i = base + threadIdx.x; i < end; i += TPB) {
+      const float gi = g[i];
+      const float mi = a0 * m[i] + (1.f - a0) * gi;
+      const float vi = a1 * v[i] + (1.f - a1) * gi * gi;
+      m[i] = mi; v[i] = vi;
+      p[i] -= d.f0 * mi / (sqrtf(vi) * d.f1 + a2);
+    }
+  } else if (op == MT_EMA) {   // p0 = ema (target), p1 = source ; a0 = decay
+    float* pe = (float*)d.p0; const float* ps = (const float*)d.p1;
+    for (long long i = base + threadIdx.x; i < end; i += TPB) { const float sv = ps[i]; pe[i] = sv + a0 * (pe[i] - sv); }
+  } else {                     // MT_PACK: p0 = dst, p1 = src ; a0 = scale
+    float* dst = (float*)d.p0; const float* src = (const float*)d.p1;
+    for (long long i = base + threadIdx.x; i < end; i += TPB) dst[i] = src[i] * a0;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int lcgan_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int I, int O,
+                     float scale, float bias_scale, int act, float gain, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (M <= 0) return LCGAN_EINVAL;
+  ProfScope p(KID_LINEAR, 2.0 * M * I * O, 4.0 * I * O, s);
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(cdiv(O, 4), cdiv(M, MT)), dim3(TPB), 0, s, x, w, bias, y, M, I, O, scale, bias_scale, act, gain);
+  return launch_status();
+}
+// gx must be zeroed by the caller
+int lcgan_linear_bwd_data(const float* gy, const float* w, float* gx, int M, int I, int O, float scale, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (M <= 0) return LCGAN_EINVAL;
+  const int ochunk = 64;
+  ProfScope p(KID_LINEAR, 2.0 * M * I * O, 4.0 * I * O, s);
+  hipLaunchKernelGGL(linear_bwd_data_kernel, dim3(cdiv(I, TPB), cdiv(M, MT), cdiv(O, ochunk)), dim3(TPB), 0, s, gy, w, gx, M, I, O, scale, ochunk);
+  return launch_status();
+}
+int lcgan_linear_wgrad(const float* gy, const float* x, float* gw, int M, int I, int O, float scale, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(KID_LINEAR, 2.0 * M * I * O, 4.0 * I * O, s);
+  hipLaunchKernelGGL(linear_wgrad_kernel, dim3(cdiv(I, TPB), O), dim3(TPB), 0, s, gy, x, gw, M, I, O, scale);
+  return launch_status();
+}
+int lcgan_colsum(const float* gy, float* gb, int M, int O, float scale, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(KID_SMALL, 0, 0, s);
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(O, TPB)), dim3(TPB), 0, s, gy, gb, M, O, scale);
+  return launch_status();
+}
+int lcgan_act_bwd_f32(const float* gy, const float* y, float* gz, long long n, int act, float gain, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(KID_SMALL, 0, 0, s);
+  hipLaunchKernelGGL(act_bwd_f32_kernel, dim3(cdiv(n, TPB)), dim3(TPB), 0, s, gy, y, gz, n, act, gain);
+  return launch_status();
+}
+
+int lcgan_demod_fwd(const float* sv, const float* wsq, float* d, int B, int C, int O, int Os, float eps, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(KID_SMALL, 0, 0, s);
+  hipLaunchKernelGGL(demod_fwd_kernel, dim3(cdiv(O, 4), B), dim3(TPB), 0, s, sv, wsq, d, B, C, O, Os, eps);
+  return launch_status();
+}
+// gs[b,c] += (demod path) ; gwsq[o,c] = (demod path).  gdq is the raw reduction of lcgan_act_bwd_reduce.
+int lcgan_demod_bwd(const float* gdq, const float* d, const float* sv, const float* wsq, float* gs, float* gwsq,
+                    int B, int C, int O, int Os, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(KID_SMALL, 0, 0, s);
+  hipLaunchKernelGGL(demod_bwd_s_kernel, dim3(cdiv(C, TPB), B), dim3(TPB), 0, s, gdq, d, sv, wsq, gs, B, C, O, Os);
+  hipLaunchKernelGGL(demod_bwd_w_kernel, dim3(cdiv(C, TPB), O), dim3(TPB), 0, s, gdq, d, sv, gwsq, B, C, O, Os);
+  return launch_status();
+}
+
+int lcgan_bce_fwd(const float* logit, int n, int target_one, float* out, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(KID_SMALL, 0, 0, s);
+  hipLaunchKernelGGL(bce_fwd_kernel, dim3(1), dim3(TPB), 0, s, logit, n, target_one ? -1.f : 1.f, out);
+  return launch_status();
+}
+int lcgan_bce_bwd(const float* logit, int n, int target_one, const float* gout, float* g, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(KID_SMALL, 0, 0, s);
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3(cdiv(n, TPB)), dim3(TPB), 0, s, logit, n, target_one ? -1.f : 1.f, gout, g);
+  return launch_status();
+}
+int lcgan_contrastive_fwd(const float* a, const float* pp, const float* n, int B, int D, float tau, float* tsave, float* out, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(KID_SMALL, 0, 0, s);
+  hipLaunchKernelGGL(contrastive_fwd_kernel, dim3(1), dim3(TPB), 0, s, a, pp, n, B, D, tau, tsave, out);
+  return launch_status();
+}
+int lcgan_contrastive_bwd(const float* a, const float* pp, const float* n, const float* tsave, const float* gout,
+                          int B, int D, float tau, float* ga, float* gp, float* gn, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(KID_SMALL, 0, 0, s);
+  hipLaunchKernelGGL(contrastive_bwd_kernel, dim3(cdiv((long long)B * D, TPB)), dim3(TPB), 0, s, a, pp, n, tsave, gout, B, D, tau, ga, gp, gn);
+  return launch_status();
+}
+int lcgan_l2norm_fwd(const float* x, float* y, float* nsave, int B, int D, float eps, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(KID_SMALL, 0, 0, s);
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(cdiv(B, 4)), dim3(TPB), 0, s, x, y, nsave, B, D, eps);
+  return launch_status();
+}
+int lcgan_l2norm_bwd(const float* gy, const float* y, const float* nsave, float* gx, int B, int D, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(KID_SMALL, 0, 0, s);
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(cdiv(B, 4)), dim3(TPB), 0, s, gy, y, nsave, gx, B, D);
+  return launch_status();
+}
+// out[0] += coef * sum |x|^pw   (out zeroed by the caller)
+int lcgan_powsum(const float* x, long long n, int pw, float coef, float* out, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (pw != 1 && pw != 2) return LCGAN_EINVAL;
+  ProfScope p(KID_SMALL, 0, 4.0 * n, s);
+  const int blocks = (int)min((long long)1024, (n + TPB - 1) / TPB);
+  hipLaunchKernelGGL(powsum_kernel, dim3(blocks), dim3(TPB), 0, s, x, n, pw, coef, out);
+  return launch_status();
+}
+int lcgan_powsum_bwd(const float* x, long long n, int pw, float coef, const float* gout, float* g, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(KID_SMALL, 0, 8.0 * n, s);
+  hipLaunchKernelGGL(powsum_bwd_kernel, dim3(cdiv(n, TPB)), dim3(TPB), 0, s, x, n, pw, coef, gout, g);
+  return launch_status();
+}
+int lcgan_avg_latent(const float* w, float* avg, int B, int D, float beta, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(KID_SMALL, 0, 0, s);
+  hipLaunchKernelGGL(avg_latent_kernel, dim3(cdiv(D, TPB)), dim3(TPB), 0, s, w, avg, B, D, beta);
+  return launch_status();
+}
+
+// descs: device array of {p0,p1,p2,p3 (8 B each), n (8 B), f0, f1 (4 B each)} = 48 B per tensor;
+// chunk_tensor / chunk_index: device int arrays, one entry per 65536-element chunk.
+//   op 0 (Adam): p0 param, p1 grad, p2 exp_avg, p3 exp_avg_sq, f0 = lr/bias_corr1, f1 = 1/sqrt(bias_corr2); a0,a1,a2 = beta1,beta2,eps
+//   op 1 (EMA):  p0 target, p1 source; a0 = decay           op 2 (pack): p0 dst, p1 src; a0 = scale
+int lcgan_multi_tensor(const void* descs, const int* chunk_tensor, const int* chunk_index, int n_chunks, int op,
+                       float a0, float a1, float a2, double total_elems, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n_chunks <= 0) return LCGAN_OK;
+  if (op < 0 || op > 2) return LCGAN_EINVAL;
+  const double bpe = op == MT_ADAM ? 28.0 : (op == MT_EMA ? 12.0 : 8.0);
+  ProfScope p(KID_OPTIM, 0, bpe * total_elems, s);
+  hipLaunchKernelGGL(multi_tensor_kernel, dim3(n_chunks), dim3(TPB), 0, s, (const MTDesc*)descs, chunk_tensor, chunk_index, op, a0, a1, a2);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,853 @@
+// NHWC stencil / elementwise / gather kernels of the LC-GAN step for gfx950.  All are HBM-bound: every thread
+// moves one 8-channel vector (16 B of bf16 / 32 B of f32), consecutive lanes walk consecutive channel vectors of
+// a pixel, so every wave access is a run of whole 16-byte lanes.
+//
+// Reference ops replaced (file:line in /root/reference):
+//   box3_act        F.avg_pool2d(3,1,1) [+ leaky_relu*gain | tanh]     custom_layers.py:136-138,150-155,196-206
+//   up2box          F.interpolate(x2 nearest) + box filter             custom_layers.py:146-147
+//   avgpool2        F.avg_pool2d(2,2)                                  custom_layers.py:202
+//   act_bwd_reduce  leaky_relu backward + bias / demod-statistic sums  (autograd of :85, :155, :158, :205, :208)
+//   scale_reduce    style gradient  sum_p x * u                        (autograd of :62-64)
+//   warp            F.grid_sample(bicubic, zeros, align_corners=False) custom_layers.py:127-134,162-165
+//   mbstd           MinibatchStdLayer                                  custom_layers.py:243-256
+//   rgb_*           1x1 convs touching the 3-channel NCHW image        cnn.py:20 ; custom_layers.py:175,181
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+static inline dim3 grid1d(long long n) { return dim3((unsigned)((n + TPB - 1) / TPB)); }
+
+// ------------------------------------------------------------------------------------------------------------
+// box filter (3x3 mean, zero padding, always /9) fused with activation
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void box3_act_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int act, float gain) {
+  const int nvec = C >> 3;
+  const long long total = (long long)B * H * W * nvec;
+  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (gid >= total) return;
+  const int v = (int)(gid % nvec);
+  const long long pix = gid / nvec;
+  const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+  F8 s = f8_zero();
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy) {
+    const int yy = h + dy;
+    if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int xx = w + dx;
+      if ((unsigned)xx >= (unsigned)W) continue;
+      const F8 t = Feat<T>::load(x + (((size_t)b * H + yy) * W + xx) * C + v * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s.v[j] += t.v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s.v[j] = act_fwd(s.v[j] * (1.f / 9.f), act) * gain;
+  Feat<T>::store(y + (size_t)pix * C + v * 8, s);
+}
+
+// gx = box3(gy * act'(y))   (box3 is self-adjoint)
+template <typename T>
+__global__ void box3_act_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ y, T* __restrict__ gx,
+                                    int B, int H, int W, int C, int act, float gain) {
+  const int nvec = C >> 3;
+  const long long total = (long long)B * H * W * nvec;
+  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (gid >= total) return;
+  const int v = (int)(gid % nvec);
+  const long long pix = gid / nvec;
+  const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+  F8 s = f8_zero();
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy) {
+    const int yy = h + dy;
+    if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int xx = w + dx;
+      if ((unsigned)xx >= (unsigned)W) continue;
+      const size_t off = (((size_t)b * H + yy) * W + xx) * C + v * 8;
+      const F8 g = Feat<T>::load(gy + off);
+      if (act == ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s.v[j] += g.v[j] * gain;
+      } else {
+        const F8 yo = Feat<T>::load(y + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s.v[j] += g.v[j] * act_grad_from_out(yo.v[j], act, gain);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s.v[j] *= (1.f / 9.f);
+  Feat<T>::store(gx + (size_t)pix * C + v * 8, s);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// nearest x2 upsample followed by the box filter == separable taps {1,2}/3 ; fused residual add
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void up2box_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                              int B, int H, int W, int C) {   // x: [B,H,W,C] -> y: [B,2H,2W,C]
+  const int nvec = C >> 3, H2 = 2 * H, W2 = 2 * W;
+  const long long total = (long long)B * H2 * W2 * nvec;
+  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (gid >= total) return;
+  const int v = (int)(gid % nvec);
+  const long long pix = gid / nvec;
+  const int X = (int)(pix % W2), Y = (int)((pix / W2) % H2), b = (int)(pix / ((long long)W2 * H2));
+  // output row Y=2i: (x[i-1] + 2 x[i]) / 3 ; Y=2i+1: (2 x[i] + x[i+1]) / 3
+  const int i = Y >> 1, j = X >> 1;
+  const int i2 = (Y & 1) ? i + 1 : i - 1, j2 = (X & 1) ? j + 1 : j - 1;
+  F8 s = f8_zero();
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int yy = a ? i2 : i;
+    if ((unsigned)yy >= (unsigned)H) continue;
+    const float wy = a ? (1.f / 3.f) : (2.f / 3.f);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int xx = c ? j2 : j;
+      if ((unsigned)xx >= (unsigned)W) continue;
+      const float wgt = wy * (c ? (1.f / 3.f) : (2.f / 3.f));
+      const F8 t = Feat<T>::load(x + (((size_t)b * H + yy) * W + xx) * C + v * 8);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s.v[q] += t.v[q] * wgt;
+    }
+  }
+  const size_t off = (size_t)pix * C + v * 8;
+  if (res) {
+    const F8 r = Feat<T>::load(res + off);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s.v[q] += r.v[q];
+  }
+  Feat<T>::store(y + off, s);
+}
+
+template <typename T>
+__global__ void up2box_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, int B, int H, int W, int C) {
+  // gy: [B,2H,2W,C] -> gx: [B,H,W,C];  x[i] feeds rows 2i-1 (1/3), 2i (2/3), 2i+1 (2/3), 2i+2 (1/3)
+  const int nvec = C >> 3, H2 = 2 * H, W2 = 2 * W;
+  const long long total = (long long)B * H * W * nvec;
+  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (gid >= total) return;
+  const int v = (int)(gid % nvec);
+  const long long pix = gid / nvec;
+  const int j = (int)(pix % W), i = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+  F8 s = f8_zero();
+#pragma unroll
+  for (int a = -1; a <= 2; ++a) {
+    const int Y = 2 * i + a;
+    if ((unsigned)Y >= (unsigned)H2) continue;
+    const float wy = (a == 0 || a == 1) ? (2.f / 3.f) : (1.f / 3.f);
+#pragma unroll
+    for (int c = -1; c <= 2; ++c) {
+      const int X = 2 * j + c;
+      if ((unsigned)X >= (unsigned)W2) continue;
+      const float wgt = wy * ((c == 0 || c == 1) ? (2.f / 3.f) : (1.f / 3.f));
+      const F8 t = Feat<T>::load(gy + (((size_t)b * H2 + Y) * W2 + X) * C + v * 8);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s.v[q] += t.v[q] * wgt;
+    }
+  }
+  Feat<T>::store(gx + (size_t)pix * C + v * 8, s);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// 2x2 average pool and its adjoint
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void avgpool2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {  // y: [B,H/2,W/2,C]
+  const int nvec = C >> 3, Ho = H >> 1, Wo = W >> 1;
+  const long long total = (long long)B * Ho * Wo * nvec;
+  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (gid >= total) return;
+  const int v = (int)(gid % nvec);
+  const long long pix = gid / nvec;
+  const int j = (int)(pix % Wo), i = (int)((pix / Wo) % Ho), b = (int)(pix / ((long long)Wo * Ho));
+  F8 s = f8_zero();
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const F8 t = Feat<T>::load(x + (((size_t)b * H + 2 * i + a) * W + 2 * j + c) * C + v * 8);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s.v[q] += t.v[q];
+    }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) s.v[q] *= 0.25f;
+  Feat<T>::store(y + (size_t)pix * C + v * 8, s);
+}
+
+template <typename T>
+__global__ void avgpool2_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, int B, int H, int W, int C) {  // gx: [B,H,W,C]
+  const int nvec = C >> 3, Ho = H >> 1, Wo = W >> 1;
+  const long long total = (long long)B * H * W * nvec;
+  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (gid >= total) return;
+  const int v = (int)(gid % nvec);
+  const long long pix = gid / nvec;
+  const int X = (int)(pix % W), Y = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+  F8 t = Feat<T>::load(gy + (((size_t)b * Ho + (Y >> 1)) * Wo + (X >> 1)) * C + v * 8);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) t.v[q] *= 0.25f;
+  Feat<T>::store(gx + (size_t)pix * C + v * 8, t);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// activation backward fused with the per-channel reductions that consume the same bytes:
+//   gz        = gy * act'(y)                                          (written when gz != nullptr)
+//   gbias[c] += sum_{b,p} gz                                           (optional)
+//   gdq[b,c] += sum_p gz * (ypre - bias[c]*bias_scale),  ypre = act^-1(y / gain)   (optional: demod gradient)
+// One block = P consecutive pixels of ONE sample; a thread keeps one channel vector in registers.
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void act_bwd_reduce_kernel(const T* __restrict__ gy, const T* __restrict__ y, T* __restrict__ gz,
+                                      const float* __restrict__ bias, float bias_scale,
+                                      float* __restrict__ gbias, float* __restrict__ gdq,
+                                      int HW, int C, int Clog, int act, float gain, int P) {
+  __shared__ float red[2][TPB * 8];
+  const int nvec = C >> 3;
+  const int groups = TPB / nvec;                       // pixel groups running in parallel (>= 1; nvec <= 256)
+  const int grp = threadIdx.x / nvec, v = threadIdx.x - grp * nvec;
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * P, p1 = min(p0 + P, HW);
+  const bool active = grp < groups;
+  float sb[8], sq[8], bv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sb[j] = 0.f; sq[j] = 0.f; bv[j] = 0.f; }
+  if (active && bias && gdq) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = (v * 8 + j < Clog) ? bias[v * 8 + j] * bias_scale : 0.f;
+  }
+  if (active) {
+    for (int p = p0 + grp; p < p1; p += groups) {
+      const size_t off = ((size_t)b * HW + p) * C + v * 8;
+      const F8 g = Feat<T>::load(gy + off);
+      F8 yo = f8_zero();
+      if (act != ACT_NONE || gdq) yo = Feat<T>::load(y + off);
+      F8 z;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        z.v[j] = g.v[j] * act_grad_from_out(yo.v[j], act, gain);
+        sb[j] += z.v[j];
+        float t = yo.v[j] / gain;
+        if (act == ACT_LRELU && t < 0.f) t *= (1.f / LRELU_SLOPE);
+        sq[j] += z.v[j] * (t - bv[j]);
+      }
+      if (gz) Feat<T>::store(gz + off, z);
+    }
+  }
+  if (!gbias && !gdq) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[0][threadIdx.x * 8 + j] = sb[j]; red[1][threadIdx.x * 8 + j] = sq[j]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += TPB) {
+    const int vv = c >> 3, jj = c & 7;
+    float tb = 0.f, tq = 0.f;
+    for (int gI = 0; gI < groups; ++gI) { const int t = gI * nvec + vv; tb += red[0][t * 8 + jj]; tq += red[1][t * 8 + jj]; }
+    if (gbias && c < Clog) atomicAdd(gbias + c, tb);
+    if (gdq) atomicAdd(gdq + (size_t)b * C + c, tq);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// style-gradient reduction fused with the modulation scale of the data gradient:
+//   gs[b,c] += sum_p x[b,p,c] * u[b,p,c] ;   u[b,p,c] <- s[b,c] * u[b,p,c]   (in place)
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void scale_reduce_kernel(T* __restrict__ u, const T* __restrict__ x, const float* __restrict__ s,
+                                    float* __restrict__ gs, int HW, int C, int P) {
+  __shared__ float red[TPB * 8];
+  const int nvec = C >> 3;
+  const int groups = TPB / nvec;
+  const int grp = threadIdx.x / nvec, v = threadIdx.x - grp * nvec;
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * P, p1 = min(p0 + P, HW);
+  const bool active = grp < groups;
+  float acc[8], sv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { acc[j] = 0.f; sv[j] = 0.f; }
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sv[j] = s[(size_t)b * C + v * 8 + j];
+    for (int p = p0 + grp; p < p1; p += groups) {
+      const size_t off = ((size_t)b * HW + p) * C + v * 8;
+      F8 uu = Feat<T>::load(u + off);
+      const F8 xx = Feat<T>::load(x + off);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { acc[j] += uu.v[j] * xx.v[j]; uu.v[j] *= sv[j]; }
+      Feat<T>::store(u + off, uu);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = acc[j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += TPB) {
+    const int vv = c >> 3, jj = c & 7;
+    float t = 0.f;
+    for (int gI = 0; gI < groups; ++gI) t += red[(gI * nvec + vv) * 8 + jj];
+    atomicAdd(gs + (size_t)b * C + c, t);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// bicubic feature warp (grid_sample: bicubic, zero padding, align_corners=False sampling of a grid whose base
+// coordinates use the align_corners=True formula -- custom_layers.py:127-134,162-165)
+// ------------------------------------------------------------------------------------------------------------
+constexpr float CUBIC_A = -0.75f;
+__device__ __forceinline__ float cc1(float x) { return ((CUBIC_A + 2.f) * x - (CUBIC_A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cc2(float x) { return ((CUBIC_A * x - 5.f * CUBIC_A) * x + 8.f * CUBIC_A) * x - 4.f * CUBIC_A; }
+__device__ __forceinline__ float dcc1(float x) { return (3.f * (CUBIC_A + 2.f) * x - 2.f * (CUBIC_A + 3.f)) * x; }
+__device__ __forceinline__ float dcc2(float x) { return (3.f * CUBIC_A * x - 10.f * CUBIC_A) * x + 8.f * CUBIC_A; }
+__device__ __forceinline__ void cubic_coeffs(float t, float c[4]) {
+  c[0] = cc2(t + 1.f); c[1] = cc1(t); c[2] = cc1(1.f - t); c[3] = cc2(2.f - t);
+}
+__device__ __forceinline__ void cubic_dcoeffs(float t, float d[4]) {   // d c[k] / d t
+  d[0] = dcc2(t + 1.f); d[1] = dcc1(t); d[2] = -dcc1(1.f - t); d[3] = -dcc2(2.f - t);
+}
+template <typename T>
+__device__ __forceinline__ void warp_coords(const T* flow, size_t pix, int h, int w, int H, int W, float scale,
+                                            float& ix, float& iy) {
+  const float fx = Feat<T>::ld1(flow + pix * 8), fy = Feat<T>::ld1(flow + pix * 8 + 1);
+  const float gx = 2.f * (float)w / (float)(W - 1) - 1.f + fx * scale;
+  const float gy = 2.f * (float)h / (float)(H - 1) - 1.f + fy * scale;
+  ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+  iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+}
+
+template <typename T>
+__global__ void warp_fwd_kernel(const T* __restrict__ x, const T* __restrict__ flow, T* __restrict__ y,
+                                int B, int H, int W, int C, float scale) {
+  const int nvec = C >> 3;
+  const long long total = (long long)B * H * W * nvec;
+  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (gid >= total) return;
+  const int v = (int)(gid % nvec);
+  const long long pix = gid / nvec;
+  const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+  float ix, iy;
+  warp_coords<T>(flow, (size_t)pix, h, w, H, W, scale, ix, iy);
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  float cx[4], cy[4];
+  cubic_coeffs(ix - fx0, cx);
+  cubic_coeffs(iy - fy0, cy);
+  const int x0 = (int)fx0 - 1, y0 = (int)fy0 - 1;
+  F8 s = f8_zero();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int yy = y0 + i;
+    if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int xx = x0 + j;
+      if ((unsigned)xx >= (unsigned)W) continue;
+      const float wgt = cy[i] * cx[j];
+      const F8 t = Feat<T>::load(x + (((size_t)b * H + yy) * W + xx) * C + v * 8);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s.v[q] += t.v[q] * wgt;
+    }
+  }
+  Feat<T>::store(y + (size_t)pix * C + v * 8, s);
+}
+
+// gx32 (fp32, zero-initialised) receives the scatter through float atomics; gflow[b,h,w,0:2] the grid gradient.
+template <typename T>
+__global__ void warp_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ flow,
+                                float* __restrict__ gx32, T* __restrict__ gflow,
+                                int B, int H, int W, int C, float scale) {
+  const int nvec = C >> 3;                                   // power of two, <= 64 (checked by the launcher)
+  const long long total = (long long)B * H * W * nvec;
+  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
+  const bool live = gid < total;
+  const long long gg = live ? gid : total - 1;
+  const int v = (int)(gg % nvec);
+  const long long pix = gg / nvec;
+  const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+  float ix, iy;
+  warp_coords<T>(flow, (size_t)pix, h, w, H, W, scale, ix, iy);
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  float cx[4], cy[4], dx[4], dy[4];
+  cubic_coeffs(ix - fx0, cx); cubic_coeffs(iy - fy0, cy);
+  cubic_dcoeffs(ix - fx0, dx); cubic_dcoeffs(iy - fy0, dy);
+  const int x0 = (int)fx0 - 1, y0 = (int)fy0 - 1;
+  F8 g = f8_zero();
+  if (live) g = Feat<T>::load(gy + (size_t)pix * C + v * 8);
+  float gix = 0.f, giy = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int yy = y0 + i;
+    if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int xx = x0 + j;
+      if ((unsigned)xx >= (unsigned)W) continue;
+      const size_t off = (((size_t)b * H + yy) * W + xx) * C + v * 8;
+      const F8 t = Feat<T>::load(x + off);
+      float dot = 0.f;
+      const float wgt = cy[i] * cx[j];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        dot += t.v[q] * g.v[q];
+        if (live) atomicAdd(gx32 + off + q, g.v[q] * wgt);
+      }
+      gix += dot * cy[i] * dx[j];
+      giy += dot * dy[i] * cx[j];
+    }
+  }
+  // reduce the grid gradient over the nvec lanes that share this pixel (they are adjacent lanes of one wave)
+  for (int o = nvec >> 1; o > 0; o >>= 1) { gix += __shfl_xor(gix, o, 64); giy += __shfl_xor(giy, o, 64); }
+  if (live && v == 0) {
+    F8 o = f8_zero();
+    o.v[0] = gix * (0.5f * (float)W) * scale;
+    o.v[1] = giy * (0.5f * (float)H) * scale;
+    Feat<T>::store(gflow + (size_t)pix * 8, o);
+  }
+}
+
+template <typename T>
+__global__ void cast_f32_kernel(const float* __restrict__ src, T* __restrict__ dst, long long nvec8) {
+  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (gid >= nvec8) return;
+  Feat<T>::store(dst + gid * 8, Feat<float>::load(src + gid * 8));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// minibatch standard deviation (group G = min(8, N), STRIDED grouping: sample n = g*M + m shares group m)
+// x: [N,H,W,C] -> y: [N,H,W,Cy], channel C = stat[m], channels > C zero.   One block per m.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wid] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+  return t;
+}
+
+template <typename T>
+__global__ void mbstd_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int G, int HW, int C, int Cy) {
+  __shared__ float sh[8];
+  const int M = N / G, m = blockIdx.x, I = HW * C;
+  float part = 0.f;
+  for (int i = threadIdx.x; i < I; i += blockDim.x) {
+    float mu = 0.f;
+    for (int g = 0; g < G; ++g) mu += Feat<T>::ld1(x + (size_t)(g * M + m) * I + i);
+    mu /= (float)G;
+    float var = 0.f;
+    for (int g = 0; g < G; ++g) { const float e = Feat<T>::ld1(x + (size_t)(g * M + m) * I + i) - mu; var += e * e; }
+    part += sqrtf(var / (float)G + 1e-8f);
+  }
+  const float stat = block_sum(part, sh) / (float)I;
+  for (int g = 0; g < G; ++g) {
+    const size_t n = (size_t)(g * M + m);
+    for (int i = threadIdx.x; i < HW * Cy; i += blockDim.x) {
+      const int p = i / Cy, c = i - p * Cy;
+      const float v = c < C ? Feat<T>::ld1(x + n * I + (size_t)p * C + c) : (c == C ? stat : 0.f);
+      Feat<T>::st1(y + n * HW * Cy + i, v);
+    }
+  }
+}
+
+// gx[g,m,i] = gy[g,m,i] + k * gstat[m] * (x - mu) / sigma ,  k = 1 / (I * G),  gstat[m] = sum_{g,p} gy[g,m,p,C]
+template <typename T>
+__global__ void mbstd_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x, T* __restrict__ gx,
+                                 int N, int G, int HW, int C, int Cy) {
+  __shared__ float sh[8];
+  const int M = N / G, m = blockIdx.x, I = HW * C;
+  float part = 0.f;
+  for (int i = threadIdx.x; i < G * HW; i += blockDim.x) {
+    const int g = i / HW, p = i - g * HW;
+    part += Feat<T>::ld1(gy + ((size_t)(g * M + m) * HW + p) * Cy + C);
+  }
+  const float kg = block_sum(part, sh) / ((float)I * (float)G);
+  for (int i = threadIdx.x; i < I; i += blockDim.x) {
+    const int p = i / C, c = i - p * C;
+    float mu = 0.f;
+    for (int g = 0; g < G; ++g) mu += Feat<T>::ld1(x + (size_t)(g * M + m) * I + i);
+    mu /= (float)G;
+    float var = 0.f;
+    for (int g = 0; g < G; ++g) { const float e = Feat<T>::ld1(x + (size_t)(g * M + m) * I + i) - mu; var += e * e; }
+    const float inv_sigma = rsqrtf(var / (float)G + 1e-8f);
+    for (int g = 0; g < G; ++g) {
+      const size_t n = (size_t)(g * M + m);
+      const float e = Feat<T>::ld1(x + n * I + i) - mu;
+      const float gyi = Feat<T>::ld1(gy + (n * HW + p) * Cy + c);
+      Feat<T>::st1(gx + n * I + i, gyi + kg * e * inv_sigma);
+    }
+  }
+}
+
+// Backward of mbstd_bwd for a cotangent v on gx:
+//   ggy[..., :C] = v ; ggy[..., C] = k * sum_{g,i} v e / sigma ; ggy[..., >C] = 0
+//   gx2[g',m,i] = k * gstat[m] * ( (v[g'] - mean_g v) / sigma - e[g'] * (sum_g v[g] e[g]) / (G sigma^3) )
+template <typename T>
+__global__ void mbstd_bwd2_kernel(const T* __restrict__ v, const T* __restrict__ gy, const T* __restrict__ x,
+                                  T* __restrict__ ggy, T* __restrict__ gx2, int N, int G, int HW, int C, int Cy) {
+  __shared__ float sh[8];
+  const int M = N / G, m = blockIdx.x, I = HW * C;
+  float part = 0.f;
+  for (int i = threadIdx.x; i < G * HW; i += blockDim.x) {
+    const int g = i / HW, p = i - g * HW;
+    part += Feat<T>::ld1(gy + ((size_t)(g * M + m) * HW + p) * Cy + C);
+  }
+  const float k = 1.f / ((float)I * (float)G);
+  const float kg = block_sum(part, sh) * k;
+  float dstat = 0.f;
+  for (int i = threadIdx.x; i < I; i += blockDim.x) {
+    float mu = 0.f, vm = 0.f;
+    for (int g = 0; g < G; ++g) {
+      mu += Feat<T>::ld1(x + (size_t)(g * M + m) * I + i);
+      vm += Feat<T>::ld1(v + (size_t)(g * M + m) * I + i);
+    }
+    mu /= (float)G; vm /= (float)G;
+    float var = 0.f, ve = 0.f;
+    for (int g = 0; g < G; ++g) {
+      const size_t o = (size_t)(g * M + m) * I + i;
+      const float e = Feat<T>::ld1(x + o) - mu;
+      var += e * e; ve += Feat<T>::ld1(v + o) * e;
+    }
+    const float inv_sigma = rsqrtf(var / (float)G + 1e-8f);
+    dstat += ve * inv_sigma;
+    const float c3 = ve * inv_sigma * inv_sigma * inv_sigma / (float)G;
+    for (int g = 0; g < G; ++g) {
+      const size_t o = (size_t)(g * M + m) * I + i;
+      const float e = Feat<T>::ld1(x + o) - mu;
+      Feat<T>::st1(gx2 + o, kg * ((Feat<T>::ld1(v + o) - vm) * inv_sigma - e * c3));
+    }
+  }
+  const float ds = block_sum(dstat, sh) * k;
+  for (int g = 0; g < G; ++g) {
+    const size_t n = (size_t)(g * M + m);
+    for (int i = threadIdx.x; i < HW * Cy; i += blockDim.x) {
+      const int p = i / Cy, c = i - p * Cy;
+      const float val = c < C ? Feat<T>::ld1(v + n * I + (size_t)p * C + c) : (c == C ? ds : 0.f);
+      Feat<T>::st1(ggy + n * HW * Cy + i, val);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// 1x1 convolutions touching the 3-channel fp32 NCHW image.  w: [Bw][3][C] fp32 (Bw = 1 shared, or B per-sample)
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void rgb_expand_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
+                                  float bias_scale, T* __restrict__ y, int B, int HW, int C, int Clog, int per_sample,
+                                  int act, float gain) {
+  const int nvec = C >> 3;
+  const long long total = (long long)B * HW * nvec;
+  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (gid >= total) return;
+  const int v = (int)(gid % nvec);
+  const long long pix = gid / nvec;
+  const int p = (int)(pix % HW), b = (int)(pix / HW);
+  const float* wb = w + (per_sample ? (size_t)b * 3 * C : 0);
+  const float i0 = img[((size_t)b * 3 + 0) * HW + p], i1 = img[((size_t)b * 3 + 1) * HW + p], i2 = img[((size_t)b * 3 + 2) * HW + p];
+  F8 s;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = v * 8 + j;
+    float t = i0 * wb[c] + i1 * wb[C + c] + i2 * wb[2 * C + c];
+    if (bias && c < Clog) t += bias[c] * bias_scale;
+    s.v[j] = c < Clog ? act_fwd(t, act) * gain : 0.f;
+  }
+  Feat<T>::store(y + (size_t)pix * C + v * 8, s);
+}
+
+template <typename T>
+__global__ void rgb_reduce_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                  float bias_scale, float* __restrict__ img, int B, int HW, int C, int per_sample) {
+  const int nvec = C >> 3;                                   // power of two <= 64
+  const long long total = (long long)B * HW * nvec;
+  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
+  const bool live = gid < total;
+  const long long gg = live ? gid : total - 1;
+  const int v = (int)(gg % nvec);
+  const long long pix = gg / nvec;
+  const int p = (int)(pix % HW), b = (int)(pix / HW);
+  const float* wb = w + (per_sample ? (size_t)b * 3 * C : 0);
+  const F8 t = Feat<T>::load(x + (size_t)pix * C + v * 8);
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = v * 8 + j;
+    o0 += t.v[j] * wb[c]; o1 += t.v[j] * wb[C + c]; o2 += t.v[j] * wb[2 * C + c];
+  }
+  for (int o = nvec >> 1; o > 0; o >>= 1) { o0 += __shfl_xor(o0, o, 64); o1 += __shfl_xor(o1, o, 64); o2 += __shfl_xor(o2, o, 64); }
+  if (live && v == 0) {
+    const float b0 = bias ? bias[0] * bias_scale : 0.f, b1 = bias ? bias[1] * bias_scale : 0.f, b2 = bias ? bias[2] * bias_scale : 0.f;
+    img[((size_t)b * 3 + 0) * HW + p] = o0 + b0;
+    img[((size_t)b * 3 + 1) * HW + p] = o1 + b1;
+    img[((size_t)b * 3 + 2) * HW + p] = o2 + b2;
+  }
+}
+
+// gw[bw][o][c] += sum_p img[b,o,p] * feat[b,p,c]
+template <typename T>
+__global__ void rgb_wgrad_kernel(const float* __restrict__ img, const T* __restrict__ feat, float* __restrict__ gw,
+                                 int HW, int C, int per_sample, int P) {
+  __shared__ float red[3][TPB * 8];
+  const int nvec = C >> 3;
+  const int groups = TPB / nvec;
+  const int grp = threadIdx.x / nvec, v = threadIdx.x - grp * nvec;
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * P, p1 = min(p0 + P, HW);
+  float a0[8], a1[8], a2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a0[j] = 0.f; a1[j] = 0.f; a2[j] = 0.f; }
+  if (grp < groups) {
+    for (int p = p0 + grp; p < p1; p += groups) {
+      const F8 t = Feat<T>::load(feat + ((size_t)b * HW + p) * C + v * 8);
+      const float i0 = img[((size_t)b * 3 + 0) * HW + p], i1 = img[((size_t)b * 3 + 1) * HW + p], i2 = img[((size_t)b * 3 + 2) * HW + p];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { a0[j] += i0 * t.v[j]; a1[j] += i1 * t.v[j]; a2[j] += i2 * t.v[j]; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[0][threadIdx.x * 8 + j] = a0[j]; red[1][threadIdx.x * 8 + j] = a1[j]; red[2][threadIdx.x * 8 + j] = a2[j]; }
+  __syncthreads();
+  float* gwb = gw + (per_sample ? (size_t)b * 3 * C : 0);
+  for (int c = threadIdx.x; c < C; c += TPB) {
+    const int vv = c >> 3, jj = c & 7;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    for (int gI = 0; gI < groups; ++gI) {
+      const int t = (gI * nvec + vv) * 8 + jj;
+      t0 += red[0][t]; t1 += red[1][t]; t2 += red[2][t];
+    }
+    atomicAdd(gwb + c, t0); atomicAdd(gwb + C + c, t1); atomicAdd(gwb + 2 * C + c, t2);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// layout converts for the (tiny) tensors that cross the NCHW fp32 module boundary
+// ------------------------------------------------------------------------------------------------------------
+// src fp32 [Bs][Clog][HW] (Bs = B, or 1 broadcast over the batch) -> dst T [B][HW][C] (channels >= Clog zero)
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int HW, int C, int Clog, int bcast) {
+  const long long total = (long long)B * HW * C;
+  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (gid >= total) return;
+  const int c = (int)(gid % C);
+  const int p = (int)((gid / C) % HW);
+  const int b = (int)(gid / ((long long)C * HW));
+  const float v = c < Clog ? src[((size_t)(bcast ? 0 : b) * Clog + c) * HW + p] : 0.f;
+  Feat<T>::st1(dst + gid, v);
+}
+// src T [B][HW][C] -> dst fp32 [Bd][Clog][HW]; reduce != 0 sums over the batch into Bd = 1
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int B, int HW, int C, int Clog, int reduce) {
+  const int Bd = reduce ? 1 : B;
+  const long long total = (long long)Bd * Clog * HW;
+  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (gid >= total) return;
+  const int p = (int)(gid % HW);
+  const int c = (int)((gid / HW) % Clog);
+  const int b = (int)(gid / ((long long)HW * Clog));
+  float v = 0.f;
+  if (reduce) { for (int bb = 0; bb < B; ++bb) v += Feat<T>::ld1(src + ((size_t)bb * HW + p) * C + c); }
+  else v = Feat<T>::ld1(src + ((size_t)b * HW + p) * C + c);
+  dst[gid] = v;
+}
+
+bool pow2_le64(int n) { return n >= 1 && n <= 64 && (n & (n - 1)) == 0; }
+int reduce_P(int HW, int B) {           // pixels per block for the reduction kernels: ~4096 blocks, >= 64 pixels
+  int P = (int)(((long long)HW * B + 4095) / 4096);
+  return P < 64 ? 64 : P;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL)                                   \
+  if ((dtype) == DT_BF16) { typedef __bf16 T; CALL; }             \
+  else if ((dtype) == DT_F32) { typedef float T; CALL; }          \
+  else return LCGAN_EINVAL;
+
+extern "C" {
+
+int lcgan_box3_act(const void* x, void* y, int B, int H, int W, int C, int act, float gain, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (C & 7) return LCGAN_EINVAL;
+  const long long n = (long long)B * H * W * (C / 8);
+  ProfScope p(KID_STENCIL, 0, (double)n * 8 * 2 * (dtype == DT_BF16 ? 2 : 4), s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(box3_act_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)x, (T*)y, B, H, W, C, act, gain));
+  return launch_status();
+}
+
+int lcgan_box3_act_bwd(const void* gy, const void* y, void* gx, int B, int H, int W, int C, int act, float gain, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (C & 7) return LCGAN_EINVAL;
+  const long long n = (long long)B * H * W * (C / 8);
+  ProfScope p(KID_STENCIL, 0, (double)n * 8 * 3 * (dtype == DT_BF16 ? 2 : 4), s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(box3_act_bwd_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)gy, (const T*)y, (T*)gx, B, H, W, C, act, gain));
+  return launch_status();
+}
+
+int lcgan_up2box(const void* x, const void* residual, void* y, int B, int H, int W, int C, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (C & 7) return LCGAN_EINVAL;
+  const long long n = (long long)B * H * W * 4 * (C / 8);
+  ProfScope p(KID_STENCIL, 0, (double)n * 8 * (residual ? 2.25 : 1.25) * (dtype == DT_BF16 ? 2 : 4), s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(up2box_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)x, (const T*)residual, (T*)y, B, H, W, C));
+  return launch_status();
+}
+
+int lcgan_up2box_bwd(const void* gy, void* gx, int B, int H, int W, int C, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (C & 7) return LCGAN_EINVAL;
+  const long long n = (long long)B * H * W * (C / 8);
+  ProfScope p(KID_STENCIL, 0, (double)n * 8 * 5 * (dtype == DT_BF16 ? 2 : 4), s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(up2box_bwd_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)gy, (T*)gx, B, H, W, C));
+  return launch_status();
+}
+
+int lcgan_avgpool2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if ((C & 7) || (H & 1) || (W & 1)) return LCGAN_EINVAL;
+  const long long n = (long long)B * (H / 2) * (W / 2) * (C / 8);
+  ProfScope p(KID_STENCIL, 0, (double)n * 8 * 5 * (dtype == DT_BF16 ? 2 : 4), s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(avgpool2_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)x, (T*)y, B, H, W, C));
+  return launch_status();
+}
+
+int lcgan_avgpool2_bwd(const void* gy, void* gx, int B, int H, int W, int C, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if ((C & 7) || (H & 1) || (W & 1)) return LCGAN_EINVAL;
+  const long long n = (long long)B * H * W * (C / 8);
+  ProfScope p(KID_STENCIL, 0, (double)n * 8 * 1.25 * (dtype == DT_BF16 ? 2 : 4), s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(avgpool2_bwd_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)gy, (T*)gx, B, H, W, C));
+  return launch_status();
+}
+
+// gz may be NULL (reductions only); gbias / gdq may be NULL.  gbias: [Clog], gdq: [B][C] -- both accumulated (+=).
+int lcgan_act_bwd_reduce(const void* gy, const void* y, void* gz, const float* bias, float bias_scale,
+                         float* gbias, float* gdq, int B, int HW, int C, int Clog, int act, float gain, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if ((C & 7) || C / 8 > TPB || Clog > C) return LCGAN_EINVAL;
+  const int P = reduce_P(HW, B);
+  dim3 grid(cdiv(HW, P), B);
+  ProfScope p(KID_ACT_BWD, 0, (double)B * HW * C * (gz ? 3 : 2) * (dtype == DT_BF16 ? 2 : 4), s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(act_bwd_reduce_kernel<T>, grid, dim3(TPB), 0, s, (const T*)gy, (const T*)y, (T*)gz,
+                                       bias, bias_scale, gbias, gdq, HW, C, Clog, act, gain, P));
+  return launch_status();
+}
+
+// u <- s * u in place; gs[b][c] += sum_p x * u(old)
+int lcgan_scale_reduce(void* u, const void* x, const float* sc, float* gs, int B, int HW, int C, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if ((C & 7) || C / 8 > TPB) return LCGAN_EINVAL;
+  const int P = reduce_P(HW, B);
+  dim3 grid(cdiv(HW, P), B);
+  ProfScope p(KID_SCALE_REDUCE, 0, (double)B * HW * C * 3 * (dtype == DT_BF16 ? 2 : 4), s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(scale_reduce_kernel<T>, grid, dim3(TPB), 0, s, (T*)u, (const T*)x, sc, gs, HW, C, P));
+  return launch_status();
+}
+
+// flow: [B,H,W,8] (channel 0 = x, 1 = y displacement in normalised units before * scale)
+int lcgan_warp_fwd(const void* x, const void* flow, void* y, int B, int H, int W, int C, float scale, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if ((C & 7) || H < 2 || W < 2) return LCGAN_EINVAL;
+  const long long n = (long long)B * H * W * (C / 8);
+  ProfScope p(KID_WARP_FWD, 0, (double)n * 8 * 2 * (dtype == DT_BF16 ? 2 : 4), s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(warp_fwd_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)x, (const T*)flow, (T*)y, B, H, W, C, scale));
+  return launch_status();
+}
+
+// gx32: fp32 [B,H,W,C], MUST be zero on entry (float atomics); gflow: [B,H,W,8]
+int lcgan_warp_bwd(const void* gy, const void* x, const void* flow, float* gx32, void* gflow,
+                   int B, int H, int W, int C, float scale, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if ((C & 7) || !pow2_le64(C / 8) || H < 2 || W < 2) return LCGAN_EINVAL;
+  const long long n = (long long)B * H * W * (C / 8);
+  ProfScope p(KID_WARP_BWD, 0, (double)n * 8 * (2 * (dtype == DT_BF16 ? 2 : 4) + 16 * 4), s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(warp_bwd_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)gy, (const T*)x, (const T*)flow,
+                                       gx32, (T*)gflow, B, H, W, C, scale));
+  return launch_status();
+}
+
+int lcgan_cast_from_f32(const float* src, void* dst, long long n, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n & 7) return LCGAN_EINVAL;
+  ProfScope p(KID_LAYOUT, 0, (double)n * (4 + (dtype == DT_BF16 ? 2 : 4)), s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(cast_f32_kernel<T>, grid1d(n / 8), dim3(TPB), 0, s, src, (T*)dst, n / 8));
+  return launch_status();
+}
+
+int lcgan_mbstd_fwd(const void* x, void* y, int N, int G, int HW, int C, int Cy, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (G < 1 || N % G || Cy <= C) return LCGAN_EINVAL;
+  ProfScope p(KID_SMALL, 0, 0, s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(mbstd_fwd_kernel<T>, dim3(N / G), dim3(512), 0, s, (const T*)x, (T*)y, N, G, HW, C, Cy));
+  return launch_status();
+}
+int lcgan_mbstd_bwd(const void* gy, const void* x, void* gx, int N, int G, int HW, int C, int Cy, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (G < 1 || N % G || Cy <= C) return LCGAN_EINVAL;
+  ProfScope p(KID_SMALL, 0, 0, s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(mbstd_bwd_kernel<T>, dim3(N / G), dim3(512), 0, s, (const T*)gy, (const T*)x, (T*)gx, N, G, HW, C, Cy));
+  return launch_status();
+}
+int lcgan_mbstd_bwd2(const void* v, const void* gy, const void* x, void* ggy, void* gx2,
+                     int N, int G, int HW, int C, int Cy, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (G < 1 || N % G || Cy <= C) return LCGAN_EINVAL;
+  ProfScope p(KID_SMALL, 0, 0, s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(mbstd_bwd2_kernel<T>, dim3(N / G), dim3(512), 0, s, (const T*)v, (const T*)gy, (const T*)x,
+                                       (T*)ggy, (T*)gx2, N, G, HW, C, Cy));
+  return launch_status();
+}
+
+// y[b,p,c] = act(sum_o img[b,o,p] w[bw,o,c] + bias[c]*bias_scale) * gain   (channels >= Clog are written as zero)
+int lcgan_rgb_expand(const float* img, const float* w, const float* bias, float bias_scale, void* y,
+                     int B, int HW, int C, int Clog, int per_sample, int act, float gain, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (C & 7) return LCGAN_EINVAL;
+  const long long n = (long long)B * HW * (C / 8);
+  ProfScope p(KID_RGB, 0, (double)n * 8 * (dtype == DT_BF16 ? 2 : 4), s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(rgb_expand_kernel<T>, grid1d(n), dim3(TPB), 0, s, img, w, bias, bias_scale, (T*)y,
+                                       B, HW, C, Clog, per_sample, act, gain));
+  return launch_status();
+}
+// img[b,o,p] = sum_c x[b,p,c] w[bw,o,c] + bias[o]*bias_scale
+int lcgan_rgb_reduce(const void* x, const float* w, const float* bias, float bias_scale, float* img,
+                     int B, int HW, int C, int per_sample, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if ((C & 7) || !pow2_le64(C / 8)) return LCGAN_EINVAL;
+  const long long n = (long long)B * HW * (C / 8);
+  ProfScope p(KID_RGB, 0, (double)n * 8 * (dtype == DT_BF16 ? 2 : 4), s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(rgb_reduce_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)x, w, bias, bias_scale, img,
+                                       B, HW, C, per_sample));
+  return launch_status();
+}
+// gw[bw][o][c] += sum_p img[b,o,p] feat[b,p,c]   (gw must be zeroed by the caller)
+int lcgan_rgb_wgrad(const float* img, const void* feat, float* gw, int B, int HW, int C, int per_sample, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if ((C & 7) || C / 8 > TPB) return LCGAN_EINVAL;
+  const int P = reduce_P(HW, B);
+  dim3 grid(cdiv(HW, P), B);
+  ProfScope p(KID_RGB, 0, (double)B * HW * C * (dtype == DT_BF16 ? 2 : 4), s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(rgb_wgrad_kernel<T>, grid, dim3(TPB), 0, s, img, (const T*)feat, gw, HW, C, per_sample, P));
+  return launch_status();
+}
+
+int lcgan_nchw_to_nhwc(const float* src, void* dst, int B, int HW, int C, int Clog, int bcast, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const long long n = (long long)B * HW * C;
+  ProfScope p(KID_LAYOUT, 0, 0, s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, grid1d(n), dim3(TPB), 0, s, src, (T*)dst, B, HW, C, Clog, bcast));
+  return launch_status();
+}
+int lcgan_nhwc_to_nchw(const void* src, float* dst, int B, int HW, int C, int Clog, int reduce, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const long long n = (long long)(reduce ? 1 : B) * Clog * HW;
+  ProfScope p(KID_LAYOUT, 0, 0, s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)src, dst, B, HW, C, Clog, reduce));
+  return launch_status();
+}
+
+}  // extern "C"

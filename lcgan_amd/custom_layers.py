@@ -1,0 +1,300 @@
+"""Layer library of LC-GAN on the MI355X HIP kernels.
+
+Mirrors the reference's `custom_layers.py` class-for-class (same class names, constructor signatures, parameter /
+buffer names and shapes, hence the same `state_dict()` layout), but every `forward` runs hand-written gfx950
+kernels through `lcgan_amd.ops`.  Between layers, feature maps are NHWC `[B,H,W,C]` tensors in the configured
+feature dtype (`lcgan_amd.config`); NCHW fp32 only appears at the Generator / Discriminator boundary.
+
+reference: custom_layers.py:7-306
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import config
+from . import kernels as KM
+from . import ops
+from .kernels import ACT_LRELU, ACT_NONE, ACT_TANH, ceil8
+
+SQRT2 = math.sqrt(2.0)
+SQRT_HALF = math.sqrt(0.5)
+
+
+class EqualizedWeight(nn.Module):
+    """reference custom_layers.py:7-14 -- stores W / lr_mul; the run-time scale c = lr_mul / sqrt(fan_in) is folded
+    into the kernels (weight prep / linear scale) instead of materialising W*c."""
+
+    def __init__(self, shape, lr_mul=1.0):
+        super().__init__()
+        self.c = float(1 / np.sqrt(np.prod(shape[1:])) * lr_mul)
+        self.weight = nn.Parameter(torch.randn(shape).div_(lr_mul))
+
+    def forward(self):
+        return self.weight * self.c
+
+
+class EqualizedLinear(nn.Module):
+    """reference custom_layers.py:17-25.  x: f32 [M, in_features]."""
+
+    def __init__(self, in_features, out_features, bias=0.0, lr_mul=1.0):
+        super().__init__()
+        self.weight = EqualizedWeight([out_features, in_features], lr_mul)
+        self.bias = nn.Parameter(torch.ones(out_features) * bias)
+        self.lr_mul = lr_mul
+
+    def forward(self, x, act=ACT_NONE):
+        return ops.LinearFn.apply(x.contiguous(), self.weight.weight, self.bias, self.weight.c, self.lr_mul, act, 1.0)
+
+
+class EqualizedConv2d(nn.Module):
+    """reference custom_layers.py:28-44.  `forward` takes an NHWC feature map; `forward_rgb` takes the fp32 NCHW image
+    (the discriminator's first 1x1 conv, cnn.py:20).  act / gain / residual are fused into the conv epilogue."""
+
+    def __init__(self, in_features, out_features, kernel_size, stride=1, no_bias=False, lr_mul=1.0):
+        super().__init__()
+        self.padding = kernel_size // 2
+        self.kernel_size = kernel_size
+        self.weight = EqualizedWeight([out_features, in_features, kernel_size, kernel_size], lr_mul)
+        self.no_bias = no_bias
+        if not self.no_bias:
+            self.bias = nn.Parameter(torch.zeros([out_features]))
+        self.stride = stride
+        self.lr_mul = lr_mul
+
+    def forward(self, x, act=ACT_NONE, gain=1.0, residual=None):
+        bias = None if self.no_bias else self.bias
+        wscale = self.weight.c
+        if act == ACT_NONE and gain != 1.0:          # a linear conv: fold the gain into the weight scale
+            assert bias is None
+            wscale, gain = wscale * gain, 1.0
+        return ops.Conv2dFn.apply(x, self.weight.weight, bias, residual, self.kernel_size, self.stride, act, gain, wscale,
+                                  self.lr_mul)
+
+    def forward_rgb(self, img, act=ACT_NONE, gain=1.0):
+        w = self.weight.weight
+        C = w.shape[0]
+        assert self.kernel_size == 1 and w.shape[1] == 3 and C % 8 == 0
+        wt = (w.view(C, 3).t() * self.weight.c).unsqueeze(0).contiguous()            # [1,3,C] torch glue (384 values)
+        bias = None if self.no_bias else self.bias
+        return ops.RGBExpandFn.apply(img.contiguous(), wt, bias, self.lr_mul, C, act, gain, config.feature_dtype())
+
+
+class ModulatedConv2d(nn.Module):
+    """reference custom_layers.py:47-86.  x: NHWC feature map, s: f32 [B, in_features] style."""
+
+    def __init__(self, in_features, out_features, kernel_size, up=1, eps=1e-8, lr_mul=1.0):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.kernel_size = kernel_size
+        self.padding = (kernel_size - 1) // 2
+        self.up = up
+        self.weight = EqualizedWeight([out_features, in_features, kernel_size, kernel_size], lr_mul)
+        self.bias = nn.Parameter(torch.zeros([out_features]))
+        self.lr_mul = lr_mul
+        self.eps = eps
+
+    def forward(self, x, s, act=ACT_NONE, gain=1.0):
+        assert self.kernel_size == 3 and self.lr_mul == 1.0
+        return ops.ModConvFn.apply(x, self.weight.weight, self.bias, s, self.up, act, gain)
+
+    def forward_to_rgb(self, x, s):
+        """kernel_size 1, out_features 3 (ToRGBBlock.modulated_conv1, custom_layers.py:175,181): per-sample 3xC weights
+        (modulate + demodulate: a few hundred values of torch glue) feed the HIP reduce kernel; output is the f32 NCHW image."""
+        assert self.kernel_size == 1 and self.out_features == 3
+        w = self.weight.weight.view(3, self.in_features) * self.weight.c                # [3,C]
+        wm = w.unsqueeze(0) * s.unsqueeze(1)                                              # [B,3,C]   custom_layers.py:62-64
+        wm = wm * torch.rsqrt(wm.square().sum(dim=2, keepdim=True) + self.eps)            # custom_layers.py:67-68
+        return ops.RGBReduceFn.apply(x, wm.contiguous(), self.bias, self.lr_mul)
+
+
+class SynthesisLayer(nn.Module):
+    """reference custom_layers.py:89-111 (use_noise is always False in the reference, cnn.py:83,87)."""
+
+    def __init__(self, in_features, out_features, latent_dim, resolution, kernel_size=3, up=1, lr_mul=1.0, use_noise=False):
+        super().__init__()
+        assert not use_noise, "the reference never enables use_noise (cnn.py:83,87)"
+        self.latent_dim = latent_dim
+        self.up = up
+        self.resolution = resolution
+        self.use_noise = use_noise
+        self.linear = EqualizedLinear(self.latent_dim, in_features, bias=1.0, lr_mul=1.0)
+        self.modulated_conv = ModulatedConv2d(in_features, out_features, kernel_size, up=self.up, lr_mul=1.0)
+
+    def forward(self, x, latent, act=ACT_NONE, gain=1.0):
+        s = self.linear(latent)
+        if self.modulated_conv.kernel_size == 1:
+            return self.modulated_conv.forward_to_rgb(x, s)
+        return self.modulated_conv(x, s, act, gain)
+
+
+def _split_latents(lat, n):
+    if isinstance(lat, (tuple, list)):
+        assert len(lat) == n
+        return list(lat)
+    if lat.dim() == 2:
+        return [lat] * n
+    return [lat[:, i].contiguous() for i in range(n)]      # reference layout [B, n, D] (custom_layers.py:141-142)
+
+
+class SynthesisBlock(nn.Module):
+    """reference custom_layers.py:114-166."""
+
+    def __init__(self, in_features, out_features, g_latent_dim, a_latent_dim, resolution, max_flow_scale, use_noise=False):
+        super().__init__()
+        self.resolution = resolution
+        self.use_noise = use_noise
+        self.max_flow_scale = max_flow_scale
+        self.modulated_conv0 = SynthesisLayer(in_features, out_features, a_latent_dim, resolution, up=2, use_noise=self.use_noise)
+        self.modulated_conv1 = SynthesisLayer(out_features, out_features, a_latent_dim, resolution, up=1, use_noise=self.use_noise)
+        self.skip_layer = EqualizedConv2d(in_features, out_features, kernel_size=1, no_bias=True, lr_mul=1.0)
+        self.flow_layer = SynthesisLayer(in_features, 2, g_latent_dim, resolution, up=2, use_noise=False)
+        self.gain = np.sqrt(2)
+        self.skip_gain = np.sqrt(0.5)
+
+    def forward(self, x, g_latent, a_latent):
+        (g_lat,) = _split_latents(g_latent, 1)
+        a0, a1 = _split_latents(a_latent, 2)
+        # flow field: up-conv (2 channels, padded to 8) -> box filter -> tanh                 :149-151
+        flow = ops.Box3ActFn.apply(self.flow_layer(x, g_lat), ACT_TANH, 1.0)
+        # main branch: up-conv -> box filter -> lrelu*sqrt2 -> conv -> lrelu                    :153-158
+        h = ops.Box3ActFn.apply(self.modulated_conv0(x, a0), ACT_LRELU, SQRT2)
+        h = self.modulated_conv1(h, a1, ACT_LRELU, 1.0)
+        # skip branch: 1x1 conv * sqrt(.5) at low res, then nearest x2 + box filter fused with the add     :145-147,159
+        skip = self.skip_layer(x, ACT_NONE, SQRT_HALF)
+        y = ops.Up2BoxAddFn.apply(skip, h)
+        # bicubic feature warp                                                                   :162-165
+        return ops.WarpFn.apply(y, flow, float(self.max_flow_scale))
+
+
+class ToRGBBlock(nn.Module):
+    """reference custom_layers.py:169-182; returns the fp32 NCHW image."""
+
+    def __init__(self, in_features, out_features, a_latent_dim, resolution, use_noise=False):
+        super().__init__()
+        self.resolution = resolution
+        self.use_noise = use_noise
+        self.modulated_conv0 = SynthesisLayer(in_features, in_features, a_latent_dim, resolution, use_noise=self.use_noise)
+        self.modulated_conv1 = SynthesisLayer(in_features, out_features, a_latent_dim, resolution, kernel_size=1, use_noise=False)
+
+    def forward(self, x, a_latent):
+        a0, a1 = _split_latents(a_latent, 2)
+        x = self.modulated_conv0(x, a0, ACT_LRELU, 1.0)
+        return self.modulated_conv1(x, a1)
+
+
+class DiscriminatorBlock(nn.Module):
+    """reference custom_layers.py:185-217 (the reference always builds it with skip=True, cnn.py:25)."""
+
+    def __init__(self, in_features, out_features, skip=False):
+        super().__init__()
+        self.conv0 = EqualizedConv2d(in_features, in_features, kernel_size=3, lr_mul=1.0)
+        self.conv1 = EqualizedConv2d(in_features, out_features, kernel_size=3, stride=2, lr_mul=1.0)
+        self.skip = skip
+        if self.skip:
+            self.skip_layer = EqualizedConv2d(in_features, out_features, kernel_size=1, no_bias=True, lr_mul=1.0)
+            self.gain = np.sqrt(2)
+            self.skip_gain = np.sqrt(0.5)
+
+    def forward(self, x):
+        h = self.conv0(x, ACT_LRELU, SQRT2 if self.skip else 1.0)              # :204-205 / :212-213
+        h = ops.Box3Fn.apply(h)                                                 # :206
+        h = self.conv1(h, ACT_LRELU, 1.0)                                       # :207-208
+        if not self.skip:
+            return h
+        pooled = ops.AvgPool2Fn.apply(x)                                        # :202
+        return self.skip_layer(pooled, ACT_NONE, SQRT_HALF, residual=h)         # :203, :209 (add fused in the epilogue)
+
+
+class MinibatchStdLayer(nn.Module):
+    """reference custom_layers.py:237-256 (num_channels = 1)."""
+
+    def __init__(self, group_size, num_channels=1):
+        super().__init__()
+        assert num_channels == 1
+        self.group_size = group_size
+        self.num_channels = num_channels
+
+    def forward(self, x):
+        N = x.shape[0]
+        G = min(self.group_size, N) if self.group_size is not None else N
+        return ops.MbstdFn.apply(x, G)
+
+
+class DiscriminatorEpilogue(nn.Module):
+    """reference custom_layers.py:220-234; returns f32 [B, in_features]."""
+
+    def __init__(self, in_features, resolution, mbstd_group_size=4):
+        super().__init__()
+        self.resolution = resolution
+        self.mb_std = MinibatchStdLayer(group_size=mbstd_group_size)
+        self.conv = EqualizedConv2d(in_features + 1, in_features, kernel_size=3, lr_mul=1.0)
+        self.linear = EqualizedLinear(in_features * (resolution ** 2), in_features, lr_mul=0.01)
+
+    def forward(self, x):
+        x = self.mb_std(x)                                                      # [B,4,4,C+1 -> padded to a multiple of 8]
+        x = self.conv(x, ACT_LRELU, 1.0)
+        flat = ops.ToNCHWFn.apply(x, self.conv.weight.weight.shape[0]).flatten(1)   # NCHW order, as x.flatten(1) at :232
+        return self.linear(flat, ACT_LRELU)
+
+
+def _qr_q(matrix: torch.Tensor) -> torch.Tensor:
+    """Q of the reduced Householder QR (torch.qr(...)[0], custom_layers.py:274-276): a 64x64 library call on the
+    parameter matrix, O(microseconds) -- left to torch.linalg (hipSOLVER), as SURVEY.md section 7 plans."""
+    return torch.linalg.qr(matrix, mode="reduced")[0]
+
+
+class MappingNetwork(nn.Module):
+    """reference custom_layers.py:259-287: x = (Q(tanh(basis)) diag(|d|+eps)) z, then affine layers without activation."""
+
+    def __init__(self, channels_list, lr_mul=0.01):
+        super().__init__()
+        self.eps = 1e-6
+        self.matrix_size = channels_list[0]
+        self.diagonal_params = nn.Parameter(torch.randn([self.matrix_size]))
+        self.basis_params = nn.Parameter(torch.randn([self.matrix_size, self.matrix_size]))
+        self.num_layers = len(channels_list) - 1
+        self.mlp = nn.Sequential(*[EqualizedLinear(channels_list[i], channels_list[i + 1], lr_mul=lr_mul)
+                                   for i in range(self.num_layers)])
+
+    def orthogonalize(self, matrix):
+        return _qr_q(matrix)
+
+    def mapping_matrix(self):
+        return self.orthogonalize(torch.tanh(self.basis_params)) * (self.diagonal_params.abs() + self.eps).unsqueeze(0)
+
+    def forward(self, z):
+        L = self.mapping_matrix().contiguous()                                  # [m,m]; 64x64 torch glue
+        x = ops.LinearFn.apply(z.contiguous(), L, None, 1.0, 0.0, ACT_NONE, 1.0)   # x_b = L z_b  (:283-285)
+        for layer in self.mlp:
+            x = layer(x)
+        return x
+
+
+class ProjectionHead(nn.Module):
+    """reference custom_layers.py:290-306.  The LeakyReLU modules stay in the Sequential (state_dict indices 0,2,4) but
+    are fused into the preceding linear kernel."""
+
+    def __init__(self, channels_list, lr_mul=0.01):
+        super().__init__()
+        self.num_layers = len(channels_list) - 1
+        if self.num_layers > 0:
+            mlp = []
+            for idx in range(self.num_layers):
+                mlp += [EqualizedLinear(channels_list[idx], channels_list[idx + 1], lr_mul=lr_mul)]
+                if idx < self.num_layers - 1:
+                    mlp += [nn.LeakyReLU(0.2)]
+            self.mlp = nn.Sequential(*mlp)
+
+    def forward(self, z):
+        mods = list(self.mlp)
+        x, i = z, 0
+        while i < len(mods):
+            fused = i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU)
+            x = mods[i](x, ACT_LRELU if fused else ACT_NONE)
+            i += 2 if fused else 1
+        return x

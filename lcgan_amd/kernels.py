@@ -1,0 +1,429 @@
+"""Tensor-level view of the C ABI (include/lcgan_hip.h): every method allocates its outputs with torch (device memory
+is plumbing), passes raw device pointers + the current HIP stream to liblcgan_hip.so and returns the outputs.
+
+`K` is the active backend.  The product only ever uses `HipKernels`; tests may install a CPU emulation of the same
+interface with `set_backend()` to exercise the host-side autograd wiring without a GPU.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+Tensor = torch.Tensor
+ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
+DT_F32, DT_BF16 = 0, 1
+
+
+def ceil8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return DT_F32
+    if dtype == torch.bfloat16:
+        return DT_BF16
+    raise TypeError(f"feature maps must be float32 or bfloat16, got {dtype}")
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class PreparedWeight:
+    """bf16 (hi [+ lo residual]) GEMM-layout copy of a conv weight: [k*k][N][Kpad]."""
+    __slots__ = ("hi", "lo", "N", "Kpad", "k")
+
+    def __init__(self, hi, lo, N, Kpad, k):
+        self.hi, self.lo, self.N, self.Kpad, self.k = hi, lo, N, Kpad, k
+
+
+class HipKernels:
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    # ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def _call(self, name, *args):
+        _lib.check(getattr(self.lib, name)(*args), name)
+
+    @staticmethod
+    def _chk(*ts):
+        for t in ts:
+            if t is not None:
+                assert t.is_cuda and t.is_contiguous(), "HIP kernels need contiguous device tensors"
+
+    # ---- conv family ------------------------------------------------------------------------------------
+    def prep_weight(self, w: Tensor, scale: float, transpose: bool, need_lo: bool, want_wsq: bool = False):
+        self._chk(w)
+        A, Bc, k, _ = w.shape
+        N, Kc = (Bc, A) if transpose else (A, Bc)
+        Kpad = (Kc + 31) // 32 * 32
+        hi = torch.empty((k * k, N, Kpad), dtype=torch.bfloat16, device=w.device)
+        lo = torch.empty_like(hi) if need_lo else None
+        wsq = torch.empty((A, Bc), dtype=torch.float32, device=w.device) if want_wsq else None
+        self._call("lcgan_conv_weight_prep", w.data_ptr(), A, Bc, k, float(scale), int(transpose), hi.data_ptr(), _p(lo), _p(wsq),
+                   self._stream())
+        return PreparedWeight(hi, lo, N, Kpad, k), wsq
+
+    def unprep_wgrad(self, gwp: Tensor, A: int, Bc: int, k: int, scale: float, transposed: bool = False,
+                     w: Optional[Tensor] = None, gwsq: Optional[Tensor] = None) -> Tensor:
+        self._chk(gwp, w, gwsq)
+        gw = torch.empty((A, Bc, k, k), dtype=torch.float32, device=gwp.device)
+        self._call("lcgan_conv_wgrad_unprep", gwp.data_ptr(), A, Bc, k, float(scale), int(transposed), _p(w), _p(gwsq), gw.data_ptr(),
+                   self._stream())
+        return gw
+
+    def conv_fwd(self, x: Tensor, pw: PreparedWeight, N: int, k: int, stride: int, pre=None, post=None, bias=None,
+                 bias_scale: float = 1.0, act: int = ACT_NONE, gain: float = 1.0, residual=None) -> Tensor:
+        self._chk(x, pre, post, bias, residual)
+        B, H, W, Cin = x.shape
+        Cout = ceil8(N)
+        y = torch.empty((B, (H + stride - 1) // stride, (W + stride - 1) // stride, Cout), dtype=x.dtype, device=x.device)
+        self._call("lcgan_conv_fwd", x.data_ptr(), pw.hi.data_ptr(), _p(pw.lo), y.data_ptr(), B, H, W, Cin, Cout, N, k, stride,
+                   _p(pre), _p(post), _p(bias), float(bias_scale), act, float(gain), _p(residual), dt_code(x.dtype), self._stream())
+        return y
+
+    def conv_bwd_data(self, g: Tensor, pw: PreparedWeight, N: int, k: int, stride: int, pre=None, post=None, bias=None,
+                      bias_scale: float = 1.0, act: int = ACT_NONE, gain: float = 1.0, residual=None) -> Tensor:
+        self._chk(g, pre, post, bias, residual)
+        B, H, W, Cg = g.shape
+        Cout = ceil8(N)
+        gx = torch.empty((B, H * stride, W * stride, Cout), dtype=g.dtype, device=g.device)
+        self._call("lcgan_conv_bwd_data", g.data_ptr(), pw.hi.data_ptr(), _p(pw.lo), gx.data_ptr(), B, H, W, Cg, Cout, N, k, stride,
+                   _p(pre), _p(post), _p(bias), float(bias_scale), act, float(gain), _p(residual), dt_code(g.dtype), self._stream())
+        return gx
+
+    def conv_wgrad(self, x: Tensor, g: Tensor, A: int, Bc: int, k: int, stride: int, pre_x=None, pre_g=None) -> Tensor:
+        self._chk(x, g, pre_x, pre_g)
+        B, Hx, Wx, Cx = x.shape
+        _, Hg, Wg, Cg = g.shape
+        gwp = torch.zeros((k * k, A, Bc), dtype=torch.float32, device=x.device)
+        self._call("lcgan_conv_wgrad", x.data_ptr(), g.data_ptr(), gwp.data_ptr(), B, Hx, Wx, Cx, Hg, Wg, Cg, A, Bc, k, stride,
+                   _p(pre_x), _p(pre_g), dt_code(x.dtype), self._stream())
+        return gwp
+
+    # ---- stencils ---------------------------------------------------------------------------------------
+    def box3_act(self, x: Tensor, act: int, gain: float) -> Tensor:
+        self._chk(x)
+        B, H, W, Cc = x.shape
+        y = torch.empty_like(x)
+        self._call("lcgan_box3_act", x.data_ptr(), y.data_ptr(), B, H, W, Cc, act, float(gain), dt_code(x.dtype), self._stream())
+        return y
+
+    def box3_act_bwd(self, gy: Tensor, y: Optional[Tensor], act: int, gain: float) -> Tensor:
+        self._chk(gy, y)
+        B, H, W, Cc = gy.shape
+        gx = torch.empty_like(gy)
+        self._call("lcgan_box3_act_bwd", gy.data_ptr(), _p(y), gx.data_ptr(), B, H, W, Cc, act, float(gain), dt_code(gy.dtype),
+                   self._stream())
+        return gx
+
+    def up2box(self, x: Tensor, residual: Optional[Tensor]) -> Tensor:
+        self._chk(x, residual)
+        B, H, W, Cc = x.shape
+        y = torch.empty((B, 2 * H, 2 * W, Cc), dtype=x.dtype, device=x.device)
+        self._call("lcgan_up2box", x.data_ptr(), _p(residual), y.data_ptr(), B, H, W, Cc, dt_code(x.dtype), self._stream())
+        return y
+
+    def up2box_bwd(self, gy: Tensor) -> Tensor:
+        self._chk(gy)
+        B, H2, W2, Cc = gy.shape
+        gx = torch.empty((B, H2 // 2, W2 // 2, Cc), dtype=gy.dtype, device=gy.device)
+        self._call("lcgan_up2box_bwd", gy.data_ptr(), gx.data_ptr(), B, H2 // 2, W2 // 2, Cc, dt_code(gy.dtype), self._stream())
+        return gx
+
+    def avgpool2(self, x: Tensor) -> Tensor:
+        self._chk(x)
+        B, H, W, Cc = x.shape
+        y = torch.empty((B, H // 2, W // 2, Cc), dtype=x.dtype, device=x.device)
+        self._call("lcgan_avgpool2", x.data_ptr(), y.data_ptr(), B, H, W, Cc, dt_code(x.dtype), self._stream())
+        return y
+
+    def avgpool2_bwd(self, gy: Tensor) -> Tensor:
+        self._chk(gy)
+        B, Ho, Wo, Cc = gy.shape
+        gx = torch.empty((B, 2 * Ho, 2 * Wo, Cc), dtype=gy.dtype, device=gy.device)
+        self._call("lcgan_avgpool2_bwd", gy.data_ptr(), gx.data_ptr(), B, 2 * Ho, 2 * Wo, Cc, dt_code(gy.dtype), self._stream())
+        return gx
+
+    def act_bwd_reduce(self, gy: Tensor, y: Optional[Tensor], act: int, gain: float, clog: int, want_gz: bool = True,
+                       bias: Optional[Tensor] = None, bias_scale: float = 1.0, want_gbias: bool = False, want_gdq: bool = False):
+        """-> (gz | None, gbias [clog] | None, gdq [B, C] | None)"""
+        self._chk(gy, y, bias)
+        B, H, W, Cc = gy.shape
+        gz = torch.empty_like(gy) if want_gz else None
+        gbias = torch.zeros((clog,), dtype=torch.float32, device=gy.device) if want_gbias else None
+        gdq = torch.zeros((B, Cc), dtype=torch.float32, device=gy.device) if want_gdq else None
+        self._call("lcgan_act_bwd_reduce", gy.data_ptr(), _p(y), _p(gz), _p(bias), float(bias_scale), _p(gbias), _p(gdq),
+                   B, H * W, Cc, clog, act, float(gain), dt_code(gy.dtype), self._stream())
+        return gz, gbias, gdq
+
+    def scale_reduce(self, u: Tensor, x: Tensor, s: Tensor) -> Tuple[Tensor, Tensor]:
+        """u <- s*u IN PLACE; returns (u, gs[b,c] = sum_p x*u_old)"""
+        self._chk(u, x, s)
+        B, H, W, Cc = u.shape
+        gs = torch.zeros((B, Cc), dtype=torch.float32, device=u.device)
+        self._call("lcgan_scale_reduce", u.data_ptr(), x.data_ptr(), s.data_ptr(), gs.data_ptr(), B, H * W, Cc, dt_code(u.dtype),
+                   self._stream())
+        return u, gs
+
+    def warp_fwd(self, x: Tensor, flow: Tensor, scale: float) -> Tensor:
+        self._chk(x, flow)
+        B, H, W, Cc = x.shape
+        assert flow.shape == (B, H, W, 8)
+        y = torch.empty_like(x)
+        self._call("lcgan_warp_fwd", x.data_ptr(), flow.data_ptr(), y.data_ptr(), B, H, W, Cc, float(scale), dt_code(x.dtype),
+                   self._stream())
+        return y
+
+    def warp_bwd(self, gy: Tensor, x: Tensor, flow: Tensor, scale: float) -> Tuple[Tensor, Tensor]:
+        self._chk(gy, x, flow)
+        B, H, W, Cc = x.shape
+        gx32 = torch.zeros((B, H, W, Cc), dtype=torch.float32, device=x.device)
+        gflow = torch.empty_like(flow)
+        self._call("lcgan_warp_bwd", gy.data_ptr(), x.data_ptr(), flow.data_ptr(), gx32.data_ptr(), gflow.data_ptr(), B, H, W, Cc,
+                   float(scale), dt_code(x.dtype), self._stream())
+        if x.dtype == torch.float32:
+            return gx32, gflow
+        gx = torch.empty_like(x)
+        self._call("lcgan_cast_from_f32", gx32.data_ptr(), gx.data_ptr(), gx32.numel(), dt_code(x.dtype), self._stream())
+        return gx, gflow
+
+    def mbstd_fwd(self, x: Tensor, G: int, Cy: int) -> Tensor:
+        self._chk(x)
+        N, H, W, Cc = x.shape
+        y = torch.empty((N, H, W, Cy), dtype=x.dtype, device=x.device)
+        self._call("lcgan_mbstd_fwd", x.data_ptr(), y.data_ptr(), N, G, H * W, Cc, Cy, dt_code(x.dtype), self._stream())
+        return y
+
+    def mbstd_bwd(self, gy: Tensor, x: Tensor, G: int) -> Tensor:
+        self._chk(gy, x)
+        N, H, W, Cc = x.shape
+        gx = torch.empty_like(x)
+        self._call("lcgan_mbstd_bwd", gy.data_ptr(), x.data_ptr(), gx.data_ptr(), N, G, H * W, Cc, gy.shape[-1], dt_code(x.dtype),
+                   self._stream())
+        return gx
+
+    def mbstd_bwd2(self, v: Tensor, gy: Tensor, x: Tensor, G: int) -> Tuple[Tensor, Tensor]:
+        self._chk(v, gy, x)
+        N, H, W, Cc = x.shape
+        ggy, gx2 = torch.empty_like(gy), torch.empty_like(x)
+        self._call("lcgan_mbstd_bwd2", v.data_ptr(), gy.data_ptr(), x.data_ptr(), ggy.data_ptr(), gx2.data_ptr(), N, G, H * W, Cc,
+                   gy.shape[-1], dt_code(x.dtype), self._stream())
+        return ggy, gx2
+
+    # ---- RGB 1x1 convs (image is f32 NCHW, w is f32 [Bw,3,C]) ----------------------------------------------
+    def rgb_expand(self, img: Tensor, w: Tensor, bias: Optional[Tensor], bias_scale: float, clog: int, act: int, gain: float,
+                   dtype: torch.dtype) -> Tensor:
+        self._chk(img, w, bias)
+        B, _, H, W = img.shape
+        Cc = w.shape[-1]
+        y = torch.empty((B, H, W, Cc), dtype=dtype, device=img.device)
+        self._call("lcgan_rgb_expand", img.data_ptr(), w.data_ptr(), _p(bias), float(bias_scale), y.data_ptr(), B, H * W, Cc, clog,
+                   int(w.shape[0] > 1), act, float(gain), dt_code(dtype), self._stream())
+        return y
+
+    def rgb_reduce(self, x: Tensor, w: Tensor, bias: Optional[Tensor], bias_scale: float) -> Tensor:
+        self._chk(x, w, bias)
+        B, H, W, Cc = x.shape
+        img = torch.empty((B, 3, H, W), dtype=torch.float32, device=x.device)
+        self._call("lcgan_rgb_reduce", x.data_ptr(), w.data_ptr(), _p(bias), float(bias_scale), img.data_ptr(), B, H * W, Cc,
+                   int(w.shape[0] > 1), dt_code(x.dtype), self._stream())
+        return img
+
+    def rgb_wgrad(self, img: Tensor, feat: Tensor, per_sample: bool) -> Tensor:
+        self._chk(img, feat)
+        B, H, W, Cc = feat.shape
+        gw = torch.zeros((B if per_sample else 1, 3, Cc), dtype=torch.float32, device=feat.device)
+        self._call("lcgan_rgb_wgrad", img.data_ptr(), feat.data_ptr(), gw.data_ptr(), B, H * W, Cc, int(per_sample),
+                   dt_code(feat.dtype), self._stream())
+        return gw
+
+    # ---- layout ---------------------------------------------------------------------------------------------
+    def nchw_to_nhwc(self, src: Tensor, B: int, calloc: int, dtype: torch.dtype) -> Tensor:
+        """src f32 [Bs,Clog,H,W] (Bs == B or 1 = broadcast) -> [B,H,W,calloc]"""
+        self._chk(src)
+        Bs, clog, H, W = src.shape
+        dst = torch.empty((B, H, W, calloc), dtype=dtype, device=src.device)
+        self._call("lcgan_nchw_to_nhwc", src.data_ptr(), dst.data_ptr(), B, H * W, calloc, clog, int(Bs == 1 and B > 1),
+                   dt_code(dtype), self._stream())
+        return dst
+
+    def nhwc_to_nchw(self, src: Tensor, clog: int, reduce: bool) -> Tensor:
+        self._chk(src)
+        B, H, W, Cc = src.shape
+        dst = torch.empty((1 if reduce else B, clog, H, W), dtype=torch.float32, device=src.device)
+        self._call("lcgan_nhwc_to_nchw", src.data_ptr(), dst.data_ptr(), B, H * W, Cc, clog, int(reduce), dt_code(src.dtype),
+                   self._stream())
+        return dst
+
+    # ---- small f32 linears ------------------------------------------------------------------------------------
+    def linear_fwd(self, x: Tensor, w: Tensor, bias: Optional[Tensor], scale: float, bias_scale: float, act: int, gain: float):
+        self._chk(x, w, bias)
+        M, I = x.shape
+        O = w.shape[0]
+        y = torch.empty((M, O), dtype=torch.float32, device=x.device)
+        self._call("lcgan_linear_fwd", x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), M, I, O, float(scale), float(bias_scale),
+                   act, float(gain), self._stream())
+        return y
+
+    def linear_bwd_data(self, gy: Tensor, w: Tensor, scale: float) -> Tensor:
+        self._chk(gy, w)
+        M, O = gy.shape
+        I = w.shape[1]
+        gx = torch.zeros((M, I), dtype=torch.float32, device=gy.device)
+        self._call("lcgan_linear_bwd_data", gy.data_ptr(), w.data_ptr(), gx.data_ptr(), M, I, O, float(scale), self._stream())
+        return gx
+
+    def linear_wgrad(self, gy: Tensor, x: Tensor, scale: float) -> Tensor:
+        self._chk(gy, x)
+        M, O = gy.shape
+        I = x.shape[1]
+        gw = torch.empty((O, I), dtype=torch.float32, device=gy.device)
+        self._call("lcgan_linear_wgrad", gy.data_ptr(), x.data_ptr(), gw.data_ptr(), M, I, O, float(scale), self._stream())
+        return gw
+
+    def colsum(self, gy: Tensor, scale: float) -> Tensor:
+        self._chk(gy)
+        M, O = gy.shape
+        gb = torch.empty((O,), dtype=torch.float32, device=gy.device)
+        self._call("lcgan_colsum", gy.data_ptr(), gb.data_ptr(), M, O, float(scale), self._stream())
+        return gb
+
+    def act_bwd_f32(self, gy: Tensor, y: Tensor, act: int, gain: float) -> Tensor:
+        self._chk(gy, y)
+        gz = torch.empty_like(gy)
+        self._call("lcgan_act_bwd_f32", gy.data_ptr(), y.data_ptr(), gz.data_ptr(), gy.numel(), act, float(gain), self._stream())
+        return gz
+
+    def demod_fwd(self, s: Tensor, wsq: Tensor, ostride: int, eps: float = 1e-8) -> Tensor:
+        self._chk(s, wsq)
+        B, Cc = s.shape
+        O = wsq.shape[0]
+        d = torch.zeros((B, ostride), dtype=torch.float32, device=s.device)
+        self._call("lcgan_demod_fwd", s.data_ptr(), wsq.data_ptr(), d.data_ptr(), B, Cc, O, ostride, float(eps), self._stream())
+        return d
+
+    def demod_bwd(self, gdq: Tensor, d: Tensor, s: Tensor, wsq: Tensor, gs: Tensor) -> Tensor:
+        """gs += demod path (in place); returns gwsq [O,C]"""
+        self._chk(gdq, d, s, wsq, gs)
+        B, Cc = s.shape
+        O = wsq.shape[0]
+        gwsq = torch.empty_like(wsq)
+        self._call("lcgan_demod_bwd", gdq.data_ptr(), d.data_ptr(), s.data_ptr(), wsq.data_ptr(), gs.data_ptr(), gwsq.data_ptr(),
+                   B, Cc, O, d.shape[1], self._stream())
+        return gwsq
+
+    # ---- losses -------------------------------------------------------------------------------------------------
+    def bce_fwd(self, logit: Tensor, target_one: bool) -> Tensor:
+        self._chk(logit)
+        out = torch.empty((), dtype=torch.float32, device=logit.device)
+        self._call("lcgan_bce_fwd", logit.data_ptr(), logit.numel(), int(target_one), out.data_ptr(), self._stream())
+        return out
+
+    def bce_bwd(self, logit: Tensor, target_one: bool, gout: Tensor) -> Tensor:
+        self._chk(logit, gout)
+        g = torch.empty_like(logit)
+        self._call("lcgan_bce_bwd", logit.data_ptr(), logit.numel(), int(target_one), gout.data_ptr(), g.data_ptr(), self._stream())
+        return g
+
+    def contrastive_fwd(self, a: Tensor, p: Tensor, n: Tensor, tau: float):
+        self._chk(a, p, n)
+        B, Dd = a.shape
+        t = torch.empty((B,), dtype=torch.float32, device=a.device)
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        self._call("lcgan_contrastive_fwd", a.data_ptr(), p.data_ptr(), n.data_ptr(), B, Dd, float(tau), t.data_ptr(), out.data_ptr(),
+                   self._stream())
+        return out, t
+
+    def contrastive_bwd(self, a: Tensor, p: Tensor, n: Tensor, t: Tensor, gout: Tensor, tau: float):
+        self._chk(a, p, n, t, gout)
+        B, Dd = a.shape
+        ga, gp, gn = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+        self._call("lcgan_contrastive_bwd", a.data_ptr(), p.data_ptr(), n.data_ptr(), t.data_ptr(), gout.data_ptr(), B, Dd, float(tau),
+                   ga.data_ptr(), gp.data_ptr(), gn.data_ptr(), self._stream())
+        return ga, gp, gn
+
+    def l2norm_fwd(self, x: Tensor, eps: float = 1e-12):
+        self._chk(x)
+        B, Dd = x.shape
+        y = torch.empty_like(x)
+        ns = torch.empty((B,), dtype=torch.float32, device=x.device)
+        self._call("lcgan_l2norm_fwd", x.data_ptr(), y.data_ptr(), ns.data_ptr(), B, Dd, float(eps), self._stream())
+        return y, ns
+
+    def l2norm_bwd(self, gy: Tensor, y: Tensor, ns: Tensor) -> Tensor:
+        self._chk(gy, y, ns)
+        B, Dd = y.shape
+        gx = torch.empty_like(y)
+        self._call("lcgan_l2norm_bwd", gy.data_ptr(), y.data_ptr(), ns.data_ptr(), gx.data_ptr(), B, Dd, self._stream())
+        return gx
+
+    def powsum(self, x: Tensor, pw: int, coef: float) -> Tensor:
+        self._chk(x)
+        out = torch.zeros((), dtype=torch.float32, device=x.device)
+        self._call("lcgan_powsum", x.data_ptr(), x.numel(), pw, float(coef), out.data_ptr(), self._stream())
+        return out
+
+    def powsum_bwd(self, x: Tensor, pw: int, coef: float, gout: Tensor) -> Tensor:
+        self._chk(x, gout)
+        g = torch.empty_like(x)
+        self._call("lcgan_powsum_bwd", x.data_ptr(), x.numel(), pw, float(coef), gout.data_ptr(), g.data_ptr(), self._stream())
+        return g
+
+    def avg_latent(self, w: Tensor, avg: Tensor, beta: float) -> None:
+        self._chk(w, avg)
+        B, Dd = w.shape
+        self._call("lcgan_avg_latent", w.data_ptr(), avg.data_ptr(), B, Dd, float(beta), self._stream())
+
+    # ---- multi-tensor -----------------------------------------------------------------------------------------------
+    def multi_tensor(self, table, op: int, a0: float, a1: float = 0.0, a2: float = 0.0) -> None:
+        """table: lcgan_amd.optim.TensorTable (device descriptor + chunk arrays)."""
+        self._call("lcgan_multi_tensor", table.descs.data_ptr(), table.chunk_tensor.data_ptr(), table.chunk_index.data_ptr(),
+                   table.n_chunks, op, float(a0), float(a1), float(a2), float(table.total), self._stream())
+
+    # ---- profiling --------------------------------------------------------------------------------------------------
+    def prof_enable(self, on: bool) -> None:
+        self.lib.lcgan_prof_enable(int(on))
+
+    def prof_collect(self):
+        import ctypes as C
+        n = 13
+        ms, fl, by = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+        cnt = (C.c_longlong * n)()
+        k = self.lib.lcgan_prof_collect(ms, fl, by, cnt)
+        names = ["conv_igemm", "conv_wgrad", "weight_prep", "stencil", "act_bwd", "warp_fwd", "warp_bwd", "rgb", "linear", "small",
+                 "optim", "layout", "scale_reduce"]
+        return {names[i]: {"ms": ms[i], "flops": fl[i], "bytes": by[i], "count": cnt[i]} for i in range(k)}
+
+
+class _Lazy:
+    """Resolves to HipKernels on first use so that importing lcgan_amd on a CPU box (build check, CPU tests) works,
+    while any attempt to RUN the product without the HIP library raises."""
+    _impl = None
+
+    def __getattr__(self, item):
+        if _Lazy._impl is None:
+            _Lazy._impl = HipKernels()
+        return getattr(_Lazy._impl, item)
+
+
+K = _Lazy()
+
+
+def set_backend(impl) -> None:
+    """Test hook: install another implementation of the HipKernels interface (None restores the HIP library)."""
+    _Lazy._impl = impl
+
+
+def backend_name() -> str:
+    return getattr(K, "name")

@@ -1,0 +1,554 @@
+"""torch.autograd.Function wrappers around the HIP kernels.
+
+Two families:
+  * double-differentiable (discriminator path, needed by the R1 penalty, loss.py:18-34): every backward is itself
+    composed of Functions of this module, so autograd.grad(..., create_graph=True) through the discriminator and a
+    second backward through that graph both run on the HIP kernels.  The convolution triple
+    (Conv2dFn, ConvTransposeFn, ConvWeightGradFn) is closed under differentiation because conv is bilinear.
+  * first-order only (generator path: ModConvFn, Box3ActFn, Up2BoxAddFn, WarpFn) with fused backward kernels.
+
+Internal feature maps are NHWC [B,H,W,C] (C multiple of 8) in `feature dtype` (bf16, or f32 = parity mode).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import kernels as KM
+from .kernels import ACT_LRELU, ACT_NONE, ACT_TANH, ceil8
+
+Tensor = torch.Tensor
+
+
+def _K():
+    return KM.K
+
+
+def _need_lo(x: Tensor) -> bool:
+    return x.dtype == torch.float32
+
+
+# =====================================================================================================
+# double-differentiable convolution triple (EqualizedConv2d, custom_layers.py:28-44)
+# =====================================================================================================
+class Conv2dFn(Function):
+    """y = act(conv_{k,stride}(x, w*wscale) + bias*bias_scale) * gain (+ residual).  w: [A,Bc,k,k] f32 parameter."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, residual, k, stride, act, gain, wscale, bias_scale):
+        assert not (act != ACT_NONE and residual is not None), "residual is only fused on linear (act-free) convs"
+        assert act != ACT_NONE or gain == 1.0, "fold the gain of an act-free conv into wscale"
+        K = _K()
+        A = w.shape[0]
+        pw, _ = K.prep_weight(w, wscale, False, _need_lo(x))
+        y = K.conv_fwd(x, pw, A, k, stride, bias=bias, bias_scale=bias_scale, act=act, gain=gain, residual=residual)
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.cfg = (k, stride, act, gain, wscale, bias_scale, bias is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        k, stride, act, gain, wscale, bias_scale, has_bias, has_res = ctx.cfg
+        gy = gy.contiguous()
+        A = w.shape[0]
+        want_gb = has_bias and ctx.needs_input_grad[2]
+        if act != ACT_NONE or want_gb:
+            gz, gb = ActBwdFn.apply(gy, y, act, gain, A, want_gb, bias_scale)
+        else:
+            gz, gb = gy, None
+        gx = ConvTransposeFn.apply(gz, w, k, stride, wscale, x.shape[-1]) if ctx.needs_input_grad[0] else None
+        gw = ConvWeightGradFn.apply(x, gz, k, stride, wscale, w.shape[0], w.shape[1]) if ctx.needs_input_grad[1] else None
+        gres = gy if (has_res and ctx.needs_input_grad[3]) else None
+        return gx, gw, (gb if want_gb else None), gres, None, None, None, None, None, None
+
+
+class ConvTransposeFn(Function):
+    """gx = adjoint of conv_{k,stride}(., w*wscale) applied to g  (stride 2: the 4-phase transposed convolution)."""
+
+    @staticmethod
+    def forward(ctx, g, w, k, stride, wscale, cin_alloc):
+        K = _K()
+        pw, _ = K.prep_weight(w, wscale, True, _need_lo(g))
+        gx = K.conv_bwd_data(g, pw, w.shape[1], k, stride)
+        assert gx.shape[-1] == cin_alloc
+        ctx.save_for_backward(g, w)
+        ctx.cfg = (k, stride, wscale)
+        return gx
+
+    @staticmethod
+    def backward(ctx, ggx):
+        g, w = ctx.saved_tensors
+        k, stride, wscale = ctx.cfg
+        ggx = ggx.contiguous()
+        gg = Conv2dFn.apply(ggx, w, None, None, k, stride, ACT_NONE, 1.0, wscale, 0.0) if ctx.needs_input_grad[0] else None
+        gw = ConvWeightGradFn.apply(ggx, g, k, stride, wscale, w.shape[0], w.shape[1]) if ctx.needs_input_grad[1] else None
+        return gg, gw, None, None, None, None
+
+
+class ConvWeightGradFn(Function):
+    """gw[A,Bc,k,k] = wscale * sum_positions g (x) x_shifted  (x: conv input side, g: conv output side)."""
+
+    @staticmethod
+    def forward(ctx, x, g, k, stride, wscale, A, Bc):
+        K = _K()
+        gwp = K.conv_wgrad(x, g, A, Bc, k, stride)
+        gw = K.unprep_wgrad(gwp, A, Bc, k, wscale)
+        ctx.save_for_backward(x, g)
+        ctx.cfg = (k, stride, wscale)
+        return gw
+
+    @staticmethod
+    def backward(ctx, ggw):
+        x, g = ctx.saved_tensors
+        k, stride, wscale = ctx.cfg
+        ggw = ggw.contiguous()
+        gx = ConvTransposeFn.apply(g, ggw, k, stride, wscale, x.shape[-1]) if ctx.needs_input_grad[0] else None
+        gg = Conv2dFn.apply(x, ggw, None, None, k, stride, ACT_NONE, 1.0, wscale, 0.0) if ctx.needs_input_grad[1] else None
+        return gx, gg, None, None, None, None, None
+
+
+class ActBwdFn(Function):
+    """(gz, gbias) = (gy * act'(y), bias_scale * sum_{b,h,w} gz).  Linear in gy; y is the saved activation OUTPUT."""
+
+    @staticmethod
+    def forward(ctx, gy, y, act, gain, clog, want_gbias, bias_scale):
+        K = _K()
+        if act == ACT_NONE:
+            _, gb, _ = K.act_bwd_reduce(gy, None, ACT_NONE, 1.0, clog, want_gz=False, want_gbias=want_gbias)
+            gz = gy
+        else:
+            gz, gb, _ = K.act_bwd_reduce(gy, y, act, gain, clog, want_gz=True, want_gbias=want_gbias)
+        if gb is None:
+            gb = gy.new_zeros((0,), dtype=torch.float32)
+        else:
+            gb = gb * bias_scale if bias_scale != 1.0 else gb
+        ctx.save_for_backward(y)
+        ctx.cfg = (act, gain, clog)
+        ctx.mark_non_differentiable(gb)
+        return gz, gb
+
+    @staticmethod
+    def backward(ctx, ggz, _ggb):
+        (y,) = ctx.saved_tensors
+        act, gain, clog = ctx.cfg
+        if act == ACT_NONE:
+            return ggz, None, None, None, None, None, None
+        g, _ = ActBwdFn.apply(ggz.contiguous(), y, act, gain, clog, False, 1.0)
+        return g, None, None, None, None, None, None
+
+
+class Box3Fn(Function):
+    """3x3 box filter (zero padding, /9) -- linear and self-adjoint (custom_layers.py:196-198)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _K().box3_act(x, ACT_NONE, 1.0)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return Box3Fn.apply(gy.contiguous())
+
+
+class AvgPool2Fn(Function):
+    """F.avg_pool2d(2,2), custom_layers.py:202."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _K().avgpool2(x)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return AvgPool2TFn.apply(gy.contiguous())
+
+
+class AvgPool2TFn(Function):
+    @staticmethod
+    def forward(ctx, gy):
+        return _K().avgpool2_bwd(gy)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        return AvgPool2Fn.apply(ggx.contiguous())
+
+
+# ---- 1x1 convs that touch the f32 NCHW image; wt is [Bw,3,C] f32 (built from the parameter with torch glue) ----
+class RGBExpandFn(Function):
+    """feat[b,p,c] = act(sum_o img[b,o,p] wt[bw,o,c] + bias[c]*bias_scale) * gain     (fromRGB: cnn.py:20-21)"""
+
+    @staticmethod
+    def forward(ctx, img, wt, bias, bias_scale, clog, act, gain, dtype):
+        y = _K().rgb_expand(img, wt, bias, bias_scale, clog, act, gain, dtype)
+        ctx.save_for_backward(img, wt, y if act != ACT_NONE else None)
+        ctx.cfg = (bias_scale, clog, act, gain, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        img, wt, y = ctx.saved_tensors
+        bias_scale, clog, act, gain, has_bias = ctx.cfg
+        gy = gy.contiguous()
+        want_gb = has_bias and ctx.needs_input_grad[2]
+        if act != ACT_NONE or want_gb:
+            gz, gb = ActBwdFn.apply(gy, y, act, gain, clog, want_gb, bias_scale)
+        else:
+            gz, gb = gy, None
+        gimg = RGBReduceFn.apply(gz, wt, None, 0.0) if ctx.needs_input_grad[0] else None
+        gwt = RGBWeightGradFn.apply(img, gz, wt.shape[0] > 1) if ctx.needs_input_grad[1] else None
+        return gimg, gwt, (gb if want_gb else None), None, None, None, None, None
+
+
+class RGBReduceFn(Function):
+    """img[b,o,p] = sum_c feat[b,p,c] wt[bw,o,c] + bias[o]*bias_scale                 (toRGB: custom_layers.py:181)"""
+
+    @staticmethod
+    def forward(ctx, feat, wt, bias, bias_scale):
+        ctx.save_for_backward(feat, wt)
+        ctx.cfg = (bias_scale, bias is not None)
+        return _K().rgb_reduce(feat, wt, bias, bias_scale)
+
+    @staticmethod
+    def backward(ctx, gimg):
+        feat, wt = ctx.saved_tensors
+        bias_scale, has_bias = ctx.cfg
+        gimg = gimg.contiguous()
+        gfeat = (RGBExpandFn.apply(gimg, wt, None, 0.0, wt.shape[-1], ACT_NONE, 1.0, feat.dtype)
+                 if ctx.needs_input_grad[0] else None)
+        gwt = RGBWeightGradFn.apply(gimg, feat, wt.shape[0] > 1) if ctx.needs_input_grad[1] else None
+        gb = gimg.sum(dim=(0, 2, 3)) * bias_scale if (has_bias and ctx.needs_input_grad[2]) else None   # 3 numbers
+        return gfeat, gwt, gb, None
+
+
+class RGBWeightGradFn(Function):
+    """gwt[bw,o,c] = sum_p img[b,o,p] feat[b,p,c]"""
+
+    @staticmethod
+    def forward(ctx, img, feat, per_sample):
+        ctx.save_for_backward(img, feat)
+        ctx.per_sample = per_sample
+        return _K().rgb_wgrad(img, feat, per_sample)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        img, feat = ctx.saved_tensors
+        ggw = ggw.contiguous()
+        gimg = RGBReduceFn.apply(feat, ggw, None, 0.0) if ctx.needs_input_grad[0] else None
+        gfeat = (RGBExpandFn.apply(img, ggw, None, 0.0, ggw.shape[-1], ACT_NONE, 1.0, feat.dtype)
+                 if ctx.needs_input_grad[1] else None)
+        return gimg, gfeat, None
+
+
+# ---- minibatch stddev (custom_layers.py:237-256) ---------------------------------------------------------
+class MbstdFn(Function):
+    @staticmethod
+    def forward(ctx, x, G):
+        ctx.save_for_backward(x)
+        ctx.G = G
+        return _K().mbstd_fwd(x, G, ceil8(x.shape[-1] + 1))
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        return MbstdBwdFn.apply(gy.contiguous(), x, ctx.G), None
+
+
+class MbstdBwdFn(Function):
+    @staticmethod
+    def forward(ctx, gy, x, G):
+        ctx.save_for_backward(gy, x)
+        ctx.G = G
+        return _K().mbstd_bwd(gy, x, G)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, v):
+        gy, x = ctx.saved_tensors
+        ggy, gx2 = _K().mbstd_bwd2(v.contiguous(), gy, x, ctx.G)
+        return ggy, gx2, None
+
+
+# ---- layout converts -----------------------------------------------------------------------------------------
+class ToNCHWFn(Function):
+    """feat [B,H,W,Calloc] -> f32 [B,Clog,H,W] (the order `flatten(1)` sees in the reference, custom_layers.py:232)."""
+
+    @staticmethod
+    def forward(ctx, feat, clog):
+        ctx.cfg = (feat.shape[-1], feat.dtype)
+        return _K().nhwc_to_nchw(feat, clog, False)
+
+    @staticmethod
+    def backward(ctx, g):
+        calloc, dtype = ctx.cfg
+        return ToNHWCFn.apply(g.contiguous(), calloc, dtype), None
+
+
+class ToNHWCFn(Function):
+    @staticmethod
+    def forward(ctx, src, calloc, dtype):
+        ctx.clog = src.shape[1]
+        return _K().nchw_to_nhwc(src, src.shape[0], calloc, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ToNCHWFn.apply(g.contiguous(), ctx.clog), None, None
+
+
+class ConstInputFn(Function):
+    """const [C,4,4] f32 -> [B,4,4,C] feature map (cnn.py:106); backward sums over the batch."""
+
+    @staticmethod
+    def forward(ctx, const, B, dtype):
+        return _K().nchw_to_nhwc(const.unsqueeze(0).contiguous(), B, ceil8(const.shape[0]), dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        return _K().nhwc_to_nchw(g.contiguous(), g.shape[-1], True)[0], None, None
+
+
+# ---- small f32 linear triple (EqualizedLinear, custom_layers.py:17-25) ---------------------------------------------
+class LinearFn(Function):
+    """y = act(scale * x @ w^T + bias*bias_scale) * gain ; x [M,I], w [O,I]"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, scale, bias_scale, act, gain):
+        y = _K().linear_fwd(x, w, bias, scale, bias_scale, act, gain)
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.cfg = (scale, bias_scale, act, gain, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        scale, bias_scale, act, gain, has_bias = ctx.cfg
+        gy = gy.contiguous()
+        gz = ActBwdF32Fn.apply(gy, y, act, gain) if act != ACT_NONE else (gy * gain if gain != 1.0 else gy)
+        gx = LinearTFn.apply(gz, w, scale) if ctx.needs_input_grad[0] else None
+        gw = LinearWeightGradFn.apply(gz, x, scale) if ctx.needs_input_grad[1] else None
+        gb = _K().colsum(gz.detach().contiguous(), bias_scale) if (has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None, None, None, None
+
+
+class LinearTFn(Function):
+    """gx = scale * g @ w"""
+
+    @staticmethod
+    def forward(ctx, g, w, scale):
+        ctx.save_for_backward(g, w)
+        ctx.scale = scale
+        return _K().linear_bwd_data(g, w, scale)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        g, w = ctx.saved_tensors
+        ggx = ggx.contiguous()
+        gg = LinearFn.apply(ggx, w, None, ctx.scale, 0.0, ACT_NONE, 1.0) if ctx.needs_input_grad[0] else None
+        gw = LinearWeightGradFn.apply(g, ggx, ctx.scale) if ctx.needs_input_grad[1] else None
+        return gg, gw, None
+
+
+class LinearWeightGradFn(Function):
+    """gw[O,I] = scale * g^T @ x"""
+
+    @staticmethod
+    def forward(ctx, g, x, scale):
+        ctx.save_for_backward(g, x)
+        ctx.scale = scale
+        return _K().linear_wgrad(g, x, scale)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        g, x = ctx.saved_tensors
+        ggw = ggw.contiguous()
+        gg = LinearFn.apply(x, ggw, None, ctx.scale, 0.0, ACT_NONE, 1.0) if ctx.needs_input_grad[0] else None
+        gx = LinearTFn.apply(g, ggw, ctx.scale) if ctx.needs_input_grad[1] else None
+        return gg, gx, None
+
+
+class ActBwdF32Fn(Function):
+    @staticmethod
+    def forward(ctx, gy, y, act, gain):
+        ctx.save_for_backward(y)
+        ctx.cfg = (act, gain)
+        return _K().act_bwd_f32(gy, y, act, gain)
+
+    @staticmethod
+    def backward(ctx, gg):
+        (y,) = ctx.saved_tensors
+        return ActBwdF32Fn.apply(gg.contiguous(), y, *ctx.cfg), None, None, None
+
+
+# =====================================================================================================
+# generator path (first-order backward, fused kernels)
+# =====================================================================================================
+class ModConvFn(Function):
+    """Modulated + demodulated convolution (ModulatedConv2d, custom_layers.py:47-86) without per-sample weights:
+         y = act(d[b,o] * conv(s[b,c] * x, W*c_eq) + bias) * gain ,   d = rsqrt(sum_c s^2 sum_k (W c_eq)^2 + eps)
+       up == 2 runs the 4-phase transposed convolution (F.conv_transpose2d stride 2, pad 1, output_padding 1)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, s, up, act, gain):
+        K = _K()
+        O, Cin, k, _ = w.shape
+        c_eq = 1.0 / math.sqrt(Cin * k * k)
+        s = s.contiguous()
+        pw, wsq = K.prep_weight(w, c_eq, False, _need_lo(x), want_wsq=True)     # [t][O][Cin] serves conv AND up-conv forward
+        d = K.demod_fwd(s, wsq, ceil8(O))
+        if up == 2:
+            y = K.conv_bwd_data(x, pw, O, k, 2, pre=s, post=d, bias=bias, bias_scale=1.0, act=act, gain=gain)
+        else:
+            y = K.conv_fwd(x, pw, O, k, 1, pre=s, post=d, bias=bias, bias_scale=1.0, act=act, gain=gain)
+        ctx.save_for_backward(x, w, bias, s, d, wsq, y)
+        ctx.cfg = (up, act, gain, c_eq)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        K = _K()
+        x, w, bias, s, d, wsq, y = ctx.saved_tensors
+        up, act, gain, c_eq = ctx.cfg
+        O, Cin, k, _ = w.shape
+        gy = gy.contiguous()
+        # activation backward + bias gradient + demod statistic  gdq[b,o] = sum_p gz * (ypre - bias)
+        gz, gb, gdq = K.act_bwd_reduce(gy, y, act, gain, O, want_gz=(act != ACT_NONE), bias=bias, bias_scale=1.0,
+                                       want_gbias=True, want_gdq=True)
+        if gz is None:
+            gz = gy
+        pwT, _ = K.prep_weight(w, c_eq, True, _need_lo(x))                       # [t][Cin][O]
+        if up == 2:
+            u = K.conv_fwd(gz, pwT, Cin, k, 2, pre=d)                            # adjoint of the transposed conv
+        else:
+            u = K.conv_bwd_data(gz, pwT, Cin, k, 1, pre=d)
+        gx, gs = K.scale_reduce(u, x, s)                                         # gx = s*u (in place), gs = sum_p x*u
+        gwsq = K.demod_bwd(gdq, d, s, wsq, gs)                                   # gs += demod path
+        if up == 2:
+            gwp = K.conv_wgrad(gz, x, Cin, O, k, 2, pre_x=d, pre_g=s)            # [t][Cin][O]
+            gw = K.unprep_wgrad(gwp, O, Cin, k, c_eq, transposed=True, w=w, gwsq=gwsq)
+        else:
+            gwp = K.conv_wgrad(x, gz, O, Cin, k, 1, pre_x=s, pre_g=d)            # [t][O][Cin]
+            gw = K.unprep_wgrad(gwp, O, Cin, k, c_eq, transposed=False, w=w, gwsq=gwsq)
+        return gx, gw, gb, gs, None, None, None
+
+
+class Box3ActFn(Function):
+    """y = act(box3(x)) * gain  (custom_layers.py:150-151, 154-155)"""
+
+    @staticmethod
+    def forward(ctx, x, act, gain):
+        y = _K().box3_act(x, act, gain)
+        ctx.save_for_backward(y)
+        ctx.cfg = (act, gain)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return _K().box3_act_bwd(gy.contiguous(), y, *ctx.cfg), None, None
+
+
+class Up2BoxAddFn(Function):
+    """y = box3(nearest_x2(x)) + residual   (custom_layers.py:146-147, 159)"""
+
+    @staticmethod
+    def forward(ctx, x, residual):
+        return _K().up2box(x, residual)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        gy = gy.contiguous()
+        return _K().up2box_bwd(gy), gy
+
+
+class WarpFn(Function):
+    """bicubic grid_sample with the base grid + flow*scale built in the kernel (custom_layers.py:127-134, 162-165)"""
+
+    @staticmethod
+    def forward(ctx, x, flow, scale):
+        ctx.save_for_backward(x, flow)
+        ctx.scale = scale
+        return _K().warp_fwd(x, flow, scale)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, flow = ctx.saved_tensors
+        gx, gflow = _K().warp_bwd(gy.contiguous(), x, flow, ctx.scale)
+        return gx, gflow, None
+
+
+# =====================================================================================================
+# losses (first-order)
+# =====================================================================================================
+class BCELogitsFn(Function):
+    """mean softplus(-+logit): F.binary_cross_entropy_with_logits against all-ones / all-zeros (worker.py:156-157,191)"""
+
+    @staticmethod
+    def forward(ctx, logit, target_one):
+        logit = logit.contiguous()
+        ctx.save_for_backward(logit)
+        ctx.t = target_one
+        return _K().bce_fwd(logit, target_one)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (logit,) = ctx.saved_tensors
+        return _K().bce_bwd(logit, ctx.t, g.contiguous()), None
+
+
+class ContrastiveFn(Function):
+    """loss.py:9-15"""
+
+    @staticmethod
+    def forward(ctx, a, p, n, tau):
+        a, p, n = a.contiguous(), p.contiguous(), n.contiguous()
+        out, t = _K().contrastive_fwd(a, p, n, tau)
+        ctx.save_for_backward(a, p, n, t)
+        ctx.tau = tau
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        a, p, n, t = ctx.saved_tensors
+        ga, gp, gn = _K().contrastive_bwd(a, p, n, t, g.contiguous(), ctx.tau)
+        return ga, gp, gn, None
+
+
+class L2NormalizeFn(Function):
+    """F.normalize(x) (cnn.py:40-41)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        y, ns = _K().l2norm_fwd(x.contiguous())
+        ctx.save_for_backward(y, ns)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        y, ns = ctx.saved_tensors
+        return _K().l2norm_bwd(gy.contiguous(), y, ns)
+
+
+class PowSumFn(Function):
+    """coef * sum |x|^pw  -- pw=1: L1 sparsity (worker.py:207-209); pw=2: R1 square sum (loss.py:20-23)."""
+
+    @staticmethod
+    def forward(ctx, x, pw, coef):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.cfg = (pw, coef)
+        return _K().powsum(x.view(-1), pw, coef)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return _K().powsum_bwd(x.view(-1), ctx.cfg[0], ctx.cfg[1], g.contiguous()).view_as(x), None, None

@@ -1,0 +1,343 @@
+"""CPU emulation of the kernel interface `lcgan_amd.kernels.HipKernels`  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Each method restates, with plain torch fp32 ops (and torch autograd for the backward kernels), what the HIP kernel of
+the same name computes on the same NHWC operands.  Uses:
+  * CPU tests install it with `lcgan_amd.kernels.set_backend()` to check the host-side autograd wiring (ops.py,
+    custom_layers.py, cnn.py, worker.py) against the oracle without a GPU;
+  * GPU tests call the HIP kernel and this emulation on identical inputs (per-kernel parity).
+Only tests may import this module.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+ACT_NONE, ACT_LRELU, ACT_TANH = 0, 1, 2
+SLOPE = 0.2
+
+
+def ceil8(n):
+    return (n + 7) // 8 * 8
+
+
+def nchw(x):      # NHWC any dtype -> NCHW f32
+    return x.float().permute(0, 3, 1, 2)
+
+
+def nhwc(y, dtype, calloc=None):   # NCHW f32 -> NHWC dtype (zero-padded to calloc channels)
+    if calloc is not None and y.shape[1] < calloc:
+        y = F.pad(y, (0, 0, 0, 0, 0, calloc - y.shape[1]))
+    return y.permute(0, 2, 3, 1).contiguous().to(dtype)
+
+
+def act_fwd(v, act):
+    if act == ACT_LRELU:
+        return F.leaky_relu(v, SLOPE)
+    if act == ACT_TANH:
+        return torch.tanh(v)
+    return v
+
+
+def act_grad_from_out(y, act, gain):
+    if act == ACT_LRELU:
+        return torch.where(y > 0, torch.ones_like(y), torch.full_like(y, SLOPE)) * gain
+    if act == ACT_TANH:
+        t = y / gain
+        return (1 - t * t) * gain
+    return torch.full_like(y, gain)
+
+
+def rb(x, like_dtype):
+    """round to the feature dtype the HIP kernel stages operands in (bf16 mode rounds, f32 mode keeps ~fp32)"""
+    return x.to(torch.bfloat16).float() if like_dtype == torch.bfloat16 else x
+
+
+class EmuWeight:
+    def __init__(self, P4, N, Kpad, k, need_lo):
+        self.P4, self.N, self.Kpad, self.k, self.need_lo = P4, N, Kpad, k, need_lo
+        self.hi, self.lo = P4, (P4 if need_lo else None)
+
+
+class EmuTable:
+    def __init__(self, entries):
+        self.entries = entries
+
+
+class EmulatedKernels:
+    name = "cpu-emulation"
+
+    # ---- conv family ------------------------------------------------------------------------------------
+    def prep_weight(self, w, scale, transpose, need_lo, want_wsq=False):
+        ws = w.detach().float() * scale
+        wsq = ws.square().sum(dim=(2, 3)) if want_wsq else None
+        P4 = ws.transpose(0, 1).contiguous() if transpose else ws
+        if not need_lo:
+            P4 = P4.to(torch.bfloat16).float()
+        Kc = P4.shape[1]
+        return EmuWeight(P4, P4.shape[0], (Kc + 31) // 32 * 32, w.shape[-1], need_lo), wsq
+
+    def unprep_wgrad(self, gwp, A, Bc, k, scale, transposed=False, w=None, gwsq=None):
+        g = gwp.view(k, k, Bc, A).permute(3, 2, 0, 1) if transposed else gwp.view(k, k, A, Bc).permute(2, 3, 0, 1)
+        gw = g * scale
+        if gwsq is not None:
+            gw = gw + 2 * scale * scale * w.detach() * gwsq[:, :, None, None]
+        return gw.contiguous()
+
+    def _epilogue(self, v, N, post, bias, bias_scale, act, gain, residual, dtype):
+        if post is not None:
+            v = v * post[:, :N, None, None]
+        if bias is not None:
+            v = v + (bias.detach() * bias_scale).view(1, -1, 1, 1)
+        v = act_fwd(v, act) * gain
+        y = nhwc(v, torch.float32, ceil8(N))
+        if residual is not None:
+            y = y + residual.float()
+        return y.to(dtype)
+
+    def conv_fwd(self, x, pw, N, k, stride, pre=None, post=None, bias=None, bias_scale=1.0, act=ACT_NONE, gain=1.0, residual=None):
+        Kc = pw.P4.shape[1]
+        xs = nchw(x)[:, :Kc]
+        if pre is not None:
+            xs = rb(xs * pre[:, :Kc, None, None], x.dtype)
+        v = F.conv2d(xs, pw.P4, stride=stride, padding=k // 2)
+        return self._epilogue(v, N, post, bias, bias_scale, act, gain, residual, x.dtype)
+
+    def conv_bwd_data(self, g, pw, N, k, stride, pre=None, post=None, bias=None, bias_scale=1.0, act=ACT_NONE, gain=1.0, residual=None):
+        Kc = pw.P4.shape[1]
+        gs = nchw(g)[:, :Kc]
+        if pre is not None:
+            gs = rb(gs * pre[:, :Kc, None, None], g.dtype)
+        v = F.conv_transpose2d(gs, pw.P4.permute(1, 0, 2, 3), stride=stride, padding=k // 2, output_padding=stride - 1)
+        return self._epilogue(v, N, post, bias, bias_scale, act, gain, residual, g.dtype)
+
+    def conv_wgrad(self, x, g, A, Bc, k, stride, pre_x=None, pre_g=None):
+        xs, gs = nchw(x)[:, :Bc], nchw(g)[:, :A]
+        if pre_x is not None:
+            xs = rb(xs * pre_x[:, :Bc, None, None], x.dtype)
+        if pre_g is not None:
+            gs = rb(gs * pre_g[:, :A, None, None], x.dtype)
+        gw = torch.nn.grad.conv2d_weight(xs, (A, Bc, k, k), gs, stride=stride, padding=k // 2)
+        return gw.permute(2, 3, 0, 1).reshape(k * k, A, Bc).contiguous()
+
+    # ---- stencils ---------------------------------------------------------------------------------------
+    def box3_act(self, x, act, gain):
+        return nhwc(act_fwd(F.avg_pool2d(nchw(x), 3, 1, 1), act) * gain, x.dtype)
+
+    def box3_act_bwd(self, gy, y, act, gain):
+        gz = nchw(gy) * (act_grad_from_out(nchw(y), act, gain) if act != ACT_NONE else gain)
+        return nhwc(F.avg_pool2d(gz, 3, 1, 1), gy.dtype)
+
+    def up2box(self, x, residual):
+        y = F.avg_pool2d(F.interpolate(nchw(x), scale_factor=2, mode="nearest"), 3, 1, 1)
+        y = nhwc(y, torch.float32)
+        if residual is not None:
+            y = y + residual.float()
+        return y.to(x.dtype)
+
+    def up2box_bwd(self, gy):
+        B, H2, W2, C = gy.shape
+        x = torch.zeros(B, C, H2 // 2, W2 // 2, requires_grad=True)
+        with torch.enable_grad():
+            y = F.avg_pool2d(F.interpolate(x, scale_factor=2, mode="nearest"), 3, 1, 1)
+            (gx,) = torch.autograd.grad(y, x, nchw(gy))
+        return nhwc(gx, gy.dtype)
+
+    def avgpool2(self, x):
+        return nhwc(F.avg_pool2d(nchw(x), 2, 2), x.dtype)
+
+    def avgpool2_bwd(self, gy):
+        return nhwc(F.interpolate(nchw(gy), scale_factor=2, mode="nearest") * 0.25, gy.dtype)
+
+    def act_bwd_reduce(self, gy, y, act, gain, clog, want_gz=True, bias=None, bias_scale=1.0, want_gbias=False, want_gdq=False):
+        g = gy.float()
+        yo = y.float() if y is not None else None
+        z = g * act_grad_from_out(yo, act, gain) if act != ACT_NONE else g * gain
+        gz = z.to(gy.dtype) if want_gz else None
+        gbias = z.sum(dim=(0, 1, 2))[:clog].contiguous() if want_gbias else None
+        gdq = None
+        if want_gdq:
+            t = yo / gain
+            if act == ACT_LRELU:
+                t = torch.where(t < 0, t / SLOPE, t)
+            bv = torch.zeros(gy.shape[-1])
+            if bias is not None:
+                bv[:clog] = bias.detach() * bias_scale
+            gdq = (z * (t - bv)).sum(dim=(1, 2)).contiguous()
+        return gz, gbias, gdq
+
+    def scale_reduce(self, u, x, s):
+        uf = u.float()
+        gs = (uf * x.float()).sum(dim=(1, 2)).contiguous()
+        u.copy_((uf * s[:, None, None, :]).to(u.dtype))
+        return u, gs
+
+    @staticmethod
+    def _grid(flow, H, W, scale):
+        gy_, gx_ = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+        base = torch.stack((2 * gx_ / (W - 1) - 1, 2 * gy_ / (H - 1) - 1), dim=-1)[None]
+        return base + flow[..., :2] * scale
+
+    def warp_fwd(self, x, flow, scale):
+        B, H, W, C = x.shape
+        y = F.grid_sample(nchw(x), self._grid(flow.float(), H, W, scale), mode="bicubic", padding_mode="zeros", align_corners=False)
+        return nhwc(y, x.dtype)
+
+    def warp_bwd(self, gy, x, flow, scale):
+        B, H, W, C = x.shape
+        xf = nchw(x).detach().requires_grad_(True)
+        ff = flow.float().detach().requires_grad_(True)
+        with torch.enable_grad():
+            y = F.grid_sample(xf, self._grid(ff, H, W, scale), mode="bicubic", padding_mode="zeros", align_corners=False)
+            gx, gf = torch.autograd.grad(y, [xf, ff], nchw(gy))
+        gf = gf.clone()
+        gf[..., 2:] = 0
+        return nhwc(gx, x.dtype), gf.to(flow.dtype)
+
+    @staticmethod
+    def _mbstd_stat(x, G):        # x: [N,H,W,C] f32 -> stat broadcast [N,H,W,1]
+        N, H, W, C = x.shape
+        y = x.reshape(G, -1, H, W, C)
+        y = y - y.mean(dim=0)
+        y = (y.square().mean(dim=0) + 1e-8).sqrt().mean(dim=[1, 2, 3])          # [M]
+        return y.reshape(1, -1, 1, 1, 1).expand(G, -1, H, W, 1).reshape(N, H, W, 1)
+
+    def _mbstd(self, x, G, Cy):
+        N, H, W, C = x.shape
+        return torch.cat([x, self._mbstd_stat(x, G), x.new_zeros(N, H, W, Cy - C - 1)], dim=-1)
+
+    def mbstd_fwd(self, x, G, Cy):
+        return self._mbstd(x.float(), G, Cy).to(x.dtype)
+
+    def mbstd_bwd(self, gy, x, G):
+        xf = x.float().detach().requires_grad_(True)
+        with torch.enable_grad():
+            (gx,) = torch.autograd.grad(self._mbstd(xf, G, gy.shape[-1]), xf, gy.float())
+        return gx.to(x.dtype)
+
+    def mbstd_bwd2(self, v, gy, x, G):
+        xf = x.float().detach().requires_grad_(True)
+        gf = gy.float().detach().requires_grad_(True)
+        with torch.enable_grad():
+            (gx,) = torch.autograd.grad(self._mbstd(xf, G, gy.shape[-1]), xf, gf, create_graph=True)
+            ggy, gx2 = torch.autograd.grad(gx, [gf, xf], v.float())
+        return ggy.to(gy.dtype), gx2.to(x.dtype)
+
+    # ---- RGB ----------------------------------------------------------------------------------------------
+    def rgb_expand(self, img, w, bias, bias_scale, clog, act, gain, dtype):
+        B = img.shape[0]
+        wb = w.detach() if w.shape[0] > 1 else w.detach().expand(B, -1, -1)
+        v = torch.einsum("bohw,boc->bhwc", img.float(), wb)
+        if bias is not None:
+            v = v + F.pad(bias.detach() * bias_scale, (0, v.shape[-1] - clog))
+        v = act_fwd(v, act) * gain
+        v[..., clog:] = 0
+        return v.to(dtype).contiguous()
+
+    def rgb_reduce(self, x, w, bias, bias_scale):
+        B = x.shape[0]
+        wb = w.detach() if w.shape[0] > 1 else w.detach().expand(B, -1, -1)
+        img = torch.einsum("bhwc,boc->bohw", x.float(), wb)
+        if bias is not None:
+            img = img + (bias.detach() * bias_scale).view(1, 3, 1, 1)
+        return img.contiguous()
+
+    def rgb_wgrad(self, img, feat, per_sample):
+        gw = torch.einsum("bohw,bhwc->boc", img.float(), feat.float())
+        return gw.contiguous() if per_sample else gw.sum(0, keepdim=True).contiguous()
+
+    # ---- layout ---------------------------------------------------------------------------------------------
+    def nchw_to_nhwc(self, src, B, calloc, dtype):
+        s = src.float()
+        if s.shape[0] == 1 and B > 1:
+            s = s.expand(B, -1, -1, -1)
+        return nhwc(s, dtype, calloc)
+
+    def nhwc_to_nchw(self, src, clog, reduce):
+        y = nchw(src)[:, :clog]
+        return (y.sum(0, keepdim=True) if reduce else y).contiguous()
+
+    # ---- linears ----------------------------------------------------------------------------------------------
+    def linear_fwd(self, x, w, bias, scale, bias_scale, act, gain):
+        v = x @ w.detach().t() * scale
+        if bias is not None:
+            v = v + bias.detach() * bias_scale
+        return act_fwd(v, act) * gain
+
+    def linear_bwd_data(self, gy, w, scale):
+        return gy @ w.detach() * scale
+
+    def linear_wgrad(self, gy, x, scale):
+        return gy.t() @ x * scale
+
+    def colsum(self, gy, scale):
+        return gy.sum(0) * scale
+
+    def act_bwd_f32(self, gy, y, act, gain):
+        return gy * act_grad_from_out(y, act, gain)
+
+    def demod_fwd(self, s, wsq, ostride, eps=1e-8):
+        d = torch.zeros(s.shape[0], ostride)
+        d[:, :wsq.shape[0]] = torch.rsqrt(s.square() @ wsq.t() + eps)
+        return d
+
+    def demod_bwd(self, gdq, d, s, wsq, gs):
+        O = wsq.shape[0]
+        gq = -0.5 * gdq[:, :O] * d[:, :O] ** 2
+        gs += 2 * s * (gq @ wsq)
+        return gq.t() @ s.square()
+
+    # ---- losses ---------------------------------------------------------------------------------------------------
+    def bce_fwd(self, logit, target_one):
+        return F.softplus(-logit if target_one else logit).mean()
+
+    def bce_bwd(self, logit, target_one, gout):
+        sgn = -1.0 if target_one else 1.0
+        return gout * sgn * torch.sigmoid(sgn * logit) / logit.numel()
+
+    def contrastive_fwd(self, a, p, n, tau):
+        t = ((a * n).sum(1) - (a * p).sum(1)) / tau
+        return F.softplus(t).mean(), t
+
+    def contrastive_bwd(self, a, p, n, t, gout, tau):
+        k = (gout * torch.sigmoid(t) / (a.shape[0] * tau))[:, None]
+        return k * (n - p), -k * a, k * a
+
+    def l2norm_fwd(self, x, eps=1e-12):
+        ns = x.norm(dim=1).clamp_min(eps)
+        return x / ns[:, None], ns
+
+    def l2norm_bwd(self, gy, y, ns):
+        return (gy - y * (gy * y).sum(1, keepdim=True)) / ns[:, None]
+
+    def powsum(self, x, pw, coef):
+        return (x.abs().sum() if pw == 1 else x.square().sum()) * coef
+
+    def powsum_bwd(self, x, pw, coef, gout):
+        return gout * coef * (torch.sign(x) if pw == 1 else 2 * x)
+
+    def avg_latent(self, w, avg, beta):
+        m = w.mean(0)
+        avg.copy_(m + beta * (avg - m))
+
+    # ---- multi-tensor ---------------------------------------------------------------------------------------------------
+    def multi_tensor(self, table, op, a0, a1=0.0, a2=0.0):
+        for e in table.entries:
+            if op == 0:
+                p, g, m, v, f0, f1 = e
+                m.mul_(a0).add_(g, alpha=1 - a0)
+                v.mul_(a1).addcmul_(g, g, value=1 - a1)
+                p.sub_(f0 * m / (v.sqrt() * f1 + a2))
+            elif op == 1:
+                pe, ps = e[0], e[1]
+                pe.copy_(ps + a0 * (pe - ps))
+            else:
+                e[0].copy_(e[1] * a0)
+
+    def prof_enable(self, on):
+        pass
+
+    def prof_collect(self):
+        return {}
