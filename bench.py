@@ -1,0 +1,150 @@
+"""bench.py -- images/sec of the LC-GAN G+D training iteration on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one full iteration in the reference's order (loader.py:45-54: train_generator -> ema_update -> train_discriminator)
+of the odd+R1 type (`epoch % 8 == 1`), which is what BASELINE.json configs[1] names: 256x256, GLOBAL batch 32 (split over the
+ranks like worker.py:35), bf16 feature maps / fp32 accumulation, synthetic data resident in HBM, reference-style random init.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+# algorithmic dense-contraction work (2*MAC of conv + linear only) per image, SURVEY.md section 8 / BASELINE.md section 3
+G_FWD = {256: 112.569e9, 512: 142.987e9, 1024: 173.756e9}
+D_FWD = {256: 93.063e9, 512: 123.178e9, 1024: 153.344e9}
+PEAK_BF16_DENSE = 2.5e15          # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+
+
+def flops_per_image(res: int, epoch: int) -> float:
+    g, d = G_FWD[res], D_FWD[res]
+    if epoch % 2 == 0:
+        return 10 * g + 18 * d + 15 * 0.072e9
+    return 4 * g + (11 if epoch % 8 == 1 else 8) * d
+
+
+def cpu_baseline(res: int, batch: int):
+    """The CPU oracle (oracle/lcgan_ref.py, a port of the reference's fp32 PyTorch path) timed on the host cores:
+    ONE odd+R1 iteration (G step + D step, no optimiser) at `batch` images."""
+    from oracle import lcgan_ref as O
+    from oracle.weights import seeded_state, seeded_tensor
+    GP, DP = seeded_state(O.g_param_shapes(res), 1001), seeded_state(O.d_param_shapes(res), 1002)
+    z = tuple(seeded_tensor((batch, 64), 10 + i) for i in range(4))
+    real = tuple(seeded_tensor((batch, 3, res, res), 20 + i, "uniform_pm1") for i in range(3))
+    t0 = time.perf_counter()
+    O.g_step(GP, DP, res, 1, z)
+    O.d_step(GP, DP, res, 1, z[:2], real)
+    dt = time.perf_counter() - t0
+    return {"value": batch / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 odd+R1 iteration (G step + D step, fp32, no optimiser) at {res}x{res}, batch {batch}: {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--res", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=32, help="GLOBAL batch (worker.py:35 splits it over the ranks)")
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--epoch-type", choices=["r1", "odd", "even", "cycle"], default="r1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from lcgan_amd import config, kernels, loader, worker
+    from tests.helpers import make_args
+    config.set_feature_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
+    assert kernels.backend_name() == "hip"
+    args = make_args(a.res, a.batch)
+    torch.manual_seed(0)                                   # identical reference-style init on every rank
+    w = worker.WORKER(args, local_rank, world)
+    torch.manual_seed(1 + rank)                            # different latents per rank
+
+    def epoch_of(i):
+        return {"r1": 1 + 8 * i, "odd": 3 + 8 * i, "even": 8 * i, "cycle": i}[a.epoch_type]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        loader.train_iteration(w, args, epoch_of(i))
+    sync()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loader.train_iteration(w, args, epoch_of(a.warmup + i))
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    images = a.batch * a.steps
+    value = images / dt
+    fl_step = sum(flops_per_image(a.res, epoch_of(a.warmup + i)) for i in range(a.steps)) / a.steps * a.batch
+    out = {
+        "metric": "images/sec (G+D step)", "value": value, "unit": "images/sec", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": f"LC-GAN G+D iteration ({a.epoch_type}: train_generator + ema + train_discriminator"
+                               f"{' with R1' if a.epoch_type == 'r1' else ''}), {a.res}x{a.res}, global batch {a.batch}",
+                   "global_batch": a.batch, "resolution": a.res, "parallelism": f"dp{world}",
+                   "algorithmic_tflop_per_step": fl_step / 1e12},
+        "step_mfma_frac": fl_step / (dt / a.steps) / (world * PEAK_BF16_DENSE),
+    }
+
+    if rank == 0 and not a.no_roofline:
+        # dominant kernel (implicit-GEMM conv): HIP events around every launch, on the launch stream, over one more iteration
+        K = kernels.K
+        K.prof_enable(True)
+        loader.train_iteration(w, args, epoch_of(a.warmup + a.steps))
+        torch.cuda.synchronize()
+        prof = K.prof_collect()
+        K.prof_enable(False)
+        ig, wg = prof["conv_igemm"], prof["conv_wgrad"]
+        ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel", "achieved": ach, "peak": PEAK_BF16_DENSE / 1e12,
+                           "unit": "TFLOP/s", "frac": ach / (PEAK_BF16_DENSE / 1e12), "traffic": None,
+                           "launches": ig["count"], "avg_launch_ms": ig["ms"] / max(ig["count"], 1),
+                           "flops_per_launch": ig["flops"] / max(ig["count"], 1)}
+        out["kernel_ms"] = {k: round(v["ms"], 3) for k, v in prof.items()}
+        out["wgrad_tflops"] = wg["flops"] / (wg["ms"] * 1e-3) / 1e12 if wg["ms"] > 0 else 0.0
+    elif world > 1 and not a.no_roofline:
+        loader.train_iteration(w, args, epoch_of(a.warmup + a.steps))       # keep the ranks in lock-step
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.res, 2)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

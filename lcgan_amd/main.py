@@ -1,0 +1,84 @@
+"""CLI entrypoint -- same flags as the reference's main.py:16-60, one spawned process per GPU (main.py:111-113)."""
+from __future__ import annotations
+
+import argparse
+import os
+import random
+
+import torch
+
+from . import loader
+
+# (flag, type, default, help) -- the reference's 34 flags, main.py:16-60
+_FLAGS = [
+    ("phase", str, "train", "train (other phases live in the reference's tooling)"),
+    ("tau", float, 0.05, "temperature of the contrastive loss"),
+    ("l_adv", float, 1.0, "adversarial weight (parsed but unused, as in the reference)"),
+    ("l_aux", float, 0.5, "weight of the auxiliary (contrastive) loss"),
+    ("l_r1", float, 10.0, "weight of the R1 penalty"),
+    ("l_s", float, 1e-7, "weight of the L1 sparsity on the mapping diagonals"),
+    ("max_flow_scale", float, 0.1, "maximum flow scale"),
+    ("geo_noise_dim", int, 64, ""), ("app_noise_dim", int, 64, ""),
+    ("geo_projection_dim", int, 256, ""), ("app_projection_dim", int, 256, ""),
+    ("geo_latent_dim", int, 64, ""), ("app_latent_dim", int, 512, ""),
+    ("epoch", int, 100000, "number of iterations"),
+    ("batch_size", int, 32, "GLOBAL batch size (split over the GPUs of the node)"),
+    ("g_lr", float, 0.002, ""), ("d_lr", float, 0.002, ""),
+    ("beta1", float, 0.0, ""), ("beta2", float, 0.99, ""),
+    ("g_ema_decay", float, 0.9999, ""), ("g_ema_start", int, 0, ""),
+    ("freezeD_start", int, 100000, ""), ("freezeD_layer", int, 5, ""),
+    ("img_resolution", int, 256, ""), ("img_ch", int, 3, ""),
+    ("psi", float, 2.0, ""), ("w_psi", float, 1.0, ""),
+    ("dataset_path", str, "synthetic", "'synthetic' or an image folder"),
+    ("model_name", str, "", "output directory"),
+    ("save_dir", str, "model", ""), ("sample_dir", str, "samples", ""),
+    ("num_fakes", int, 10, ""), ("ctrl_dim", int, -1, ""), ("num_videos", int, 10, ""),
+    ("save_interval", int, 5000, ""), ("print_interval", int, 100, ""), ("show_interval", int, 1000, ""),
+]
+
+
+def parse_args(argv=None):
+    parser = argparse.ArgumentParser(description="LC-GAN training on MI355X (HIP kernels)")
+    for name, typ, default, help_ in _FLAGS:
+        parser.add_argument("--" + name, type=typ, default=default, help=help_)
+    parser.add_argument("--best", default=False, action="store_true", help="load the *_best checkpoints")
+    parser.add_argument("--feature_dtype", choices=["bf16", "f32"], default="bf16", help="feature-map dtype of the HIP path")
+    return check_args(parser.parse_args(argv))
+
+
+def check_args(args):
+    if not args.model_name:
+        print("model name must be given")
+        args.model_name = "lcgan_run"
+    for d in (args.model_name, os.path.join(args.model_name, args.save_dir), os.path.join(args.model_name, args.sample_dir)):
+        os.makedirs(d, exist_ok=True)
+    if args.epoch < 1:
+        print("number of epochs must be larger than or equal to one")
+    if args.batch_size < 1:
+        print("batch size must be larger than or equal to one")
+    return args
+
+
+def _run(local_rank, args, gpus, port):
+    from . import config
+    config.set_feature_dtype(torch.bfloat16 if args.feature_dtype == "bf16" else torch.float32)
+    loader.load_worker(local_rank, args, gpus, port)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    print(args)
+    gpus_per_node = torch.cuda.device_count()
+    if gpus_per_node == 0:
+        raise SystemExit("no HIP device visible: lcgan_amd has no CPU fallback (the CPU restatement lives in oracle/ for tests only)")
+    port_number = random.randint(22000, 23000)
+    print("Processing with {} GPUs".format(gpus_per_node))
+    if gpus_per_node == 1:
+        _run(0, args, 1, port_number)
+    else:
+        torch.multiprocessing.set_start_method("spawn", force=True)
+        torch.multiprocessing.spawn(fn=_run, args=(args, gpus_per_node, port_number), nprocs=gpus_per_node)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,173 @@
+"""Per-rank trainer -- counterpart of the reference's worker.py:30-253 (training part) on the HIP kernels.
+
+Kept: class name, constructor signature, `train_generator` / `train_discriminator` / `ema_update` / `freeze_discriminator` /
+`requires_grad` / `save_model` / `load_model`, attribute names (`generator`, `discriminator`, `generator_ema`, `g_optimizer`,
+`d_optimizer`, `local_batch_size`), the order of random draws, loss assembly and the `module.`-prefixed checkpoints.
+Out of scope: the PIL/albumentations data pipeline, FID and video tooling -- `--dataset_path synthetic`
+feeds uniform [-1,1] tensors of the dataset's shape/range (custom_dataset.py:81-86); a real folder needs torchvision.
+"""
+from __future__ import annotations
+
+import copy
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import cnn, loss
+from .ema import Ema
+from .optim import Adam, DataParallel
+
+
+class SyntheticTriples:
+    """Endless (image, geometry_change, appearance_change) batches, uniform in [-1, 1], fp32, resident on the device."""
+
+    def __init__(self, batch, res, device, seed=1234, pool=4):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        self.items = [tuple((torch.rand(batch, 3, res, res, generator=g) * 2 - 1).to(device) for _ in range(3)) for _ in range(pool)]
+        self.i = 0
+
+    def next(self):
+        item = self.items[self.i % len(self.items)]
+        self.i += 1
+        return item
+
+
+class WORKER(object):
+    def __init__(self, args, local_rank, gpus_per_node, device=None):
+        self.args = args
+        self.local_rank = local_rank
+        self.gpus_per_node = gpus_per_node
+        self.local_batch_size = args.batch_size // gpus_per_node                      # worker.py:35
+        self.global_iter_counter = 0
+        self.device = torch.device(device) if device is not None else torch.device("cuda", local_rank)
+        if self.device.type == "cuda" and not torch.cuda.is_available():
+            raise RuntimeError("lcgan_amd needs a HIP device: there is no CPU fallback for the training step")
+        self.group = dist.new_group(list(range(gpus_per_node))) if (dist.is_available() and dist.is_initialized()) else None
+        self.data = self.prepare_training_dataset()
+        self.generator, self.discriminator, self.g_optimizer, self.d_optimizer = self.set_cnn_models()
+        self.generator_ema = copy.deepcopy(self.generator)                            # worker.py:40 (keeps the `module.` prefix)
+        self.ema = Ema(self.generator, self.generator_ema, self.args.g_ema_decay, self.args.g_ema_start)
+        self.best_fid = 9999
+
+    # ---- data -----------------------------------------------------------------------------------------------------
+    def prepare_training_dataset(self):
+        path = str(getattr(self.args, "dataset_path", "synthetic"))
+        if path.startswith("synthetic"):
+            return SyntheticTriples(self.local_batch_size, self.args.img_resolution, self.device, seed=1234 + self.local_rank)
+        raise NotImplementedError("the image-folder pipeline (custom_dataset.py) is outside the accelerated hot path; "
+                                  "run with --dataset_path synthetic")
+
+    def sample_data_basket(self):
+        return self.data.next()
+
+    # ---- models / optimisers (worker.py:75-112) ---------------------------------------------------------------------
+    def set_cnn_models(self):
+        generator = cnn.Generator(self.args).to(self.device)
+        discriminator = cnn.Discriminator(self.args).to(self.device)
+        g_parameters = [p for _, p in generator.named_parameters()]
+        d_parameters = [p for _, p in discriminator.named_parameters()]
+        generator = DataParallel(generator, self.group)
+        discriminator = DataParallel(discriminator, self.group)
+        betas = (self.args.beta1, self.args.beta2)
+        g_optimizer = Adam(g_parameters, lr=self.args.g_lr, betas=betas, eps=1e-8)
+        d_optimizer = Adam(d_parameters, lr=self.args.d_lr, betas=betas, eps=1e-8)
+        return generator, discriminator, g_optimizer, d_optimizer
+
+    def freeze_discriminator(self, freeze_up_to_index=5):
+        """worker.py:127-131: freezes conv1x1, LeakyReLU and the first `freeze_up_to_index` blocks of D.shared_model."""
+        for i, (_, layer) in enumerate(self.discriminator.module.shared_model.named_children()):
+            if i < freeze_up_to_index + 2:
+                for param in layer.parameters():
+                    param.requires_grad = False
+
+    def requires_grad(self, model, flag=True):
+        for p in model.parameters():
+            p.requires_grad = flag
+
+    def _randn(self, dim):
+        return torch.randn(self.local_batch_size, dim, device=self.device)
+
+    # ---- D step (worker.py:137-177) -----------------------------------------------------------------------------------
+    def train_discriminator(self, epoch):
+        self.d_optimizer.zero_grad()
+        image, geometry_change, appearance_change = self.sample_data_basket()
+        rand1 = self._randn(self.args.geo_noise_dim)
+        rand2 = self._randn(self.args.app_noise_dim)
+        with torch.no_grad():                      # G is frozen in this phase (loader.py:50); same numbers, no graph
+            fake_img = self.generator(rand1, rand2)
+        fake_logit, _, _ = self.discriminator(fake_img, False)
+
+        if epoch % 2 == 1:
+            image = image.detach().clone().requires_grad_(True)                       # worker.py:152
+            real_logit, _, _ = self.discriminator(image, False)
+            d_loss = loss.bce_with_logits(real_logit, True) + loss.bce_with_logits(fake_logit, False)
+            if epoch % 8 == 1:
+                d_loss = d_loss + loss.cal_r1_reg(real_logit, image, self.device) * self.args.l_r1
+        else:
+            real_logit, geometry_feat, appearance_feat = self.discriminator(image, True)
+            _, geometry_positive, appearance_negative = self.discriminator(geometry_change, True)
+            _, geometry_negative, appearance_positive = self.discriminator(appearance_change, True)
+            d_adv_loss = loss.bce_with_logits(real_logit, True) + loss.bce_with_logits(fake_logit, False)
+            d_aug_loss = (loss.contrastive_loss(geometry_feat, geometry_positive, geometry_negative, self.args.tau)
+                          + loss.contrastive_loss(appearance_feat, appearance_positive, appearance_negative, self.args.tau)) * self.args.l_aux
+            d_loss = d_adv_loss + d_aug_loss
+
+        d_loss.backward()
+        self.discriminator.sync_gradients()
+        self.d_optimizer.step()
+        return d_loss.item()
+
+    # ---- G step (worker.py:179-214) -----------------------------------------------------------------------------------
+    def train_generator(self, epoch):
+        self.g_optimizer.zero_grad()
+        rand1 = self._randn(self.args.geo_noise_dim)
+        rand2 = self._randn(self.args.app_noise_dim)
+        resample1 = self._randn(self.args.geo_noise_dim)
+        resample2 = self._randn(self.args.app_noise_dim)
+
+        if epoch % 2 == 1:
+            logit, _, _ = self.discriminator(self.generator(rand1, rand2), False)
+            g_loss = loss.bce_with_logits(logit, True)
+        else:
+            anchor_image = self.generator(rand1, rand2)
+            resample_geometry = self.generator(resample1, rand2)
+            resample_appearance = self.generator(rand1, resample2)
+            logit, geometry_feat, appearance_feat = self.discriminator(anchor_image, True)
+            _, geometry_positive, appearance_negative = self.discriminator(resample_geometry, True)
+            _, geometry_negative, appearance_positive = self.discriminator(resample_appearance, True)
+            g_adv_loss = loss.bce_with_logits(logit, True)
+            g_aug_loss = (loss.contrastive_loss(geometry_feat, geometry_positive, geometry_negative, self.args.tau)
+                          + loss.contrastive_loss(appearance_feat, appearance_positive, appearance_negative, self.args.tau)) * self.args.l_aux
+            g_sparsity_loss = loss.l1_sparsity([self.generator.module.geometry_mapping.diagonal_params,
+                                                self.generator.module.appearance_mapping.diagonal_params], self.args.l_s)
+            g_loss = g_adv_loss + g_aug_loss + g_sparsity_loss
+
+        g_loss.backward()
+        self.generator.sync_gradients()
+        self.g_optimizer.step()
+        return g_loss.item()
+
+    def ema_update(self, current_step):
+        self.ema.update(current_step)
+
+    # ---- checkpoints (worker.py:219-253): `module.`-prefixed state_dicts, same file names ------------------------------
+    def _paths(self, best=False):
+        d = os.path.join(self.args.model_name, self.args.save_dir)
+        sfx = "_best" if best else ""
+        return (f"{d}/gen_model{sfx}.ckpt", f"{d}/gen_ema_model{sfx}.ckpt", f"{d}/disc_model{sfx}.ckpt")
+
+    def save_model(self, best=False):
+        g, e, d = self._paths(best)
+        torch.save(self.generator.state_dict(), g)
+        torch.save(self.generator_ema.state_dict(), e)
+        torch.save(self.discriminator.state_dict(), d)
+
+    def save_best_model(self):
+        self.save_model(best=True)
+
+    def load_model(self):
+        g, e, d = self._paths(bool(getattr(self.args, "best", False)))
+        self.generator.load_state_dict(torch.load(g, map_location=self.device))
+        self.generator_ema.load_state_dict(torch.load(e, map_location=self.device))
+        self.discriminator.load_state_dict(torch.load(d, map_location=self.device))

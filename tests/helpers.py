@@ -1,0 +1,83 @@
+"""Shared test helpers: argument namespaces, seeded worker construction, golden-vector comparison."""
+import os
+import types
+
+import numpy as np
+import torch
+
+from oracle import lcgan_ref as O
+from oracle.weights import seeded_state, seeded_tensor
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def make_args(res=32, batch=8, **kw):
+    a = types.SimpleNamespace(
+        phase="train", img_resolution=res, batch_size=batch, geo_latent_dim=64, app_latent_dim=512, geo_noise_dim=64,
+        app_noise_dim=64, max_flow_scale=0.1, geo_projection_dim=256, app_projection_dim=256, tau=0.05, l_adv=1.0, l_aux=0.5,
+        l_r1=10.0, l_s=1e-7, g_lr=0.002, d_lr=0.002, beta1=0.0, beta2=0.99, g_ema_decay=0.9999, g_ema_start=0,
+        freezeD_start=100000, freezeD_layer=5, dataset_path="synthetic", model_name="", save_dir="model", sample_dir="samples",
+        best=False, epoch=1, print_interval=100, save_interval=5000, show_interval=1000)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+class FixedFeed:
+    """Replaces a WORKER's random draws and data with the seeded tensors the golden vectors were captured with."""
+
+    def __init__(self, w, B, res, device):
+        self.z = [seeded_tensor((B, 64), 2000 + i).to(device) for i in range(4)]
+        self.real = tuple(seeded_tensor((B, 3, res, res), 2100 + i, "uniform_pm1").to(device) for i in range(3))
+        self.i = 0
+        w._randn = self._randn
+        w.sample_data_basket = lambda: self.real
+
+    def reset(self):
+        self.i = 0
+
+    def _randn(self, dim):
+        t = self.z[self.i % 4]
+        self.i += 1
+        return t
+
+
+def seeded_worker(res, B, device, gpus=1, **kw):
+    from lcgan_amd import worker
+    w = worker.WORKER(make_args(res, B * gpus, **kw), 0, gpus, device=device)
+    load_seeded(w, res, device)
+    return w
+
+
+def load_seeded(w, res, device):
+    GP, DP = seeded_state(O.g_param_shapes(res), 1001), seeded_state(O.d_param_shapes(res), 1002)
+    w.generator.module.load_state_dict({k: v.to(device) for k, v in GP.items()})
+    w.discriminator.module.load_state_dict({k: v.to(device) for k, v in DP.items()})
+    return GP, DP
+
+
+def sample(t, n=257):
+    f = t.detach().float().cpu().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n]
+
+
+def check_grads_vs_golden(S, tag, named_params, tol):
+    """named_params: iterable of (name-without-module-prefix, parameter with .grad).  Returns the worst relative error."""
+    worst = 0.0
+    for k, p in named_params:
+        key = f"{tag}/grad/{k}/abssum"
+        if p.grad is None:
+            assert key not in S, f"{tag}: {k} has no grad but the reference produced one"
+            continue
+        assert key in S, f"{tag}: {k} has a grad but the reference left it None"
+        g = p.grad
+        ref_abssum = float(S[key])
+        got_abssum = float(g.double().abs().sum())
+        e1 = abs(got_abssum - ref_abssum) / max(ref_abssum, 1e-30)
+        ref_s = S[f"{tag}/grad/{k}/sample"]
+        scale = max(float(np.abs(ref_s).max()), ref_abssum / g.numel(), 1e-30)
+        e2 = float(np.abs(sample(g).numpy() - ref_s).max()) / scale
+        worst = max(worst, e1, e2)
+        assert e1 <= tol and e2 <= tol, f"{tag} {k}: abssum err {e1:.2e}, sample err {e2:.2e} (tol {tol})"
+    return worst

@@ -1,0 +1,307 @@
+"""Per-kernel parity on the MI355X: every C-ABI kernel (called through lcgan_amd.kernels.HipKernels -> liblcgan_hip.so)
+against the CPU emulation of the same kernel on identical seeded inputs, in both feature dtypes.
+
+Tolerances (relative to the max |reference| of the tensor):
+  * f32 features ("parity mode", bf16x3 split MFMA):  2e-4  (well inside BASELINE.json's 1e-3)
+  * bf16 features: the emulation rounds operands at the same points, so only accumulation order and the final bf16
+    rounding differ: 1.2e-2 max-abs-relative (1.5 bf16 ulp of the largest element), 2e-3 relative L2.
+"""
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.hip_emulation import EmulatedKernels, ceil8   # noqa: E402
+
+E = EmulatedKernels()
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def H():
+    from lcgan_amd.kernels import HipKernels
+    return HipKernels()
+
+
+def dev(t):
+    return None if t is None else t.cuda()
+
+
+def tol(dtype):
+    return (2e-4, 1e-4) if dtype == torch.float32 else (1.2e-2, 2e-3)
+
+
+def check(got, ref, dtype, what=""):
+    got, ref = got.detach().float().cpu(), ref.detach().float()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    mx, l2 = tol(dtype)
+    scale = ref.abs().max().clamp_min(1e-20)
+    e_max = float((got - ref).abs().max() / scale)
+    e_l2 = float((got - ref).norm() / ref.norm().clamp_min(1e-20))
+    assert math.isfinite(e_max) and e_max <= mx and e_l2 <= l2, f"{what}: max-rel {e_max:.3e} (tol {mx}), l2-rel {e_l2:.3e} (tol {l2})"
+
+
+def feat(shape, dtype, seed, clog=None, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(shape, generator=g) * scale
+    if clog is not None:
+        x[..., clog:] = 0
+    return x.to(dtype)
+
+
+def vec(shape, seed, lo=0.5, hi=1.5):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(shape, generator=g) * (hi - lo) + lo
+
+
+# ------------------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # B, H, W, Cin(log), Cout(log), k, stride
+    (2, 8, 8, 32, 32, 3, 1),
+    (3, 16, 16, 64, 128, 3, 1),
+    (2, 12, 20, 40, 24, 3, 1),       # ragged: M, N, K all off-tile
+    (2, 16, 16, 64, 96, 3, 2),
+    (2, 8, 8, 128, 256, 1, 1),
+    (4, 4, 4, 513, 512, 3, 1),       # discriminator epilogue conv (513 -> padded 520 / 544)
+    (1, 64, 64, 128, 128, 3, 1),     # several M tiles per sample
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd(H, dtype, case):
+    B, Hh, W, Ci, Co, k, stride = case
+    x = feat((B, Hh, W, ceil8(Ci)), dtype, 1, Ci)
+    w = torch.randn(Co, Ci, k, k, generator=torch.Generator().manual_seed(2))
+    bias = torch.randn(Co, generator=torch.Generator().manual_seed(3))
+    scale = 1 / math.sqrt(Ci * k * k)
+    need_lo = dtype == torch.float32
+    pw_e, _ = E.prep_weight(w, scale, False, need_lo)
+    pw_h, _ = H.prep_weight(w.cuda(), scale, False, need_lo)
+    # plain
+    check(H.conv_fwd(x.cuda(), pw_h, Co, k, stride), E.conv_fwd(x, pw_e, Co, k, stride), dtype, "plain")
+    # bias + lrelu*gain
+    check(H.conv_fwd(x.cuda(), pw_h, Co, k, stride, bias=bias.cuda(), bias_scale=0.5, act=1, gain=1.4),
+          E.conv_fwd(x, pw_e, Co, k, stride, bias=bias, bias_scale=0.5, act=1, gain=1.4), dtype, "bias+lrelu")
+    # modulated: pre/post scales + residual
+    pre, post = vec((B, ceil8(Ci)), 4), vec((B, ceil8(Co)), 5)
+    ref0 = E.conv_fwd(x, pw_e, Co, k, stride)
+    res = feat(tuple(ref0.shape), dtype, 6, Co)
+    check(H.conv_fwd(x.cuda(), pw_h, Co, k, stride, pre=pre.cuda(), post=post.cuda(), bias=bias.cuda(), residual=res.cuda()),
+          E.conv_fwd(x, pw_e, Co, k, stride, pre=pre, post=post, bias=bias, residual=res), dtype, "mod+residual")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES + [(2, 8, 8, 64, 2, 3, 2), (2, 16, 16, 2, 64, 3, 1)])
+def test_conv_bwd_data(H, dtype, case):
+    B, Hh, W, Ci, Co, k, stride = case          # g has Co channels on the (Hh/stride) grid; output has Ci channels
+    if stride == 2 and k != 3:
+        pytest.skip("no strided 1x1")
+    Hg, Wg = Hh // stride, W // stride
+    g = feat((B, Hg, Wg, ceil8(Co)), dtype, 11, Co)
+    w = torch.randn(Co, Ci, k, k, generator=torch.Generator().manual_seed(12))
+    scale = 1 / math.sqrt(Ci * k * k)
+    need_lo = dtype == torch.float32
+    pw_e, _ = E.prep_weight(w, scale, True, need_lo)
+    pw_h, _ = H.prep_weight(w.cuda(), scale, True, need_lo)
+    check(H.conv_bwd_data(g.cuda(), pw_h, Ci, k, stride), E.conv_bwd_data(g, pw_e, Ci, k, stride), dtype, "plain")
+    pre, post = vec((B, ceil8(Co)), 13), vec((B, ceil8(Ci)), 14)
+    bias = torch.randn(Ci, generator=torch.Generator().manual_seed(15))
+    check(H.conv_bwd_data(g.cuda(), pw_h, Ci, k, stride, pre=pre.cuda(), post=post.cuda(), bias=bias.cuda(), act=1, gain=1.2),
+          E.conv_bwd_data(g, pw_e, Ci, k, stride, pre=pre, post=post, bias=bias, act=1, gain=1.2), dtype, "mod+bias+act")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES + [(2, 16, 16, 64, 2, 3, 2)])
+def test_conv_wgrad(H, dtype, case):
+    B, Hh, W, Ci, Co, k, stride = case
+    x = feat((B, Hh, W, ceil8(Ci)), dtype, 21, Ci)
+    g = feat((B, Hh // stride, W // stride, ceil8(Co)), dtype, 22, Co)
+    ref = E.conv_wgrad(x, g, Co, Ci, k, stride)
+    check(H.conv_wgrad(x.cuda(), g.cuda(), Co, Ci, k, stride), ref, dtype, "plain")
+    px, pg = vec((B, ceil8(Ci)), 23), vec((B, ceil8(Co)), 24)
+    check(H.conv_wgrad(x.cuda(), g.cuda(), Co, Ci, k, stride, pre_x=px.cuda(), pre_g=pg.cuda()),
+          E.conv_wgrad(x, g, Co, Ci, k, stride, pre_x=px, pre_g=pg), dtype, "prescaled")
+    # un-prep, both orientations, with the demod term
+    w = torch.randn(Co, Ci, k, k, generator=torch.Generator().manual_seed(25))
+    gwsq = torch.randn(Co, Ci, generator=torch.Generator().manual_seed(26))
+    check(H.unprep_wgrad(ref.cuda(), Co, Ci, k, 0.3, False, w.cuda(), gwsq.cuda()), E.unprep_wgrad(ref, Co, Ci, k, 0.3, False, w, gwsq),
+          torch.float32, "unprep")
+    refT = ref.permute(0, 2, 1).contiguous()
+    check(H.unprep_wgrad(refT.cuda(), Co, Ci, k, 0.3, True, w.cuda(), gwsq.cuda()), E.unprep_wgrad(refT, Co, Ci, k, 0.3, True, w, gwsq),
+          torch.float32, "unprep-T")
+
+
+def test_mfma_layout_asymmetric(H):
+    """A = identity-like input against an asymmetric weight: catches a transposed C/D or operand map (guide: sec. 3)."""
+    C = 32
+    x = torch.zeros(1, 8, 8, C)
+    for c in range(C):
+        x[0, c % 8, c // 8, c] = 1.0 + c            # one-hot pixels/channels
+    w = (torch.arange(C * C, dtype=torch.float32).reshape(C, C, 1, 1) % 17) - 8.0
+    pw_e, _ = E.prep_weight(w, 1.0, False, True)
+    pw_h, _ = H.prep_weight(w.cuda(), 1.0, False, True)
+    got, ref = H.conv_fwd(x.cuda(), pw_h, C, 1, 1).cpu(), E.conv_fwd(x, pw_e, C, 1, 1)
+    assert torch.allclose(got, ref, atol=1e-3), float((got - ref).abs().max())
+    gw = H.conv_wgrad(x.cuda(), ref.cuda(), C, C, 1, 1).cpu()
+    assert torch.allclose(gw, E.conv_wgrad(x, ref, C, C, 1, 1), rtol=1e-3, atol=1e-2)
+
+
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 8, 8, 16), (3, 12, 20, 40), (1, 32, 32, 128)])
+def test_stencils(H, dtype, shape):
+    x = feat(shape, dtype, 31)
+    for act, gain in ((0, 1.0), (1, 1.4), (2, 1.0)):
+        y_ref = E.box3_act(x, act, gain)
+        check(H.box3_act(x.cuda(), act, gain), y_ref, dtype, f"box3 act{act}")
+        gy = feat(shape, dtype, 32)
+        check(H.box3_act_bwd(gy.cuda(), y_ref.cuda(), act, gain), E.box3_act_bwd(gy, y_ref, act, gain), dtype, f"box3 bwd act{act}")
+    B, Hh, W, C = shape
+    res = feat((B, 2 * Hh, 2 * W, C), dtype, 33)
+    check(H.up2box(x.cuda(), res.cuda()), E.up2box(x, res), dtype, "up2box+res")
+    check(H.up2box(x.cuda(), None), E.up2box(x, None), dtype, "up2box")
+    check(H.up2box_bwd(res.cuda()), E.up2box_bwd(res), dtype, "up2box bwd")
+    check(H.avgpool2(x.cuda()), E.avgpool2(x), dtype, "avgpool2")
+    check(H.avgpool2_bwd(x.cuda()), E.avgpool2_bwd(x), dtype, "avgpool2 bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape,clog", [((2, 8, 8, 16), 16), ((3, 10, 6, 8), 2), ((2, 16, 16, 520), 513), ((2, 64, 64, 128), 128)])
+def test_act_bwd_reduce_and_scale_reduce(H, dtype, shape, clog):
+    B, Hh, W, C = shape
+    gy, y = feat(shape, dtype, 41, clog), feat(shape, dtype, 42, clog)
+    bias = torch.randn(clog, generator=torch.Generator().manual_seed(43))
+    for act, gain in ((1, 1.4), (0, 1.0)):
+        r = E.act_bwd_reduce(gy, y, act, gain, clog, True, bias, 0.7, True, True)
+        g = H.act_bwd_reduce(gy.cuda(), y.cuda(), act, gain, clog, True, bias.cuda(), 0.7, True, True)
+        check(g[0], r[0], dtype, "gz")
+        check(g[1], r[1], torch.float32, "gbias")
+        check(g[2], r[2], torch.float32, "gdq")
+    u, x = feat(shape, dtype, 44), feat(shape, dtype, 45)
+    s = vec((B, C), 46)
+    u_ref, gs_ref = E.scale_reduce(u.clone(), x, s)
+    u_got, gs_got = H.scale_reduce(u.cuda(), x.cuda(), s.cuda())
+    check(u_got, u_ref, dtype, "scaled u")
+    check(gs_got, gs_ref, torch.float32, "gs")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 8, 8, 32), (2, 16, 16, 128), (1, 32, 32, 512)])
+def test_warp(H, dtype, shape):
+    B, Hh, W, C = shape
+    x = feat(shape, dtype, 51)
+    flow = torch.zeros(B, Hh, W, 8)
+    flow[..., :2] = torch.tanh(torch.randn(B, Hh, W, 2, generator=torch.Generator().manual_seed(52)))
+    flow = flow.to(dtype)
+    check(H.warp_fwd(x.cuda(), flow.cuda(), 0.1), E.warp_fwd(x, flow, 0.1), dtype, "warp fwd")
+    gy = feat(shape, dtype, 53)
+    gx_r, gf_r = E.warp_bwd(gy, x, flow, 0.1)
+    gx_g, gf_g = H.warp_bwd(gy.cuda(), x.cuda(), flow.cuda(), 0.1)
+    check(gx_g, gx_r, dtype, "warp gx")
+    check(gf_g, gf_r, dtype, "warp gflow")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,G", [(4, 4), (8, 8), (16, 8), (32, 8)])
+def test_mbstd(H, dtype, N, G):
+    C = 64
+    x = feat((N, 4, 4, C), dtype, 61)
+    Cy = ceil8(C + 1)
+    check(H.mbstd_fwd(x.cuda(), G, Cy), E.mbstd_fwd(x, G, Cy), dtype, "fwd")
+    gy = feat((N, 4, 4, Cy), dtype, 62, C + 1)
+    check(H.mbstd_bwd(gy.cuda(), x.cuda(), G), E.mbstd_bwd(gy, x, G), dtype, "bwd")
+    v = feat((N, 4, 4, C), dtype, 63)
+    r = E.mbstd_bwd2(v, gy, x, G)
+    g = H.mbstd_bwd2(v.cuda(), gy.cuda(), x.cuda(), G)
+    check(g[0], r[0], dtype, "bwd2 ggy")
+    check(g[1], r[1], dtype, "bwd2 gx")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("per_sample", [False, True])
+def test_rgb(H, dtype, per_sample):
+    B, Hh, W, C = 3, 16, 16, 128
+    img = torch.randn(B, 3, Hh, W, generator=torch.Generator().manual_seed(71))
+    w = torch.randn(B if per_sample else 1, 3, C, generator=torch.Generator().manual_seed(72)) * 0.3
+    bias = torch.randn(C, generator=torch.Generator().manual_seed(73))
+    check(H.rgb_expand(img.cuda(), w.cuda(), bias.cuda(), 0.5, C, 1, 1.2, dtype), E.rgb_expand(img, w, bias, 0.5, C, 1, 1.2, dtype), dtype, "expand")
+    x = feat((B, Hh, W, C), dtype, 74)
+    b3 = torch.randn(3, generator=torch.Generator().manual_seed(75))
+    check(H.rgb_reduce(x.cuda(), w.cuda(), b3.cuda(), 1.0), E.rgb_reduce(x, w, b3, 1.0), torch.float32 if dtype == torch.float32 else dtype, "reduce")
+    check(H.rgb_wgrad(img.cuda(), x.cuda(), per_sample), E.rgb_wgrad(img, x, per_sample), torch.float32 if dtype == torch.float32 else dtype, "wgrad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layout(H, dtype):
+    src = torch.randn(3, 13, 4, 4, generator=torch.Generator().manual_seed(81))
+    check(H.nchw_to_nhwc(src.cuda(), 3, 16, dtype), E.nchw_to_nhwc(src, 3, 16, dtype), dtype, "to nhwc")
+    check(H.nchw_to_nhwc(src[:1].contiguous().cuda(), 5, 16, dtype), E.nchw_to_nhwc(src[:1], 5, 16, dtype), dtype, "broadcast")
+    f = feat((3, 4, 4, 16), dtype, 82, 13)
+    check(H.nhwc_to_nchw(f.cuda(), 13, False), E.nhwc_to_nchw(f, 13, False), torch.float32, "to nchw")
+    check(H.nhwc_to_nchw(f.cuda(), 13, True), E.nhwc_to_nchw(f, 13, True), torch.float32, "reduce")
+
+
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,I,O", [(8, 64, 64), (32, 8192, 512), (5, 6, 8), (96, 512, 1), (32, 512, 2048)])
+def test_linear(H, M, I, O):
+    g = torch.Generator().manual_seed(91)
+    x, w, b = torch.randn(M, I, generator=g), torch.randn(O, I, generator=g), torch.randn(O, generator=g)
+    sc = 1 / math.sqrt(I)
+    f32 = torch.float32
+    check(H.linear_fwd(x.cuda(), w.cuda(), b.cuda(), sc, 0.01, 1, 1.0), E.linear_fwd(x, w, b, sc, 0.01, 1, 1.0), f32, "fwd")
+    gy = torch.randn(M, O, generator=g)
+    check(H.linear_bwd_data(gy.cuda(), w.cuda(), sc), E.linear_bwd_data(gy, w, sc), f32, "bwd data")
+    check(H.linear_wgrad(gy.cuda(), x.cuda(), sc), E.linear_wgrad(gy, x, sc), f32, "wgrad")
+    check(H.colsum(gy.cuda(), 0.01), E.colsum(gy, 0.01), f32, "colsum")
+    check(H.act_bwd_f32(gy.cuda(), x[:, :1].expand(M, O).contiguous().cuda(), 1, 1.0), E.act_bwd_f32(gy, x[:, :1].expand(M, O), 1, 1.0), f32, "act bwd")
+
+
+def test_demod(H):
+    g = torch.Generator().manual_seed(101)
+    B, C, O = 4, 64, 24
+    s, wsq = torch.randn(B, C, generator=g) + 1, torch.rand(O, C, generator=g) * 0.1
+    d_ref = E.demod_fwd(s, wsq, ceil8(O))
+    check(H.demod_fwd(s.cuda(), wsq.cuda(), ceil8(O)), d_ref, torch.float32, "demod")
+    gdq = torch.zeros(B, ceil8(O))
+    gdq[:, :O] = torch.randn(B, O, generator=g)
+    gs0 = torch.randn(B, C, generator=g)
+    gs_ref = gs0.clone()
+    gwsq_ref = E.demod_bwd(gdq, d_ref, s, wsq, gs_ref)
+    gs_got = gs0.clone().cuda()
+    gwsq_got = H.demod_bwd(gdq.cuda(), d_ref.cuda(), s.cuda(), wsq.cuda(), gs_got)
+    check(gs_got, gs_ref, torch.float32, "gs")
+    check(gwsq_got, gwsq_ref, torch.float32, "gwsq")
+
+
+def test_losses(H):
+    g = torch.Generator().manual_seed(111)
+    f32 = torch.float32
+    logit = torch.randn(32, 1, generator=g) * 3
+    gout = torch.tensor(0.7)
+    for t1 in (True, False):
+        check(H.bce_fwd(logit.cuda(), t1), E.bce_fwd(logit, t1), f32, "bce")
+        check(H.bce_bwd(logit.cuda(), t1, gout.cuda()), E.bce_bwd(logit, t1, gout), f32, "bce bwd")
+    a, p, n = (torch.nn.functional.normalize(torch.randn(32, 256, generator=g)) for _ in range(3))
+    lr, tr = E.contrastive_fwd(a, p, n, 0.05)
+    lg, tg = H.contrastive_fwd(a.cuda(), p.cuda(), n.cuda(), 0.05)
+    check(lg, lr, f32, "contrastive"), check(tg, tr, f32, "t")
+    for x, y in zip(H.contrastive_bwd(a.cuda(), p.cuda(), n.cuda(), tg, gout.cuda(), 0.05), E.contrastive_bwd(a, p, n, tr, gout, 0.05)):
+        check(x, y, f32, "contrastive bwd")
+    x = torch.randn(32, 256, generator=g)
+    yr, nr = E.l2norm_fwd(x)
+    yg, ng = H.l2norm_fwd(x.cuda())
+    check(yg, yr, f32, "l2norm"), check(ng, nr, f32, "norm")
+    gy = torch.randn(32, 256, generator=g)
+    check(H.l2norm_bwd(gy.cuda(), yg, ng), E.l2norm_bwd(gy, yr, nr), f32, "l2norm bwd")
+    big = torch.randn(3 * 256 * 256 + 5, generator=g)
+    for pw in (1, 2):
+        check(H.powsum(big.cuda(), pw, 0.25), E.powsum(big, pw, 0.25), f32, "powsum")
+        check(H.powsum_bwd(big.cuda(), pw, 0.25, gout.cuda()), E.powsum_bwd(big, pw, 0.25, gout), f32, "powsum bwd")
+    w, avg = torch.randn(8, 512, generator=g), torch.randn(512, generator=g)
+    avg_ref, avg_got = avg.clone(), avg.clone().cuda()
+    E.avg_latent(w, avg_ref, 0.998), H.avg_latent(w.cuda(), avg_got, 0.998)
+    check(avg_got, avg_ref, f32, "avg latent")

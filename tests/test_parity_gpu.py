@@ -1,0 +1,191 @@
+"""End-to-end parity on the MI355X: the worker's G and D steps run on the HIP kernels (through the C ABI) and are compared
+with (a) the golden vectors captured from the reference (tests/golden/*.npz) and (b) the CPU oracle on the same inputs.
+
+Tolerances: parity mode (f32 features, bf16x3 MFMA) 1e-3 relative -- BASELINE.json's north_star tolerance -- with the
+3e-3 allowance for even-iteration gradients explained in test_wiring_cpu.py; bf16 features (the benchmark dtype) are
+compared with the oracle at 5e-2 on losses / relative-L2 0.15 on gradients (bf16 has 8 mantissa bits: 2^-9 per rounding,
+accumulated over ~40 layers and the backward pass)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import lcgan_ref as O                      # noqa: E402
+from oracle.weights import seeded_state, seeded_tensor  # noqa: E402
+from tests.helpers import GOLD, FixedFeed, check_grads_vs_golden, make_args, seeded_worker   # noqa: E402
+
+TOL, TOL_EVEN_GRADS = 1e-3, 3e-3
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def S():
+    return np.load(os.path.join(GOLD, "step_r32.npz"))
+
+
+def rel(a, b):
+    a = torch.as_tensor(np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a), dtype=torch.float64)
+    b = torch.as_tensor(np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b), dtype=torch.float64)
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture()
+def f32_mode():
+    from lcgan_amd import config, kernels
+    assert kernels.backend_name() == "hip"
+    with config.feature_dtype_as(torch.float32):
+        yield
+
+
+@pytest.mark.parametrize("epoch", [0, 1])
+def test_train_generator_vs_golden(S, f32_mode, epoch):
+    res, B = int(S["res"]), int(S["B"])
+    w = seeded_worker(res, B, DEV)
+    FixedFeed(w, B, res, DEV)
+    w.g_optimizer.step = lambda: None
+    w.requires_grad(w.generator, True), w.requires_grad(w.discriminator, False)
+    g_loss = w.train_generator(epoch)
+    assert rel(g_loss, S[f"g{epoch}/loss"]) <= TOL
+    check_grads_vs_golden(S, f"g{epoch}", w.generator.module.named_parameters(), TOL if epoch % 2 else TOL_EVEN_GRADS)
+    assert rel(w.generator.module.avg_latent1, S[f"g{epoch}/avg_latent1"]) <= TOL
+    assert rel(w.generator.module.avg_latent2, S[f"g{epoch}/avg_latent2"]) <= TOL
+
+
+@pytest.mark.parametrize("epoch,frozen", [(0, 0), (1, 0), (3, 0), (1, 2)])
+def test_train_discriminator_vs_golden(S, f32_mode, epoch, frozen):
+    res, B = int(S["res"]), int(S["B"])
+    tag = f"d{epoch}" + (f"_freeze{frozen}" if frozen else "")
+    w = seeded_worker(res, B, DEV)
+    FixedFeed(w, B, res, DEV)
+    w.d_optimizer.step = lambda: None
+    w.requires_grad(w.generator, False), w.requires_grad(w.discriminator, True)
+    if frozen:
+        w.freeze_discriminator(frozen)
+    d_loss = w.train_discriminator(epoch)
+    assert rel(d_loss, S[f"{tag}/loss"]) <= TOL
+    check_grads_vs_golden(S, tag, w.discriminator.module.named_parameters(), TOL if epoch % 2 else TOL_EVEN_GRADS)
+
+
+def test_forward_256_vs_golden(f32_mode):
+    """Whole networks at the benchmark resolution against the reference's outputs (forward_r256.npz)."""
+    from lcgan_amd import cnn
+    Fw = np.load(os.path.join(GOLD, "forward_r256.npz"))
+    res, B = int(Fw["res"]), int(Fw["B"])
+    args = make_args(res, B)
+    G, D = cnn.Generator(args).to(DEV), cnn.Discriminator(args).to(DEV)
+    G.load_state_dict({k: v.to(DEV) for k, v in seeded_state(O.g_param_shapes(res), 1001).items()})
+    D.load_state_dict({k: v.to(DEV) for k, v in seeded_state(O.d_param_shapes(res), 1002).items()})
+    z1, z2 = seeded_tensor((B, 64), 3000).to(DEV), seeded_tensor((B, 64), 3001).to(DEV)
+    with torch.no_grad():
+        img = G(z1, z2)
+        assert rel(img[:, :, ::16, ::16], Fw["img/slice"]) <= TOL
+        assert abs(float(img.double().abs().sum()) - float(Fw["img/abssum"])) <= TOL * float(Fw["img/abssum"])
+        assert rel(G.avg_latent1, Fw["avg_latent1"]) <= TOL and rel(G.avg_latent2, Fw["avg_latent2"]) <= TOL
+        assert rel(G(z1, z2, 0.7)[:, :, ::16, ::16], Fw["img_trunc/slice"]) <= TOL
+        real = seeded_tensor((B, 3, res, res), 3002, "uniform_pm1").to(DEV)
+        logit, ge, ae = D(real, True)
+        assert rel(logit, Fw["logit"]) <= TOL and rel(ge, Fw["geo_emb"]) <= TOL and rel(ae, Fw["app_emb"]) <= TOL
+        assert rel(D(img, False)[0], Fw["logit_fake"]) <= TOL
+
+
+def test_adam_and_ema_kernels_vs_torch():
+    from lcgan_amd.ema import Ema
+    from lcgan_amd.optim import Adam
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in ((5, 3), (200001,), (1,), (512, 513, 3, 3))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt, topt = Adam(ps, lr=0.002, betas=(0.0, 0.99)), torch.optim.Adam(ref, lr=0.002, betas=(0.0, 0.99), eps=1e-8)
+    for it in range(3):
+        for i, (p, r) in enumerate(zip(ps, ref)):
+            if i == 2 and it == 1:
+                p.grad, r.grad = None, None
+            else:
+                g = torch.randn_like(p)
+                p.grad, r.grad = g.clone(), g.clone()
+        opt.step(), topt.step()
+    for p, r in zip(ps, ref):
+        assert torch.allclose(p, r, rtol=1e-5, atol=1e-7)
+    src = torch.nn.Linear(300, 70).to(DEV)
+    tgt = torch.nn.Linear(300, 70).to(DEV)
+    e = Ema(src, tgt, decay=0.99, start_iter=0)
+    with torch.no_grad():
+        for p in src.parameters():
+            p.add_(1.0)
+    before = [p.detach().clone() for p in tgt.parameters()]
+    e.update(0)
+    for p, b, s in zip(tgt.parameters(), before, src.parameters()):
+        assert torch.allclose(p, s + 0.99 * (b - s), rtol=1e-6, atol=1e-6)
+
+
+def _oracle_step(res, B, epoch, feed):
+    GP, DP = seeded_state(O.g_param_shapes(res), 1001), seeded_state(O.d_param_shapes(res), 1002)
+    z = [t.cpu() for t in feed.z]
+    real = tuple(t.cpu() for t in feed.real)
+    return O.g_step(GP, DP, res, epoch, tuple(z)), O.d_step(GP, DP, res, epoch, (z[0], z[1]), real)
+
+
+@pytest.mark.parametrize("dtype,loss_tol,grad_l2", [(torch.float32, 1e-3, 2e-3), (torch.bfloat16, 5e-2, 0.15)])
+def test_r1_iteration_64_vs_oracle(dtype, loss_tol, grad_l2):
+    """One odd+R1 iteration (BASELINE config 2's iteration type) at 64x64, batch 8, against the oracle, both dtypes."""
+    from lcgan_amd import config
+    res, B = 64, 8
+    with config.feature_dtype_as(dtype):
+        w = seeded_worker(res, B, DEV)
+        feed = FixedFeed(w, B, res, DEV)
+        w.g_optimizer.step = lambda: None
+        w.d_optimizer.step = lambda: None
+        w.requires_grad(w.generator, True), w.requires_grad(w.discriminator, False)
+        g_loss = w.train_generator(1)
+        w.requires_grad(w.generator, False), w.requires_grad(w.discriminator, True)
+        feed.reset()
+        d_loss = w.train_discriminator(1)
+    (g_ref, g_grads, _, _), (d_ref, d_grads, _, parts) = _oracle_step(res, B, 1, feed)
+    assert abs(g_loss - float(g_ref)) <= loss_tol * abs(float(g_ref)), (g_loss, float(g_ref))
+    assert abs(d_loss - float(d_ref)) <= loss_tol * abs(float(d_ref)), (d_loss, float(d_ref))
+
+    def l2(named, refs):
+        num = den = 0.0
+        for k, p in named:
+            if k in refs:
+                num += float((p.grad.double().cpu() - refs[k].double()).square().sum())
+                den += float(refs[k].double().square().sum())
+        return (num / den) ** 0.5
+    eg, ed = l2(w.generator.module.named_parameters(), g_grads), l2(w.discriminator.module.named_parameters(), d_grads)
+    assert eg <= grad_l2 and ed <= grad_l2, (eg, ed)
+
+
+def test_full_size_properties_256():
+    """BASELINE config-2 shapes (256x256, bf16): size-independent properties of the hot path.
+    (1) determinism of the forward; (2) linearity of the R1 gradient in the logit weight: scaling logit_mapper by a
+    doubles d(sum logit)/d(image), so R1 quadruples; (3) a full iteration with Adam + EMA keeps everything finite and
+    moves every used parameter."""
+    from lcgan_amd import config, loader, loss
+    res, B = 256, 4
+    with config.feature_dtype_as(torch.bfloat16):
+        w = seeded_worker(res, B, DEV)
+        real = seeded_tensor((B, 3, res, res), 7, "uniform_pm1").to(DEV)
+        D = w.discriminator
+        w.requires_grad(D, True)
+
+        def r1_of():
+            img = real.clone().requires_grad_(True)
+            logit, _, _ = D(img, False)
+            return float(loss.cal_r1_reg(logit, img))
+        a = r1_of()
+        assert a == r1_of()
+        with torch.no_grad():
+            D.module.logit_mapper.mlp[0].weight.weight.mul_(2.0)
+        b = r1_of()
+        assert abs(b / a - 4.0) <= 2e-2, (a, b)
+        with torch.no_grad():
+            D.module.logit_mapper.mlp[0].weight.weight.mul_(0.5)
+        before = {k: v.clone() for k, v in w.generator.module.state_dict().items()}
+        gl, dl = loader.train_iteration(w, make_args(res, B), 1)
+        assert np.isfinite(gl) and np.isfinite(dl)
+        moved = [k for k, v in w.generator.module.state_dict().items() if not torch.equal(v, before[k])]
+        assert len(moved) == len(before)
+        for v in list(w.generator.module.state_dict().values()) + list(w.discriminator.module.state_dict().values()):
+            assert torch.isfinite(v).all()
