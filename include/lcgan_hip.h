@@ -10,7 +10,7 @@
  *     (outputs and workspaces are allocated by the caller); `stream` is a hipStream_t passed as void*.
  *   - return value: 0 = launched, -1 = invalid argument, -2 = HIP launch error.  Nothing synchronises.
  *   - feature maps are NHWC ([B][H][W][C], C a multiple of 8; logical channels <= C, padding channels are 0),
- *     element type `dtype`: 0 = f32 ("parity mode": bf16x3 split MFMA, ~fp32 accuracy), 1 = bf16.
+ *     element type `dtype`: 0 = f32 ("parity mode": 3-way bf16 split, 6 MFMAs per product, fp32-grade), 1 = bf16.
  *   - per-sample channel vectors (styles, demodulation) are f32 [B][C] with the alloc width of the tensor
  *     they scale.  Images crossing the module boundary are f32 NCHW [B][3][H][W].
  *   - act: 0 none, 1 leaky_relu(0.2), 2 tanh;  out = act(v) * gain.
@@ -25,23 +25,23 @@ extern "C" {
  * replaces F.conv2d custom_layers.py:41,43,83 ; F.conv_transpose2d custom_layers.py:78 ; EqualizedWeight
  * scaling custom_layers.py:10,14 ; modulation/demodulation custom_layers.py:62-68 ; and their autograd. */
 
-/* w [A][Bc][k][k] f32 (reference layout) -> wp_hi/wp_lo bf16 [k*k][N][Kpad], N = transpose ? Bc : A,
- * Kpad = roundup32(transpose ? A : Bc); wp_lo (the bf16 residual, needed for dtype 0) and wsq [A][Bc]
- * (= sum_taps (scale*w)^2, the demodulation statistic) may be NULL. */
+/* w [A][Bc][k][k] f32 (reference layout) -> wp bf16 [parts][k*k][N][Kpad], N = transpose ? Bc : A,
+ * Kpad = roundup32(transpose ? A : Bc); part p holds the p-th bf16 term of the split scale*w = p0 + p1 + p2
+ * (parts = 1 for dtype bf16, 3 for dtype f32); wsq [A][Bc] (= sum_taps (scale*w)^2, the demodulation statistic) may be NULL. */
 int lcgan_conv_weight_prep(const float* w, int A, int Bc, int k, float scale, int transpose,
-                           void* wp_hi, void* wp_lo, float* wsq, void* stream);
+                           void* wp, int parts, float* wsq, void* stream);
 /* gw[a][b][t] = scale*gwp[t][a][b] + 2 scale^2 w[a][b][t] gwsq[a][b]  (w, gwsq may be NULL);
  * transposed != 0 reads gwp as [t][Bc][A] (weight gradient of the transposed convolution) */
 int lcgan_conv_wgrad_unprep(const float* gwp, int A, int Bc, int k, float scale, int transposed, const float* w,
                             const float* gwsq, float* gw, void* stream);
 /* y = act(post[b,n] * conv_{k,stride,pad=k/2}(pre[b,c] * x, wp) + bias[n]*bias_scale) * gain + residual */
-int lcgan_conv_fwd(const void* x, const void* wp_hi, const void* wp_lo, void* y,
+int lcgan_conv_fwd(const void* x, const void* wp, void* y,
                    int B, int Hin, int Win, int Cin, int Cout, int N, int k, int stride,
                    const float* pre, const float* post, const float* bias, float bias_scale,
                    int act, float gain, const void* residual, int dtype, void* stream);
 /* adjoint of lcgan_conv_fwd w.r.t. x (weights from weight_prep(transpose=1)); stride 2 == the x2 transposed
  * convolution of ModulatedConv2d(up=2): output [B][Hg*stride][Wg*stride][Cout]. */
-int lcgan_conv_bwd_data(const void* g, const void* wpT_hi, const void* wpT_lo, void* gx,
+int lcgan_conv_bwd_data(const void* g, const void* wpT, void* gx,
                         int B, int Hg, int Wg, int Cg, int Cout, int N, int k, int stride,
                         const float* pre, const float* post, const float* bias, float bias_scale,
                         int act, float gain, const void* residual, int dtype, void* stream);

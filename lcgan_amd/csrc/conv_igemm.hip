@@ -13,8 +13,9 @@
 //    and a per-(sample, out-channel) demodulation post-scale in the epilogue, so the per-sample weights the
 //    reference materialises ([B,Co,Ci,3,3], custom_layers.py:62-72) never exist.
 //  * Epilogue fuses demod, bias, leaky-ReLU, gain and a residual add.
-//  * fp32 feature maps (parity mode) run the same MFMA path with a hi/lo bf16 split of both operands
-//    (3 MFMAs per product, ~2^-16 relative error) -- NSPLIT == 3.
+//  * fp32 feature maps (parity mode) run the same MFMA path with a 3-way bf16 split x = p0 + p1 + p2 of both operands
+//    (24 mantissa bits) and the 6 products with i + j <= 2 -- fp32-grade (~2^-24) products, template parameter P == 3.
+//    (A 2-way split, ~2^-17, is not enough: the backward chain D -> G amplifies relative error ~200x.)
 //  * conv_wgrad_kernel reduces over positions: operands are staged row-major ([position][channel]) and read
 //    with ds_read_b64_tr_b16 so no transpose pass is needed; split-K partials are combined with fp32 atomics.
 #include "common.h"
@@ -28,7 +29,7 @@ constexpr int TILE = BM * LDS_ROW;        // elements per staged operand tile
 struct TapTable { int n; int dy[9]; int dx[9]; int wt[9]; };
 
 struct ConvArgs {
-  const void* x; const __bf16* w_hi; const __bf16* w_lo; void* y;
+  const void* x; const __bf16* w; size_t w_part; void* y;   // w: [P][taps][N][Kpad], w_part = elements per part
   const float* pre; const float* post; const float* bias; const void* residual;
   int B, Hin, Win, Cin;
   int Hout, Wout, Cout;
@@ -46,10 +47,11 @@ __device__ __forceinline__ bf16x8 to_bf16x8(const F8& f) {
   for (int i = 0; i < 8; ++i) r[i] = (__bf16)f.v[i];
   return r;
 }
-__device__ __forceinline__ bf16x8 residual_bf16x8(const F8& f, const bf16x8& hi) {
+// peel one bf16 part off f (f <- f - part): repeated P times this yields the P-way split
+__device__ __forceinline__ bf16x8 peel_bf16x8(F8& f) {
   bf16x8 r;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) r[i] = (__bf16)(f.v[i] - (float)hi[i]);
+  for (int i = 0; i < 8; ++i) { r[i] = (__bf16)f.v[i]; f.v[i] -= (float)r[i]; }
   return r;
 }
 __device__ __forceinline__ bf16x8 zero_bf16x8() {
@@ -59,10 +61,10 @@ __device__ __forceinline__ bf16x8 zero_bf16x8() {
   return r;
 }
 
-template <typename T, int NSPLIT>
+template <typename T, int P>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NT = (NSPLIT == 3) ? 4 : 2;            // operand tiles per stage: A_hi, B_hi, (A_lo, B_lo)
+  constexpr int NT = 2 * P;                            // operand tiles per stage: A parts 0..P-1, then B parts 0..P-1
   __bf16* lds = (__bf16*)smem;
   int* row_off = (int*)(smem + 2 * NT * TILE * sizeof(__bf16));
   int* row_b = row_off + BM;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   }
 
   F8 ra[2];
-  bf16x8 rb_hi[2], rb_lo[2];
+  bf16x8 rb[P][2];
 
   auto gload = [&](int q) {
     const int tap = q / a.kc_per_tap;
@@ -119,14 +121,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int n = n0 + lrow + 64 * i;
-      if (n < a.N) {
-        const size_t off = ((size_t)wt * a.N + n) * a.Kpad + c0;
-        rb_hi[i] = *(const bf16x8*)(a.w_hi + off);
-        if (NSPLIT == 3) rb_lo[i] = *(const bf16x8*)(a.w_lo + off);
-      } else {
-        rb_hi[i] = zero_bf16x8();
-        if (NSPLIT == 3) rb_lo[i] = zero_bf16x8();
-      }
+      const size_t off = ((size_t)wt * a.N + n) * a.Kpad + c0;
+#pragma unroll
+      for (int pp = 0; pp < P; ++pp) rb[pp][i] = (n < a.N) ? *(const bf16x8*)(a.w + pp * a.w_part + off) : zero_bf16x8();
     }
   };
 
@@ -135,12 +132,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int o = (lrow + 64 * i) * LDS_ROW + lvec * 8;
-      const bf16x8 hi = to_bf16x8(ra[i]);
-      *(bf16x8*)(base + o) = hi;
-      *(bf16x8*)(base + TILE + o) = rb_hi[i];
-      if (NSPLIT == 3) {
-        *(bf16x8*)(base + 2 * TILE + o) = residual_bf16x8(ra[i], hi);
-        *(bf16x8*)(base + 3 * TILE + o) = rb_lo[i];
+      F8 f = ra[i];
+#pragma unroll
+      for (int pp = 0; pp < P; ++pp) {
+        *(bf16x8*)(base + pp * TILE + o) = peel_bf16x8(f);
+        *(bf16x8*)(base + (P + pp) * TILE + o) = rb[pp][i];
       }
     }
   };
@@ -155,33 +151,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
   auto compute = [&](int buf) {
     const __bf16* A = lds + buf * NT * TILE;
-    const __bf16* Bt = A + TILE;
+    const __bf16* Bt = A + P * TILE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int koff = ks * 16 + (lane >> 5) * 8;
-      bf16x8 ah[2], bh[2], al[2], bl[2];
+      bf16x8 af[P][2], bf[P][2];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int o = (wm * 64 + mi * 32 + (lane & 31)) * LDS_ROW + koff;
-        ah[mi] = *(const bf16x8*)(A + o);
-        if (NSPLIT == 3) al[mi] = *(const bf16x8*)(A + 2 * TILE + o);
+      for (int pp = 0; pp < P; ++pp) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          af[pp][mi] = *(const bf16x8*)(A + pp * TILE + (wm * 64 + mi * 32 + (lane & 31)) * LDS_ROW + koff);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          bf[pp][ni] = *(const bf16x8*)(Bt + pp * TILE + (wn * 64 + ni * 32 + (lane & 31)) * LDS_ROW + koff);
       }
+      // products a_i * b_j with i + j < P, smallest terms first
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int o = (wn * 64 + ni * 32 + (lane & 31)) * LDS_ROW + koff;
-        bh[ni] = *(const bf16x8*)(Bt + o);
-        if (NSPLIT == 3) bl[ni] = *(const bf16x8*)(Bt + 2 * TILE + o);
-      }
+      for (int sum = P - 1; sum >= 0; --sum)
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+        for (int i = 0; i <= sum; ++i)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          if (NSPLIT == 3) {
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
-          }
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-        }
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][mi], bf[sum - i][ni], acc[mi][ni], 0, 0, 0);
     }
   };
 
@@ -249,10 +242,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* tile, int row0, int col)
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <typename T, int NSPLIT>
+template <typename T, int P>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NT = (NSPLIT == 3) ? 4 : 2;            // G_hi, X_hi, (G_lo, X_lo)
+  constexpr int NT = 2 * P;                            // G parts 0..P-1, then X parts 0..P-1
   __bf16* lds = (__bf16*)smem;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -305,12 +298,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int o = (lpos + 16 * i) * WG_ROW + lvec * 8;
-      const bf16x8 gh = to_bf16x8(rg[i]), xh = to_bf16x8(rx[i]);
-      *(bf16x8*)(base + o) = gh;
-      *(bf16x8*)(base + WG_TILE + o) = xh;
-      if (NSPLIT == 3) {
-        *(bf16x8*)(base + 2 * WG_TILE + o) = residual_bf16x8(rg[i], gh);
-        *(bf16x8*)(base + 3 * WG_TILE + o) = residual_bf16x8(rx[i], xh);
+      F8 fg = rg[i], fx = rx[i];
+#pragma unroll
+      for (int pp = 0; pp < P; ++pp) {
+        *(bf16x8*)(base + pp * WG_TILE + o) = peel_bf16x8(fg);
+        *(bf16x8*)(base + (P + pp) * WG_TILE + o) = peel_bf16x8(fx);
       }
     }
   };
@@ -331,30 +323,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
   auto compute = [&](int buf) {
     const __bf16* G = lds + buf * NT * WG_TILE;
-    const __bf16* X = G + WG_TILE;
+    const __bf16* X = G + P * WG_TILE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 ah[2], bh[2], al[2], bl[2];
+      bf16x8 af[P][2], bf[P][2];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        ah[mi] = tr_frag(G, ks * 16 + trow, wm * 64 + mi * 32 + tcol);
-        if (NSPLIT == 3) al[mi] = tr_frag(G + 2 * WG_TILE, ks * 16 + trow, wm * 64 + mi * 32 + tcol);
+      for (int pp = 0; pp < P; ++pp) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) af[pp][mi] = tr_frag(G + pp * WG_TILE, ks * 16 + trow, wm * 64 + mi * 32 + tcol);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) bf[pp][ni] = tr_frag(X + pp * WG_TILE, ks * 16 + trow, wn * 64 + ni * 32 + tcol);
       }
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        bh[ni] = tr_frag(X, ks * 16 + trow, wn * 64 + ni * 32 + tcol);
-        if (NSPLIT == 3) bl[ni] = tr_frag(X + 2 * WG_TILE, ks * 16 + trow, wn * 64 + ni * 32 + tcol);
-      }
+      for (int sum = P - 1; sum >= 0; --sum)
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+        for (int i = 0; i <= sum; ++i)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          if (NSPLIT == 3) {
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
-          }
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-        }
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][mi], bf[sum - i][ni], acc[mi][ni], 0, 0, 0);
     }
   };
 
@@ -385,11 +373,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 // =========================================================================================================
 // weight layout kernels
 // =========================================================================================================
-// w [A][Bc][kk] fp32 (reference layout, custom_layers.py:32,55)  ->  wp [kk][N][Kpad] bf16 (hi, lo), scaled.
+// w [A][Bc][kk] fp32 (reference layout, custom_layers.py:32,55)  ->  wp [parts][kk][N][Kpad] bf16 split, scaled.
 //   transpose == 0: N = A,  reduction channel = Bc   (forward conv)
 //   transpose == 1: N = Bc, reduction channel = A    (data gradient / transposed conv)
 __global__ void prep_weight_kernel(const float* __restrict__ w, int A, int Bc, int kk, float scale, int transpose,
-                                   __bf16* __restrict__ hi, __bf16* __restrict__ lo, int N, int Kc, int Kpad) {
+                                   __bf16* __restrict__ out, int parts, int N, int Kc, int Kpad) {
   const size_t total = (size_t)kk * N * Kpad;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(idx % Kpad);
@@ -400,9 +388,11 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, int A, int Bc, i
       const int aa = transpose ? c : n, bb = transpose ? n : c;
       v = w[((size_t)aa * Bc + bb) * kk + t] * scale;
     }
-    const __bf16 h = (__bf16)v;
-    hi[idx] = h;
-    if (lo) lo[idx] = (__bf16)(v - (float)h);
+    for (int pp = 0; pp < parts; ++pp) {           // bf16 split v = p0 + p1 + ... (8 mantissa bits per part)
+      const __bf16 h = (__bf16)v;
+      out[(size_t)pp * total + idx] = h;
+      v -= (float)h;
+    }
   }
 }
 
@@ -434,7 +424,7 @@ __global__ void unprep_wgrad_kernel(const float* __restrict__ gwp, int A, int Bc
 
 template <typename T, int NS>
 int launch_igemm(const ConvArgs& a, int nphase, hipStream_t s) {
-  constexpr int NT = (NS == 3) ? 4 : 2;
+  constexpr int NT = 2 * NS;
   const size_t smem = 2 * NT * TILE * sizeof(__bf16) + 2 * BM * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
@@ -460,14 +450,14 @@ int dispatch_igemm(const ConvArgs& a, int nphase, int dtype, hipStream_t s) {
 extern "C" {
 
 int lcgan_conv_weight_prep(const float* w, int A, int Bc, int k, float scale, int transpose,
-                           void* wp_hi, void* wp_lo, float* wsq, void* stream) {
+                           void* wp, int parts, float* wsq, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (k != 1 && k != 3) return LCGAN_EINVAL;
+  if ((k != 1 && k != 3) || parts < 1 || parts > 3) return LCGAN_EINVAL;
   const int kk = k * k, N = transpose ? Bc : A, Kc = transpose ? A : Bc, Kpad = (Kc + 31) / 32 * 32;
   ProfScope p(KID_WEIGHT_PREP, 0, (double)A * Bc * kk * 8, s);
   const size_t total = (size_t)kk * N * Kpad;
   hipLaunchKernelGGL(prep_weight_kernel, dim3((unsigned)min((size_t)4096, (total + 255) / 256)), dim3(256), 0, s,
-                     w, A, Bc, kk, scale, transpose, (__bf16*)wp_hi, (__bf16*)wp_lo, N, Kc, Kpad);
+                     w, A, Bc, kk, scale, transpose, (__bf16*)wp, parts, N, Kc, Kpad);
   if (wsq) hipLaunchKernelGGL(wsq_kernel, dim3(cdiv((long long)A * Bc, 256)), dim3(256), 0, s, w, A * Bc, kk, scale, wsq);
   return launch_status();
 }
@@ -483,18 +473,18 @@ int lcgan_conv_wgrad_unprep(const float* gwp, int A, int Bc, int k, float scale,
   return launch_status();
 }
 
+// (parity mode, dtype f32, expects weights prepared with parts = 3; bf16 with parts = 1)
 // Forward convolution  y[b,ho,wo,n] = act(post[b,n] * sum_{t,c} pre[b,c] x[b, ho*stride+ky-pad, wo*stride+kx-pad, c] wp[t][n][c]
 //                                        + bias[n]*bias_scale) * gain + residual
 // x: [B,Hin,Win,Cin]  wp: lcgan_conv_weight_prep(transpose=0)  y: [B,Hout,Wout,Cout], Hout = ceil(Hin/stride)
-int lcgan_conv_fwd(const void* x, const void* wp_hi, const void* wp_lo, void* y,
+int lcgan_conv_fwd(const void* x, const void* wp, void* y,
                    int B, int Hin, int Win, int Cin, int Cout, int N, int k, int stride,
                    const float* pre, const float* post, const float* bias, float bias_scale,
                    int act, float gain, const void* residual, int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || (Cin & 7) || (Cout & 7) || N > Cout) return LCGAN_EINVAL;
-  if (dtype == DT_F32 && !wp_lo) return LCGAN_EINVAL;
   ConvArgs a = {};
-  a.x = x; a.w_hi = (const __bf16*)wp_hi; a.w_lo = (const __bf16*)wp_lo; a.y = y;
+  a.x = x; a.w = (const __bf16*)wp; a.y = y;
   a.pre = pre; a.post = post; a.bias = bias; a.residual = residual;
   a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin;
   a.Hout = (Hin + stride - 1) / stride; a.Wout = (Win + stride - 1) / stride; a.Cout = Cout;
@@ -502,6 +492,7 @@ int lcgan_conv_fwd(const void* x, const void* wp_hi, const void* wp_lo, void* y,
   const long long M = (long long)B * a.Hm * a.Wm;
   if (M <= 0 || M >= (1ll << 31) || (long long)B * Hin * Win >= (1ll << 31)) return LCGAN_EINVAL;
   a.M = (int)M; a.N = N; a.Kpad = (Cin + 31) / 32 * 32; a.kc_per_tap = a.Kpad / BK;
+  a.w_part = (size_t)k * k * N * a.Kpad;
   a.in_mul = stride; a.out_mul = 1; a.pre_stride = Cin; a.post_stride = Cout;
   a.bias_scale = bias_scale; a.gain = gain; a.act = act;
   const int pad = k / 2;
@@ -517,16 +508,15 @@ int lcgan_conv_fwd(const void* x, const void* wp_hi, const void* wp_lo, void* y,
 //   gx[b,h,w,n] = act(post[b,n] * sum_{t,c} pre[b,c] g[b,(h+pad-ky)/stride,(w+pad-kx)/stride,c] wpT[t][n][c] + bias) * gain + residual
 // g: [B,Hg,Wg,Cg] (the conv's output grid)  wpT: lcgan_conv_weight_prep(transpose=1)  gx: [B,Hg*stride,Wg*stride,Cout]
 // stride 2 runs as 4 sub-pixel phases with 1/2/2/4 taps (== F.conv_transpose2d(stride=2, padding=1, output_padding=1)).
-int lcgan_conv_bwd_data(const void* g, const void* wpT_hi, const void* wpT_lo, void* gx,
+int lcgan_conv_bwd_data(const void* g, const void* wpT, void* gx,
                         int B, int Hg, int Wg, int Cg, int Cout, int N, int k, int stride,
                         const float* pre, const float* post, const float* bias, float bias_scale,
                         int act, float gain, const void* residual, int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || (Cg & 7) || (Cout & 7) || N > Cout) return LCGAN_EINVAL;
   if (stride == 2 && k != 3) return LCGAN_EINVAL;
-  if (dtype == DT_F32 && !wpT_lo) return LCGAN_EINVAL;
   ConvArgs a = {};
-  a.x = g; a.w_hi = (const __bf16*)wpT_hi; a.w_lo = (const __bf16*)wpT_lo; a.y = gx;
+  a.x = g; a.w = (const __bf16*)wpT; a.y = gx;
   a.pre = pre; a.post = post; a.bias = bias; a.residual = residual;
   a.B = B; a.Hin = Hg; a.Win = Wg; a.Cin = Cg;
   a.Hout = Hg * stride; a.Wout = Wg * stride; a.Cout = Cout;
@@ -534,6 +524,7 @@ int lcgan_conv_bwd_data(const void* g, const void* wpT_hi, const void* wpT_lo, v
   const long long M = (long long)B * a.Hm * a.Wm;
   if (M <= 0 || (long long)B * a.Hout * a.Wout >= (1ll << 31)) return LCGAN_EINVAL;
   a.M = (int)M; a.N = N; a.Kpad = (Cg + 31) / 32 * 32; a.kc_per_tap = a.Kpad / BK;
+  a.w_part = (size_t)k * k * N * a.Kpad;
   a.in_mul = 1; a.out_mul = stride; a.pre_stride = Cg; a.post_stride = Cout;
   a.bias_scale = bias_scale; a.gain = gain; a.act = act;
   const int pad = k / 2;
@@ -590,7 +581,7 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
     const size_t smem = 2 * 2 * WG_TILE * sizeof(__bf16);
     hipLaunchKernelGGL((conv_wgrad_kernel<__bf16, 1>), grid, dim3(256), smem, s, a);
   } else if (dtype == DT_F32) {
-    const size_t smem = 2 * 4 * WG_TILE * sizeof(__bf16);
+    const size_t smem = 2 * 6 * WG_TILE * sizeof(__bf16);
     static bool attr_set = false;
     if (!attr_set) {
       hipFuncSetAttribute((const void*)conv_wgrad_kernel<float, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -34,11 +34,12 @@ def _p(t: Optional[Tensor]):
 
 
 class PreparedWeight:
-    """bf16 (hi [+ lo residual]) GEMM-layout copy of a conv weight: [k*k][N][Kpad]."""
-    __slots__ = ("hi", "lo", "N", "Kpad", "k")
+    """bf16 GEMM-layout copy of a conv weight: [parts][k*k][N][Kpad]; parts = 1 (bf16 features) or 3 (f32 parity mode:
+    scale*w = p0 + p1 + p2, 24 mantissa bits)."""
+    __slots__ = ("buf", "parts", "N", "Kpad", "k")
 
-    def __init__(self, hi, lo, N, Kpad, k):
-        self.hi, self.lo, self.N, self.Kpad, self.k = hi, lo, N, Kpad, k
+    def __init__(self, buf, parts, N, Kpad, k):
+        self.buf, self.parts, self.N, self.Kpad, self.k = buf, parts, N, Kpad, k
 
 
 class HipKernels:
@@ -67,12 +68,12 @@ class HipKernels:
         A, Bc, k, _ = w.shape
         N, Kc = (Bc, A) if transpose else (A, Bc)
         Kpad = (Kc + 31) // 32 * 32
-        hi = torch.empty((k * k, N, Kpad), dtype=torch.bfloat16, device=w.device)
-        lo = torch.empty_like(hi) if need_lo else None
+        parts = 3 if need_lo else 1
+        buf = torch.empty((parts, k * k, N, Kpad), dtype=torch.bfloat16, device=w.device)
         wsq = torch.empty((A, Bc), dtype=torch.float32, device=w.device) if want_wsq else None
-        self._call("lcgan_conv_weight_prep", w.data_ptr(), A, Bc, k, float(scale), int(transpose), hi.data_ptr(), _p(lo), _p(wsq),
+        self._call("lcgan_conv_weight_prep", w.data_ptr(), A, Bc, k, float(scale), int(transpose), buf.data_ptr(), parts, _p(wsq),
                    self._stream())
-        return PreparedWeight(hi, lo, N, Kpad, k), wsq
+        return PreparedWeight(buf, parts, N, Kpad, k), wsq
 
     def unprep_wgrad(self, gwp: Tensor, A: int, Bc: int, k: int, scale: float, transposed: bool = False,
                      w: Optional[Tensor] = None, gwsq: Optional[Tensor] = None) -> Tensor:
@@ -88,7 +89,8 @@ class HipKernels:
         B, H, W, Cin = x.shape
         Cout = ceil8(N)
         y = torch.empty((B, (H + stride - 1) // stride, (W + stride - 1) // stride, Cout), dtype=x.dtype, device=x.device)
-        self._call("lcgan_conv_fwd", x.data_ptr(), pw.hi.data_ptr(), _p(pw.lo), y.data_ptr(), B, H, W, Cin, Cout, N, k, stride,
+        assert pw.parts == (3 if x.dtype == torch.float32 else 1)
+        self._call("lcgan_conv_fwd", x.data_ptr(), pw.buf.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, N, k, stride,
                    _p(pre), _p(post), _p(bias), float(bias_scale), act, float(gain), _p(residual), dt_code(x.dtype), self._stream())
         return y
 
@@ -98,7 +100,8 @@ class HipKernels:
         B, H, W, Cg = g.shape
         Cout = ceil8(N)
         gx = torch.empty((B, H * stride, W * stride, Cout), dtype=g.dtype, device=g.device)
-        self._call("lcgan_conv_bwd_data", g.data_ptr(), pw.hi.data_ptr(), _p(pw.lo), gx.data_ptr(), B, H, W, Cg, Cout, N, k, stride,
+        assert pw.parts == (3 if g.dtype == torch.float32 else 1)
+        self._call("lcgan_conv_bwd_data", g.data_ptr(), pw.buf.data_ptr(), gx.data_ptr(), B, H, W, Cg, Cout, N, k, stride,
                    _p(pre), _p(post), _p(bias), float(bias_scale), act, float(gain), _p(residual), dt_code(g.dtype), self._stream())
         return gx
 

@@ -25,7 +25,7 @@ OUT = os.path.join(ROOT, "tests", "golden")
 REF = "/root/reference"
 
 from . import lcgan_ref as O          # noqa: E402  (shapes only; the numbers below come from the reference)
-from .weights import seeded_state, seeded_tensor   # noqa: E402
+from .weights import grad_stats, seeded_state, seeded_tensor   # noqa: E402
 
 
 def _import_reference():
@@ -46,7 +46,10 @@ def sample(t: torch.Tensor, n: int = 257) -> np.ndarray:
 def summarize(prefix: str, t: torch.Tensor, d: dict):
     d[prefix + "/sample"] = sample(t)
     d[prefix + "/sum"] = np.float64(t.detach().double().sum().item())
-    d[prefix + "/abssum"] = np.float64(t.detach().double().abs().sum().item())
+    st = grad_stats(t, prefix.split("/grad/")[-1])
+    d[prefix + "/abssum"] = np.float64(st["abssum"])
+    d[prefix + "/l2"] = np.float64(st["l2"])
+    d[prefix + "/proj"] = st["proj"]
 
 
 def load(module, state):

@@ -51,3 +51,14 @@ def seeded_tensor(shape, seed: int, kind: str = "normal") -> torch.Tensor:
     else:
         raise ValueError(kind)
     return torch.from_numpy(a)
+
+
+def grad_stats(t: torch.Tensor, key: str, nproj: int = 8) -> dict:
+    """Global statistics of a gradient tensor that stay meaningful when ONE element differs (a leaky-ReLU mask flip at a
+    pre-activation of ~1e-7 is rounding noise, yet moves single gradient entries by percents): L1 and L2 norms and
+    `nproj` projections on +-1 vectors drawn from PCG64(crc32(key))."""
+    import zlib
+    f = t.detach().double().reshape(-1).cpu()
+    rng = np.random.Generator(np.random.PCG64(zlib.crc32(key.encode())))
+    signs = torch.from_numpy(rng.integers(0, 2, size=(nproj, f.numel()), dtype=np.int8).astype(np.float64) * 2 - 1)
+    return {"abssum": float(f.abs().sum()), "l2": float(f.norm()), "proj": (signs @ f).numpy()}

@@ -63,7 +63,10 @@ def sample(t, n=257):
 
 
 def check_grads_vs_golden(S, tag, named_params, tol):
-    """named_params: iterable of (name-without-module-prefix, parameter with .grad).  Returns the worst relative error."""
+    """Gradient parity against the golden vectors through statistics that are robust to single activation-mask flips
+    (oracle/weights.py:grad_stats): |L1 - L1ref| / L1ref, |L2 - L2ref| / L2ref and max_k |proj_k - proj_k,ref| / L2ref.
+    named_params: iterable of (name-without-module-prefix, parameter with .grad).  Returns the worst error."""
+    from oracle.weights import grad_stats
     worst = 0.0
     for k, p in named_params:
         key = f"{tag}/grad/{k}/abssum"
@@ -71,13 +74,11 @@ def check_grads_vs_golden(S, tag, named_params, tol):
             assert key not in S, f"{tag}: {k} has no grad but the reference produced one"
             continue
         assert key in S, f"{tag}: {k} has a grad but the reference left it None"
-        g = p.grad
-        ref_abssum = float(S[key])
-        got_abssum = float(g.double().abs().sum())
-        e1 = abs(got_abssum - ref_abssum) / max(ref_abssum, 1e-30)
-        ref_s = S[f"{tag}/grad/{k}/sample"]
-        scale = max(float(np.abs(ref_s).max()), ref_abssum / g.numel(), 1e-30)
-        e2 = float(np.abs(sample(g).numpy() - ref_s).max()) / scale
-        worst = max(worst, e1, e2)
-        assert e1 <= tol and e2 <= tol, f"{tag} {k}: abssum err {e1:.2e}, sample err {e2:.2e} (tol {tol})"
+        st = grad_stats(p.grad, k)
+        ref_l1, ref_l2, ref_proj = float(S[key]), float(S[f"{tag}/grad/{k}/l2"]), S[f"{tag}/grad/{k}/proj"]
+        e1 = abs(st["abssum"] - ref_l1) / max(ref_l1, 1e-30)
+        e2 = abs(st["l2"] - ref_l2) / max(ref_l2, 1e-30)
+        e3 = float(np.abs(st["proj"] - ref_proj).max()) / max(ref_l2, 1e-30)
+        worst = max(worst, e1, e2, e3)
+        assert max(e1, e2, e3) <= tol, f"{tag} {k}: L1 err {e1:.2e}, L2 err {e2:.2e}, projection err {e3:.2e} (tol {tol})"
     return worst

@@ -197,17 +197,15 @@ def _sample(t, n=257):
 
 
 def _check_grads(S, tag, grads, tol=RTOL):
+    from oracle.weights import grad_stats
     worst = 0.0
     for k, g in grads.items():
-        ref_abssum = float(S[f"{tag}/grad/{k}/abssum"])
-        got_abssum = float(g.double().abs().sum())
-        assert abs(got_abssum - ref_abssum) <= tol * max(ref_abssum, 1e-30), (tag, k, got_abssum, ref_abssum)
-        ref_s = S[f"{tag}/grad/{k}/sample"]
-        # per-key scale: the sample's own max can be tiny for some tensors, use abssum/numel as floor
-        scale = max(np.abs(ref_s).max(), ref_abssum / g.numel())
-        err = np.abs(_sample(g).numpy() - ref_s).max() / max(scale, 1e-30)
-        worst = max(worst, err)
-        assert err <= tol, (tag, k, err)
+        st = grad_stats(g, k)
+        ref_l1, ref_l2, ref_proj = float(S[f"{tag}/grad/{k}/abssum"]), float(S[f"{tag}/grad/{k}/l2"]), S[f"{tag}/grad/{k}/proj"]
+        errs = (abs(st["abssum"] - ref_l1) / max(ref_l1, 1e-30), abs(st["l2"] - ref_l2) / max(ref_l2, 1e-30),
+                float(np.abs(st["proj"] - ref_proj).max()) / max(ref_l2, 1e-30))
+        worst = max(worst, *errs)
+        assert max(errs) <= tol, (tag, k, errs)
     return worst
 
 

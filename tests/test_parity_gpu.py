@@ -1,8 +1,8 @@
 """End-to-end parity on the MI355X: the worker's G and D steps run on the HIP kernels (through the C ABI) and are compared
 with (a) the golden vectors captured from the reference (tests/golden/*.npz) and (b) the CPU oracle on the same inputs.
 
-Tolerances: parity mode (f32 features, bf16x3 MFMA) 1e-3 relative -- BASELINE.json's north_star tolerance -- with the
-3e-3 allowance for even-iteration gradients explained in test_wiring_cpu.py; bf16 features (the benchmark dtype) are
+Tolerances: parity mode (f32 features, 3-way bf16 split MFMA) 1e-3 relative -- BASELINE.json's north_star tolerance --
+on outputs / losses (max-abs relative) and on gradients through the kink-robust statistics of tests/helpers.py; bf16 features (the benchmark dtype) are
 compared with the oracle at 5e-2 on losses / relative-L2 0.15 on gradients (bf16 has 8 mantissa bits: 2^-9 per rounding,
 accumulated over ~40 layers and the backward pass)."""
 import os
@@ -17,7 +17,7 @@ from oracle import lcgan_ref as O                      # noqa: E402
 from oracle.weights import seeded_state, seeded_tensor  # noqa: E402
 from tests.helpers import GOLD, FixedFeed, check_grads_vs_golden, make_args, seeded_worker   # noqa: E402
 
-TOL, TOL_EVEN_GRADS = 1e-3, 3e-3
+TOL, TOL_EVEN_GRADS = 1e-3, 3e-3      # see tests/test_wiring_cpu.py for the even-iteration allowance
 DEV = "cuda:0"
 
 

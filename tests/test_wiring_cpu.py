@@ -15,10 +15,12 @@ from oracle.weights import seeded_state, seeded_tensor
 from tests.helpers import GOLD, FixedFeed, check_grads_vs_golden, seeded_worker
 
 TOL = 1e-3        # north_star tolerance (relative, fp32)
-# Even iterations carry the contrastive loss exp(sim / tau) with tau = 0.05: fp32 rounding of the embeddings is amplified
-# 20x, and few-element gradients (e.g. the 2-value flow bias) are sums with heavy cancellation.  Two fp32-correct
-# implementations (reference vs oracle, different summation orders) already differ by up to ~1e-3 there, so gradients of
-# even iterations are compared at 3e-3; losses and every odd-iteration quantity stay at 1e-3.
+# Gradients are compared through L1 / L2 norms and seeded random projections (tests/helpers.py): elementwise maxima are
+# ill-posed because a leaky-ReLU pre-activation within ~1e-7 of zero flips its mask under any change of summation order
+# (measured: one such flip of 131 072 elements moves single weight-gradient entries by 2.6e-2).
+# Even iterations add the contrastive loss exp(sim / tau), tau = 0.05: rounding of the embeddings is amplified 20x and
+# few-element gradients (the 2-value flow bias) are sums with heavy cancellation; two fp32-correct implementations
+# (reference vs oracle) already differ by ~1e-3 there, so even-iteration gradients are held to 3e-3.
 TOL_EVEN_GRADS = 3e-3
 
 
