@@ -62,12 +62,11 @@ def sample(t, n=257):
     return f[::step][:n]
 
 
-def check_grads_vs_golden(S, tag, named_params, tol):
-    """Gradient parity against the golden vectors through statistics that are robust to single activation-mask flips
-    (oracle/weights.py:grad_stats): |L1 - L1ref| / L1ref, |L2 - L2ref| / L2ref and max_k |proj_k - proj_k,ref| / L2ref.
-    named_params: iterable of (name-without-module-prefix, parameter with .grad).  Returns the worst error."""
+def grad_errors_vs_golden(S, tag, named_params):
+    """Per-tensor error of gradients against the golden vectors through statistics that are robust to single activation-mask
+    flips (oracle/weights.py:grad_stats): max(|L1 - L1ref| / L1ref, |L2 - L2ref| / L2ref, max_k |proj_k - proj_k,ref| / L2ref)."""
     from oracle.weights import grad_stats
-    worst = 0.0
+    errs = {}
     for k, p in named_params:
         key = f"{tag}/grad/{k}/abssum"
         if p.grad is None:
@@ -76,9 +75,28 @@ def check_grads_vs_golden(S, tag, named_params, tol):
         assert key in S, f"{tag}: {k} has a grad but the reference left it None"
         st = grad_stats(p.grad, k)
         ref_l1, ref_l2, ref_proj = float(S[key]), float(S[f"{tag}/grad/{k}/l2"]), S[f"{tag}/grad/{k}/proj"]
-        e1 = abs(st["abssum"] - ref_l1) / max(ref_l1, 1e-30)
-        e2 = abs(st["l2"] - ref_l2) / max(ref_l2, 1e-30)
-        e3 = float(np.abs(st["proj"] - ref_proj).max()) / max(ref_l2, 1e-30)
-        worst = max(worst, e1, e2, e3)
-        assert max(e1, e2, e3) <= tol, f"{tag} {k}: L1 err {e1:.2e}, L2 err {e2:.2e}, projection err {e3:.2e} (tol {tol})"
-    return worst
+        errs[k] = max(abs(st["abssum"] - ref_l1) / max(ref_l1, 1e-30), abs(st["l2"] - ref_l2) / max(ref_l2, 1e-30),
+                      float(np.abs(st["proj"] - ref_proj).max()) / max(ref_l2, 1e-30))
+    return errs
+
+
+def check_grads_vs_golden(S, tag, named_params, tol):
+    """Strict form: EVERY tensor within tol (used where both sides round identically enough: CPU emulation vs reference)."""
+    errs = grad_errors_vs_golden(S, tag, named_params)
+    bad = {k: v for k, v in errs.items() if v > tol}
+    assert not bad, f"{tag}: {len(bad)} tensors above {tol}: {sorted(bad.items(), key=lambda kv: -kv[1])[:4]}"
+    return max(errs.values())
+
+
+def check_grads_vs_golden_kink_tolerant(S, tag, named_params, tol, kink_tol=1e-2, kink_frac=0.05, median_tol=2e-4):
+    """GPU form.  The HIP path sums in a different order than the reference, so a leaky-ReLU pre-activation within ~1e-7
+    of zero can land on the other side of the kink (measured: 1 element of 131 072 -> single entries of low-resolution
+    weight gradients move by 2.6e-2; tests/test_wiring_cpu.py).  Such a flip is rounding noise of the REFERENCE too.  Required:
+    the median tensor error is fp32-grade (<= median_tol), at least 1 - kink_frac of the tensors are within tol, none above kink_tol."""
+    errs = grad_errors_vs_golden(S, tag, named_params)
+    v = np.array(sorted(errs.values()))
+    over = {k: e for k, e in errs.items() if e > tol}
+    assert float(np.median(v)) <= median_tol, f"{tag}: median gradient error {np.median(v):.2e} > {median_tol}"
+    assert len(over) <= kink_frac * len(v), f"{tag}: {len(over)}/{len(v)} tensors above {tol}: {sorted(over.items(), key=lambda kv: -kv[1])[:5]}"
+    assert v[-1] <= kink_tol, f"{tag}: worst tensor {v[-1]:.2e} > {kink_tol}: {max(errs, key=errs.get)}"
+    return float(v[-1])
