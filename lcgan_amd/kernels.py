@@ -191,14 +191,14 @@ class HipKernels:
     def warp_bwd(self, gy: Tensor, x: Tensor, flow: Tensor, scale: float) -> Tuple[Tensor, Tensor]:
         self._chk(gy, x, flow)
         B, H, W, Cc = x.shape
-        gx32 = torch.zeros((B, H, W, Cc), dtype=torch.float32, device=x.device)
-        gflow = torch.empty_like(flow)
-        self._call("lcgan_warp_bwd", gy.data_ptr(), x.data_ptr(), flow.data_ptr(), gx32.data_ptr(), gflow.data_ptr(), B, H, W, Cc,
-                   float(scale), dt_code(x.dtype), self._stream())
-        if x.dtype == torch.float32:
-            return gx32, gflow
-        gx = torch.empty_like(x)
-        self._call("lcgan_cast_from_f32", gx32.data_ptr(), gx.data_ptr(), gx32.numel(), dt_code(x.dtype), self._stream())
+        npix = B * H * W
+        ovf_cap = 1 << 20
+        ws_cnt = torch.empty((npix + 4,), dtype=torch.int32, device=x.device)
+        ws_ent = torch.empty((npix * 32, 2), dtype=torch.int32, device=x.device)
+        ws_ovf = torch.empty((ovf_cap, 3), dtype=torch.int32, device=x.device)
+        gx, gflow = torch.empty_like(x), torch.empty_like(flow)
+        self._call("lcgan_warp_bwd", gy.data_ptr(), x.data_ptr(), flow.data_ptr(), gx.data_ptr(), gflow.data_ptr(), ws_cnt.data_ptr(),
+                   ws_ent.data_ptr(), ws_ovf.data_ptr(), ovf_cap, B, H, W, Cc, float(scale), dt_code(x.dtype), self._stream())
         return gx, gflow
 
     def mbstd_fwd(self, x: Tensor, G: int, Cy: int) -> Tensor:

@@ -205,6 +205,22 @@ def test_warp(H, dtype, shape):
     check(gf_g, gf_r, dtype, "warp gflow")
 
 
+def test_warp_bwd_overflow_lists(H):
+    """Every output pixel samples (almost) the same point: the per-input-pixel lists (capacity 32) overflow into the
+    global overflow list; the gather must still be exact."""
+    B, Hh, W, C = 2, 16, 16, 32
+    dtype = torch.float32
+    x, gy = feat((B, Hh, W, C), dtype, 54), feat((B, Hh, W, C), dtype, 55)
+    gyy, gxx = torch.meshgrid(torch.arange(Hh, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    flow = torch.zeros(B, Hh, W, 8)
+    flow[..., 0] = -(2 * gxx / (W - 1) - 1) + 0.013        # cancels the base grid: every pixel lands near the centre
+    flow[..., 1] = -(2 * gyy / (Hh - 1) - 1) - 0.021
+    gx_r, gf_r = E.warp_bwd(gy, x, flow, 1.0)
+    gx_g, gf_g = H.warp_bwd(gy.cuda(), x.cuda(), flow.cuda(), 1.0)
+    check(gx_g, gx_r, dtype, "overflow gx")
+    check(gf_g, gf_r, dtype, "overflow gflow")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("N,G", [(4, 4), (8, 8), (16, 8), (32, 8)])
 def test_mbstd(H, dtype, N, G):
