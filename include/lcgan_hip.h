@@ -91,7 +91,7 @@ int lcgan_nhwc_to_nchw(const void* src, float* dst, int B, int HW, int C, int Cl
 /* ---- small f32 linears: EqualizedLinear custom_layers.py:24-25 (+ autograd) ------------------------------- */
 int lcgan_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int I, int O,
                      float scale, float bias_scale, int act, float gain, void* stream);
-int lcgan_linear_bwd_data(const float* gy, const float* w, float* gx, int M, int I, int O, float scale, void* stream); /* gx zeroed by caller */
+int lcgan_linear_bwd_data(const float* gy, const float* w, float* gx, int M, int I, int O, float scale, void* stream);
 int lcgan_linear_wgrad(const float* gy, const float* x, float* gw, int M, int I, int O, float scale, void* stream);
 int lcgan_colsum(const float* gy, float* gb, int M, int O, float scale, void* stream);
 int lcgan_act_bwd_f32(const float* gy, const float* y, float* gz, long long n, int act, float gain, void* stream);
@@ -118,6 +118,9 @@ int lcgan_avg_latent(const float* w, float* avg, int B, int D, float beta, void*
  *      gradient bucket pack for the RCCL all-reduce that replaces DDP's reducer worker.py:88-96 (op 2) -------- */
 int lcgan_multi_tensor(const void* descs, const int* chunk_tensor, const int* chunk_index, int n_chunks, int op,
                        float a0, float a1, float a2, double total_elems, void* stream);
+
+/* tuning switches (A/B tests): option 0 = bf16 halo-tile conv kernel on/off; returns the previous value */
+int lcgan_set_option(int option, int value);
 
 /* ---- per-launch HIP-event profiling (bench.py roofline) ---------------------------------------------------- */
 int lcgan_prof_enable(int on);

@@ -56,6 +56,7 @@ SIGNATURES = {
     "lcgan_powsum_bwd": [P, LL, I, F, P, P, P],
     "lcgan_avg_latent": [P, P, I, I, F, P],
     "lcgan_multi_tensor": [P, P, P, I, I, F, F, F, D, P],
+    "lcgan_set_option": [I, I],
     "lcgan_prof_enable": [I],
     "lcgan_prof_collect": [P, P, P, P],
     "lcgan_prof_active": [],

@@ -20,7 +20,11 @@
 //    with ds_read_b64_tr_b16 so no transpose pass is needed; split-K partials are combined with fp32 atomics.
 #include "common.h"
 
+#include <algorithm>
+
 namespace {
+
+int g_use_halo = 1;                       // lcgan_set_option(0, ...): bf16 halo-tile fast path on/off (A/B testing)
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDS_ROW = 40;               // bf16 per staged row: 32 + 8 pad (80 B stride: conflict-free ds_read_b128)
@@ -215,6 +219,212 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         Feat<T>::st1(y + off, v);
       }
     }
+}
+
+// =========================================================================================================
+// halo-tile kernel (bf16 fast path): the input patch of a 16x16 output tile (plus its tap halo) is staged in LDS ONCE per
+// 32-channel chunk and reused by every tap, so the A-side staging cost (global loads, style multiply, conversions,
+// ds_write) is amortised over up to 9 taps instead of being repeated per tap as in conv_igemm_kernel.  Per tap only the
+// 128 x 32 weight tile moves.  512 threads = 8 waves (4 x 2), each wave 64 x 64 outputs; one barrier per tap.
+// Same tap-table geometry as conv_igemm_kernel: forward stride 1/2 (IN_MUL), data gradient stride 1, 4-phase transposed conv.
+// =========================================================================================================
+constexpr int HT = 16;                        // tile edge: 16 x 16 = 256 output positions of ONE sample
+constexpr int HROW = 40;                      // bf16 per staged pixel row (32 channels + 8 pad = 80 B)
+
+struct HaloArgs {
+  const __bf16* x; const __bf16* w; __bf16* y;
+  const float* pre; const float* post; const float* bias; const __bf16* residual;
+  int B, Hin, Win, Cin, Hout, Wout, Cout, Hm, Wm, N, Kpad, kc_per_tap;
+  int out_mul, tiles_x, tiles_y;
+  float bias_scale, gain; int act;
+  TapTable taps[4];
+  int hy0[4], hx0[4], hh[4], hw[4];          // per phase: halo origin (min dy, min dx) and extent in input pixels
+  int halo_elems;                            // LDS elements reserved for the halo (max over phases)
+};
+
+template <int IN_MUL>
+__global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NI = IN_MUL == 1 ? 3 : 9;     // halo (pixel, 8-channel vector) items per thread: ceil(hh*hw*4 / 512)
+  __bf16* halo = (__bf16*)smem;
+  __bf16* Bt = halo + a.halo_elems;           // 2 x [128][HROW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int phase = blockIdx.z, n0 = blockIdx.y * BN;
+  const int tile = blockIdx.x;
+  const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
+  const TapTable& tt = a.taps[phase];
+  const int hy0 = a.hy0[phase], hx0 = a.hx0[phase], hh = a.hh[phase], hw = a.hw[phase];
+  const int gy0 = ty * HT * IN_MUL + hy0, gx0 = tx * HT * IN_MUL + hx0;     // input pixel of halo (0,0)
+
+  // ---- halo items of this thread (fixed for the whole K loop; only the channel chunk moves) -------------------------
+  const int hvec = tid & 3;
+  int goff[NI], loff[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int hp = (tid >> 2) + k * 128;
+    loff[k] = -1; goff[k] = -1;
+    if (hp < hh * hw) {
+      const int hy = hp / hw, hx = hp - hy * hw;
+      const int gy = gy0 + hy, gx = gx0 + hx;
+      loff[k] = hp * HROW + hvec * 8;
+      if ((unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win) goff[k] = ((b * a.Hin + gy) * a.Win + gx) * a.Cin + hvec * 8;
+    }
+  }
+  bf16x8 hreg[NI];
+  auto halo_load = [&](int c0) {
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const bool ok = goff[k] >= 0 && c0 + hvec * 8 < a.Cin;
+      hreg[k] = ok ? *(const bf16x8*)(a.x + (size_t)goff[k] + c0) : zero_bf16x8();
+    }
+    if (a.pre) {
+      const float* ps = a.pre + (size_t)b * a.Cin + c0 + hvec * 8;
+      float sc[8];
+      if (c0 + hvec * 8 < a.Cin) {
+        const f32x4 p0 = *(const f32x4*)ps, p1 = *(const f32x4*)(ps + 4);
+        sc[0] = p0[0]; sc[1] = p0[1]; sc[2] = p0[2]; sc[3] = p0[3]; sc[4] = p1[0]; sc[5] = p1[1]; sc[6] = p1[2]; sc[7] = p1[3];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sc[j] = 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < NI; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hreg[k][j] = (__bf16)((float)hreg[k][j] * sc[j]);
+    }
+  };
+  auto halo_store = [&]() {
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (loff[k] >= 0) *(bf16x8*)(halo + loff[k]) = hreg[k];
+  };
+
+  // ---- weight tile: 128 rows x 4 vectors = 512 items, one per thread ---------------------------------------------------
+  const int brow = tid >> 2;
+  bf16x8 breg;
+  auto b_load = [&](int q) {                  // q = chunk * ntaps + tap
+    const int c = q / tt.n, t = q - c * tt.n;
+    const int n = n0 + brow;
+    breg = (n < a.N) ? *(const bf16x8*)(a.w + ((size_t)tt.wt[t] * a.N + n) * a.Kpad + c * BK + hvec * 8) : zero_bf16x8();
+  };
+  auto b_store = [&](int buf) { *(bf16x8*)(Bt + buf * TILE + brow * HROW + hvec * 8) = breg; };
+
+  // ---- per-lane fragment bases ---------------------------------------------------------------------------------------
+  int abase[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int r = wm * 64 + mi * 32 + (lane & 31);
+    abase[mi] = (((r >> 4) * IN_MUL) * hw + (r & 15) * IN_MUL) * HROW + (lane >> 5) * 8;
+  }
+  const int bbase = (wn * 64 + (lane & 31)) * HROW + (lane >> 5) * 8;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int ntaps = tt.n, nchunks = a.kc_per_tap, total = ntaps * nchunks;
+  halo_load(0);
+  halo_store();
+  b_load(0);
+  b_store(0);
+  __syncthreads();
+  int q = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    if (c + 1 < nchunks) halo_load((c + 1) * BK);                  // in flight during the taps of chunk c
+    for (int t = 0; t < ntaps; ++t, ++q) {
+      const int cur = q & 1;
+      if (q + 1 < total) b_load(q + 1);
+      const int toff = ((tt.dy[t] - hy0) * hw + (tt.dx[t] - hx0)) * HROW;
+      const __bf16* Bc = Bt + cur * TILE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[2], bf[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) af[mi] = *(const bf16x8*)(halo + abase[mi] + toff + ks * 16);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) bf[ni] = *(const bf16x8*)(Bc + bbase + ni * 32 * HROW + ks * 16);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+      }
+      if (t == ntaps - 1 && c + 1 < nchunks) {
+        __syncthreads();                                           // every wave is done reading this chunk's halo
+        halo_store();
+      }
+      if (q + 1 < total) b_store(cur ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue ----------------------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
+      const bool nalloc = n < a.Cout, nlog = n < a.N;
+      const float bv = (a.bias && nlog) ? a.bias[n] * a.bias_scale : 0.f;
+      const float pv = (a.post && nalloc) ? a.post[(size_t)b * a.Cout + n] : 1.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int py = ty * HT + (row >> 4), px = tx * HT + (row & 15);
+        if (py >= a.Hm || px >= a.Wm || !nalloc) continue;
+        const int oy = py * a.out_mul + (phase >> 1), ox = px * a.out_mul + (phase & 1);
+        float v = acc[mi][ni][r] * pv + bv;
+        v = (a.act == ACT_LRELU ? (v > 0.f ? v : v * LRELU_SLOPE) : v) * a.gain;
+        const size_t off = ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n;
+        if (a.residual) v += (float)a.residual[off];
+        a.y[off] = (__bf16)v;
+      }
+    }
+}
+
+// host side: returns true when the halo kernel was launched for this geometry
+bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
+  if (c.Hm < HT || c.Wm < HT || c.act == ACT_TANH) return false;
+  if ((long long)c.B * c.Hin * c.Win * c.Cin >= (1ll << 31) || (long long)c.B * c.Hout * c.Wout * c.Cout >= (1ll << 31)) return false;
+  HaloArgs a = {};
+  a.x = (const __bf16*)c.x; a.w = c.w; a.y = (__bf16*)c.y; a.pre = c.pre; a.post = c.post; a.bias = c.bias;
+  a.residual = (const __bf16*)c.residual;
+  a.B = c.B; a.Hin = c.Hin; a.Win = c.Win; a.Cin = c.Cin; a.Hout = c.Hout; a.Wout = c.Wout; a.Cout = c.Cout;
+  a.Hm = c.Hm; a.Wm = c.Wm; a.N = c.N; a.Kpad = c.Kpad; a.kc_per_tap = c.kc_per_tap; a.out_mul = c.out_mul;
+  a.tiles_x = cdiv(c.Wm, HT); a.tiles_y = cdiv(c.Hm, HT);
+  a.bias_scale = c.bias_scale; a.gain = c.gain; a.act = c.act;
+  int max_halo = 0;
+  for (int p = 0; p < nphase; ++p) {
+    a.taps[p] = c.taps[p];
+    int ymin = 99, ymax = -99, xmin = 99, xmax = -99;
+    for (int t = 0; t < c.taps[p].n; ++t) {
+      ymin = std::min(ymin, c.taps[p].dy[t]); ymax = std::max(ymax, c.taps[p].dy[t]);
+      xmin = std::min(xmin, c.taps[p].dx[t]); xmax = std::max(xmax, c.taps[p].dx[t]);
+    }
+    a.hy0[p] = ymin; a.hx0[p] = xmin;
+    a.hh[p] = (HT - 1) * in_mul + (ymax - ymin) + 1; a.hw[p] = (HT - 1) * in_mul + (xmax - xmin) + 1;
+    max_halo = std::max(max_halo, a.hh[p] * a.hw[p]);
+  }
+  if (max_halo * 4 > (in_mul == 1 ? 3 : 9) * 512) return false;
+  a.halo_elems = max_halo * HROW;
+  const size_t smem = ((size_t)a.halo_elems + 2 * TILE) * sizeof(__bf16);
+  dim3 grid(c.B * a.tiles_x * a.tiles_y, cdiv(c.Cout, BN), nphase);
+  if (in_mul == 1) {
+    static bool set1 = false;
+    if (!set1) { hipFuncSetAttribute((const void*)conv_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set1 = true; }
+    hipLaunchKernelGGL(conv_halo_kernel<1>, grid, dim3(512), smem, s, a);
+  } else {
+    static bool set2 = false;
+    if (!set2) { hipFuncSetAttribute((const void*)conv_halo_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set2 = true; }
+    hipLaunchKernelGGL(conv_halo_kernel<2>, grid, dim3(512), smem, s, a);
+  }
+  return true;
 }
 
 // =========================================================================================================
@@ -437,6 +647,7 @@ int launch_igemm(const ConvArgs& a, int nphase, hipStream_t s) {
 }
 
 int dispatch_igemm(const ConvArgs& a, int nphase, int dtype, hipStream_t s) {
+  if (dtype == DT_BF16 && g_use_halo && try_launch_halo(a, nphase, a.in_mul, s)) return launch_status();
   if (dtype == DT_BF16) return launch_igemm<__bf16, 1>(a, nphase, s);
   if (dtype == DT_F32) return launch_igemm<float, 3>(a, nphase, s);
   return LCGAN_EINVAL;
@@ -448,6 +659,12 @@ int dispatch_igemm(const ConvArgs& a, int nphase, int dtype, hipStream_t s) {
 // C ABI (declared in include/lcgan_hip.h)
 // =========================================================================================================
 extern "C" {
+
+// option 0: use the halo-tile conv kernel for bf16 (1 = default) ; returns the previous value
+int lcgan_set_option(int option, int value) {
+  if (option == 0) { const int old = g_use_halo; g_use_halo = value; return old; }
+  return LCGAN_EINVAL;
+}
 
 int lcgan_conv_weight_prep(const float* w, int A, int Bc, int k, float scale, int transpose,
                            void* wp, int parts, float* wsq, void* stream) {

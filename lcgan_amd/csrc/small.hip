@@ -10,59 +10,91 @@
 //   ema           Ema.update                                          ema.py:19-32
 //   avg_latent    truncation-trick running mean                       cnn.py:95-97
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
 constexpr int TPB = 256;
 constexpr int MT = 32;     // rows of the small-M GEMMs handled per block
 
-// y[m,o] = act(scale * sum_i x[m,i] w[o,i] + bias[o]*bias_scale) * gain     one wave per output column o
+// y[m,o] = act(scale * sum_i x[m,i] w[o,i] + bias[o]*bias_scale) * gain
+// Block = 8 output columns x 32 rows of x.  The x tile is staged TRANSPOSED in LDS ([i][m], padded) so the inner loop is
+// one broadcast weight load (16 B per 4 i) + one conflict-free LDS read per FMA; weights (the big operand) are read once.
+constexpr int LIN_IC = 512;                 // i-chunk staged per pass (512 x 33 floats = 66 KB)
 __global__ __launch_bounds__(TPB) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           int M, int I, int O, float scale, float bias_scale, int act, float gain) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int o = blockIdx.x * 4 + wid, m0 = blockIdx.y * MT;
-  if (o >= O) return;
-  const int mc = min(MT, M - m0);
-  float acc[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) acc[m] = 0.f;
-  const float* wr = w + (size_t)o * I;
-  for (int i = lane; i < I; i += 64) {
-    const float wv = wr[i];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-      if (m < mc) acc[m] += x[(size_t)(m0 + m) * I + i] * wv;
-  }
-  const float bv = bias ? bias[o] * bias_scale : 0.f;
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    if (m < mc) {
-      const float t = wave_sum(acc[m]);
-      if (lane == 0) y[(size_t)(m0 + m) * O + o] = act_fwd(t * scale + bv, act) * gain;
+  extern __shared__ float xs[];              // [LIN_IC][33]
+  const int m = threadIdx.x & 31, ol = threadIdx.x >> 5;
+  const int o = blockIdx.x * 8 + ol, m0 = blockIdx.y * MT;
+  const int mrow = m0 + m;
+  const bool ovalid = o < O;
+  const float* wr = w + (size_t)(ovalid ? o : 0) * I;
+  float acc = 0.f;
+  for (int i0 = 0; i0 < I; i0 += LIN_IC) {
+    const int ic = min(LIN_IC, I - i0);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < MT * ic; idx += TPB) {          // coalesced along i, transposed into LDS
+      const int mm = idx / ic, ii = idx - mm * ic;
+      xs[ii * 33 + mm] = (m0 + mm < M) ? x[(size_t)(m0 + mm) * I + i0 + ii] : 0.f;
     }
+    __syncthreads();
+    if (ovalid) {
+      int ii = 0;
+      if (((I | i0) & 3) == 0) {
+        for (; ii + 4 <= ic; ii += 4) {
+          const f32x4 wv = *(const f32x4*)(wr + i0 + ii);
+          acc += wv[0] * xs[ii * 33 + m] + wv[1] * xs[(ii + 1) * 33 + m] + wv[2] * xs[(ii + 2) * 33 + m] + wv[3] * xs[(ii + 3) * 33 + m];
+        }
+      }
+      for (; ii < ic; ++ii) acc += wr[i0 + ii] * xs[ii * 33 + m];
+    }
+  }
+  if (ovalid && mrow < M) {
+    const float bv = bias ? bias[o] * bias_scale : 0.f;
+    y[(size_t)mrow * O + o] = act_fwd(acc * scale + bv, act) * gain;
   }
 }
 
-// gx[m,i] += scale * sum_{o in chunk} gy[m,o] w[o,i]         (gx zeroed by the caller; fp32 atomics across O chunks)
+// gx[m,i] = scale * sum_o gy[m,o] w[o,i]
+// Block = 64 columns i x 32 rows m (4 waves x 8 rows each).  gy is staged transposed in LDS ([o][m]) so each weight element
+// (coalesced along i) meets 8 broadcast LDS values; no atomics, gx is written once.
+constexpr int LIN_OC = 512;                 // o-chunk staged per pass (512 x 32 floats = 64 KB)
 __global__ __launch_bounds__(TPB) void linear_bwd_data_kernel(const float* __restrict__ gy, const float* __restrict__ w,
-                                                               float* __restrict__ gx, int M, int I, int O, float scale, int ochunk) {
-  const int i = blockIdx.x * TPB + threadIdx.x, m0 = blockIdx.y * MT;
-  const int o0 = blockIdx.z * ochunk, o1 = min(o0 + ochunk, O);
-  if (i >= I) return;
-  const int mc = min(MT, M - m0);
-  float acc[MT];
+                                                               float* __restrict__ gx, int M, int I, int O, float scale) {
+  extern __shared__ float gs[];              // [LIN_OC][32]
+  const int il = threadIdx.x & 63, mg = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + il, m0 = blockIdx.y * MT;
+  const bool ivalid = i < I;
+  float acc[8];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) acc[m] = 0.f;
-  for (int o = o0; o < o1; ++o) {
-    const float wv = w[(size_t)o * I + i];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-      if (m < mc) acc[m] += gy[(size_t)(m0 + m) * O + o] * wv;
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int o0 = 0; o0 < O; o0 += LIN_OC) {
+    const int oc = min(LIN_OC, O - o0);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < oc * MT; idx += TPB) {           // lanes walk m: conflict-free LDS writes
+      const int oo = idx >> 5, mm = idx & 31;
+      gs[idx] = (m0 + mm < M) ? gy[(size_t)(m0 + mm) * O + o0 + oo] : 0.f;
+    }
+    __syncthreads();
+    if (ivalid) {
+      const float* wc = w + (size_t)o0 * I + i;
+#pragma unroll 4
+      for (int oo = 0; oo < oc; ++oo) {
+        const float wv = wc[(size_t)oo * I];
+        const f32x4 g0 = *(const f32x4*)(gs + oo * 32 + mg * 8), g1 = *(const f32x4*)(gs + oo * 32 + mg * 8 + 4);
+        acc[0] += g0[0] * wv; acc[1] += g0[1] * wv; acc[2] += g0[2] * wv; acc[3] += g0[3] * wv;
+        acc[4] += g1[0] * wv; acc[5] += g1[1] * wv; acc[6] += g1[2] * wv; acc[7] += g1[3] * wv;
+      }
+    }
   }
+  if (ivalid) {
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
-    if (m < mc) atomicAdd(gx + (size_t)(m0 + m) * I + i, acc[m] * scale);
+    for (int j = 0; j < 8; ++j) {
+      const int mrow = m0 + mg * 8 + j;
+      if (mrow < M) gx[(size_t)mrow * I + i] = acc[j] * scale;
+    }
+  }
 }
 
 // gw[o,i] = scale * sum_m gy[m,o] x[m,i]
@@ -272,16 +304,20 @@ int lcgan_linear_fwd(const float* x, const float* w, const float* bias, float* y
   hipStream_t s = (hipStream_t)stream;
   if (M <= 0) return LCGAN_EINVAL;
   ProfScope p(KID_LINEAR, 2.0 * M * I * O, 4.0 * I * O, s);
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3(cdiv(O, 4), cdiv(M, MT)), dim3(TPB), 0, s, x, w, bias, y, M, I, O, scale, bias_scale, act, gain);
+  const size_t smem = (size_t)std::min(LIN_IC, I) * 33 * sizeof(float);
+  static bool set = false;
+  if (!set) { hipFuncSetAttribute((const void*)linear_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LIN_IC * 33 * 4); set = true; }
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(cdiv(O, 8), cdiv(M, MT)), dim3(TPB), smem, s, x, w, bias, y, M, I, O, scale, bias_scale, act, gain);
   return launch_status();
 }
-// gx must be zeroed by the caller
 int lcgan_linear_bwd_data(const float* gy, const float* w, float* gx, int M, int I, int O, float scale, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (M <= 0) return LCGAN_EINVAL;
-  const int ochunk = 64;
   ProfScope p(KID_LINEAR, 2.0 * M * I * O, 4.0 * I * O, s);
-  hipLaunchKernelGGL(linear_bwd_data_kernel, dim3(cdiv(I, TPB), cdiv(M, MT), cdiv(O, ochunk)), dim3(TPB), 0, s, gy, w, gx, M, I, O, scale, ochunk);
+  const size_t smem = (size_t)std::min(LIN_OC, O) * 32 * sizeof(float);
+  static bool set = false;
+  if (!set) { hipFuncSetAttribute((const void*)linear_bwd_data_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LIN_OC * 32 * 4); set = true; }
+  hipLaunchKernelGGL(linear_bwd_data_kernel, dim3(cdiv(I, 64), cdiv(M, MT)), dim3(TPB), smem, s, gy, w, gx, M, I, O, scale);
   return launch_status();
 }
 int lcgan_linear_wgrad(const float* gy, const float* x, float* gw, int M, int I, int O, float scale, void* stream) {

@@ -283,7 +283,7 @@ class HipKernels:
         self._chk(gy, w)
         M, O = gy.shape
         I = w.shape[1]
-        gx = torch.zeros((M, I), dtype=torch.float32, device=gy.device)
+        gx = torch.empty((M, I), dtype=torch.float32, device=gy.device)
         self._call("lcgan_linear_bwd_data", gy.data_ptr(), w.data_ptr(), gx.data_ptr(), M, I, O, float(scale), self._stream())
         return gx
 

@@ -67,6 +67,11 @@ CONV_CASES = [
     (2, 8, 8, 128, 256, 1, 1),
     (4, 4, 4, 513, 512, 3, 1),       # discriminator epilogue conv (513 -> padded 520 / 544)
     (1, 64, 64, 128, 128, 3, 1),     # several M tiles per sample
+    # shapes that take the bf16 halo-tile kernel (M grid >= 16 x 16): stride 2, ragged tiles, 1x1, padded channels
+    (2, 32, 32, 64, 96, 3, 2),
+    (1, 20, 40, 40, 24, 3, 1),
+    (2, 32, 32, 128, 256, 1, 1),
+    (2, 64, 32, 72, 136, 3, 2),
 ]
 
 
@@ -95,7 +100,8 @@ def test_conv_fwd(H, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("case", CONV_CASES + [(2, 8, 8, 64, 2, 3, 2), (2, 16, 16, 2, 64, 3, 1)])
+@pytest.mark.parametrize("case", CONV_CASES + [(2, 8, 8, 64, 2, 3, 2), (2, 16, 16, 2, 64, 3, 1), (2, 32, 32, 64, 2, 3, 2),
+                                  (1, 64, 64, 2, 64, 3, 1), (1, 48, 40, 32, 48, 3, 2)])
 def test_conv_bwd_data(H, dtype, case):
     B, Hh, W, Ci, Co, k, stride = case          # g has Co channels on the (Hh/stride) grid; output has Ci channels
     if stride == 2 and k != 3:
