@@ -581,6 +581,161 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 }
 
 // =========================================================================================================
+// weight gradient, bf16 fast path for 3x3 kernels: one workgroup owns a whole kernel ROW (ky; kx = 0,1,2).
+// A reduction chunk is a 32-position row segment of the output-side grid, so
+//   * the output-gradient tile G [32 pos][128 a] is staged once for 3 taps,
+//   * the three shifted input windows come from ONE halo row segment X [(32*STRIDE + 2) px][128 c] in LDS (tap kx reads
+//     rows p*STRIDE + kx through the transposed LDS read),
+//   * (sample, row, segment) decoding is scalar, and chunks whose input row is padding are skipped.
+// =========================================================================================================
+template <int STRIDE>
+__device__ __forceinline__ bf16x8 tr_frag_rows(const __bf16* tile, int row_a, int row_b, int col) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + row_a * WG_ROW + col));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + row_b * WG_ROW + col));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int STRIDE>
+__global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int XR = 32 * STRIDE + 2;                       // halo pixels per segment
+  constexpr int NX = (XR * 16 + 511) / 512;                  // X items (pixel, vec) per thread (512 threads)
+  constexpr int STAGE = (32 + XR) * WG_ROW;                  // elements per stage: G then X
+  __bf16* lds = (__bf16*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3;                    // 8 waves: 2 (a) x 4 (c), wave tile 64 x 32
+  const int a0 = blockIdx.x * 128, c0 = blockIdx.y * 128;
+  const int ky = blockIdx.z / a.nsplit, split = blockIdx.z - ky * a.nsplit;
+  const int segs = a.Wm >> 5;
+  const int q_begin = split * a.chunks_per_split;
+  const int q_end = min(q_begin + a.chunks_per_split, a.nchunks);
+  if (q_begin >= q_end) return;
+  const __bf16* __restrict__ x = (const __bf16*)a.x;
+  const __bf16* __restrict__ g = (const __bf16*)a.g;
+  const int lpos = tid >> 4, lvec = tid & 15;
+  const bool ga_ok = a0 + lvec * 8 < a.Cg, xc_ok = c0 + lvec * 8 < a.Cx;
+
+  bf16x8 rg, rx[NX];
+  bool live = false;                                         // does the chunk in the registers carry any data?
+
+  auto decode = [&](int q, int& b, int& row, int& j0) {
+    const int seg = q % segs, t = q / segs;
+    row = t % a.Hm; b = t / a.Hm; j0 = seg << 5;
+  };
+  auto gload = [&](int q) -> bool {
+    int b, row, j0;
+    decode(q, b, row, j0);
+    const int yy = row * STRIDE + ky - 1;
+    if ((unsigned)yy >= (unsigned)a.Hx) return false;        // this kernel row only meets padding here: contributes nothing
+    float sg[8], sx[8];
+    if (a.pre_g) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sg[j] = ga_ok ? a.pre_g[(size_t)b * a.Cg + a0 + lvec * 8 + j] : 0.f;
+    }
+    if (a.pre_x) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sx[j] = xc_ok ? a.pre_x[(size_t)b * a.Cx + c0 + lvec * 8 + j] : 0.f;
+    }
+    const size_t gbase = ((size_t)(b * a.Hm + row) * a.Wm + j0) * a.Cg + a0 + lvec * 8;
+    rg = ga_ok ? *(const bf16x8*)(g + gbase + (size_t)lpos * a.Cg) : zero_bf16x8();
+    if (a.pre_g) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rg[j] = (__bf16)((float)rg[j] * sg[j]);
+    }
+    const int xx0 = j0 * STRIDE - 1;
+    const size_t xrow = (size_t)(b * a.Hx + yy) * a.Wx;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int r = lpos + 32 * k;                           // halo pixel index (tid>>4 + 32k)
+      const int xx = xx0 + r;
+      const bool ok = r < XR && xc_ok && (unsigned)xx < (unsigned)a.Wx;
+      rx[k] = ok ? *(const bf16x8*)(x + (xrow + xx) * a.Cx + c0 + lvec * 8) : zero_bf16x8();
+      if (a.pre_x) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rx[k][j] = (__bf16)((float)rx[k][j] * sx[j]);
+      }
+    }
+    return true;
+  };
+  auto sstore = [&](int buf) {
+    __bf16* G = lds + buf * STAGE;
+    __bf16* X = G + 32 * WG_ROW;
+    *(bf16x8*)(G + lpos * WG_ROW + lvec * 8) = rg;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int r = lpos + 32 * k;
+      if (r < XR) *(bf16x8*)(X + r * WG_ROW + lvec * 8) = rx[k];
+    }
+  };
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.f;
+
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int trow = 8 * (g16 >> 1) + (i16 >> 2);
+  const int tcol = 16 * (g16 & 1) + 4 * (i16 & 3);
+
+  auto compute = [&](int buf) {
+    const __bf16* G = lds + buf * STAGE;
+    const __bf16* X = G + 32 * WG_ROW;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int p = ks * 16 + trow;                          // position (within the segment) of this lane's first row block
+      bf16x8 af[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) af[mi] = tr_frag_rows<1>(G, p, p + 4, wm * 64 + mi * 32 + tcol);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const bf16x8 bf = tr_frag_rows<STRIDE>(X, p * STRIDE + kx, (p + 4) * STRIDE + kx, wn * 32 + tcol);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[kx][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf, acc[kx][mi], 0, 0, 0);
+      }
+    }
+  };
+
+  // software pipeline over the chunks that carry data
+  int q = q_begin;
+  while (q < q_end && !gload(q)) ++q;
+  if (q < q_end) {
+    sstore(0);
+    __syncthreads();
+    int cur = 0;
+    while (true) {
+      int qn = q + 1;
+      bool have_next = false;
+      while (qn < q_end) { if (gload(qn)) { have_next = true; break; } ++qn; }
+      compute(cur);
+      if (!have_next) break;
+      sstore(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+      q = qn;
+    }
+  }
+
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int cc = c0 + wn * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int aa = a0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (aa < a.A && cc < a.Bc) atomicAdd(a.gwp + ((size_t)(ky * 3 + kx) * a.A + aa) * a.Bc + cc, acc[kx][mi][r]);
+      }
+    }
+}
+
+// =========================================================================================================
 // weight layout kernels
 // =========================================================================================================
 // w [A][Bc][kk] fp32 (reference layout, custom_layers.py:32,55)  ->  wp [parts][kk][N][Kpad] bf16 split, scaled.
@@ -794,7 +949,25 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
   a.nsplit = cdiv(a.nchunks, a.chunks_per_split);
   dim3 grid(cdiv(A, 128), cdiv(Bc, 128), k * k * a.nsplit);
   ProfScope p(KID_CONV_WGRAD, 2.0 * M * A * Bc * k * k, 0, s);
-  if (dtype == DT_BF16) {
+  if (dtype == DT_BF16 && g_use_halo && k == 3 && (Wg & 31) == 0 &&
+      (long long)B * Hx * Wx * Cx < (1ll << 31) && (long long)B * Hg * Wg * Cg < (1ll << 31)) {
+    // row-segment kernel: chunk = (sample, row, 32-position segment); grid.z = kernel row x split
+    a.nchunks = B * Hg * (Wg >> 5);
+    const int tiles3 = cdiv(A, 128) * cdiv(Bc, 128) * 3;
+    int ns = (1536 + tiles3 - 1) / tiles3;
+    ns = max(1, min(ns, a.nchunks / 8 > 0 ? a.nchunks / 8 : 1));
+    a.chunks_per_split = cdiv(a.nchunks, ns);
+    a.nsplit = cdiv(a.nchunks, a.chunks_per_split);
+    dim3 grid3(cdiv(A, 128), cdiv(Bc, 128), 3 * a.nsplit);
+    const size_t smem3 = 2 * (size_t)(32 + 32 * stride + 2) * WG_ROW * sizeof(__bf16);
+    if (stride == 1) {
+      hipLaunchKernelGGL((conv_wgrad3_kernel<1>), grid3, dim3(512), smem3, s, a);
+    } else {
+      static bool set = false;
+      if (!set) { hipFuncSetAttribute((const void*)conv_wgrad3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3); set = true; }
+      hipLaunchKernelGGL((conv_wgrad3_kernel<2>), grid3, dim3(512), smem3, s, a);
+    }
+  } else if (dtype == DT_BF16) {
     const size_t smem = 2 * 2 * WG_TILE * sizeof(__bf16);
     hipLaunchKernelGGL((conv_wgrad_kernel<__bf16, 1>), grid, dim3(256), smem, s, a);
   } else if (dtype == DT_F32) {

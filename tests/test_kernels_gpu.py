@@ -121,7 +121,10 @@ def test_conv_bwd_data(H, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("case", CONV_CASES + [(2, 16, 16, 64, 2, 3, 2)])
+@pytest.mark.parametrize("case", CONV_CASES + [(2, 16, 16, 64, 2, 3, 2),
+                                  # row-segment bf16 kernel (k = 3, output-side width a multiple of 32)
+                                  (1, 64, 64, 128, 256, 3, 2), (1, 32, 64, 72, 40, 3, 1), (2, 32, 64, 64, 2, 3, 2),
+                                  (2, 32, 32, 256, 128, 3, 1)])
 def test_conv_wgrad(H, dtype, case):
     B, Hh, W, Ci, Co, k, stride = case
     x = feat((B, Hh, W, ceil8(Ci)), dtype, 21, Ci)
