@@ -19,6 +19,89 @@ from .ema import Ema
 from .optim import Adam, DataParallel
 
 
+class LazyLoss(float):
+    """What train_generator / train_discriminator return: a float whose value is fetched from the device ON DEMAND.
+    The reference calls `.item()` right after the optimiser step (worker.py:177, 214), which drains the GPU queue twice per
+    iteration; here the scalar is copied asynchronously into pinned memory and `float()` / formatting waits for that copy only
+    when somebody looks (log lines every print_interval).  Behaves as a float in arithmetic and formatting."""
+
+    def __new__(cls, tensor):
+        obj = super().__new__(cls, float("nan"))
+        if tensor.is_cuda:
+            obj._host = torch.empty((), dtype=torch.float32, pin_memory=True)
+            obj._host.copy_(tensor.detach(), non_blocking=True)
+            obj._event = torch.cuda.Event()
+            obj._event.record()
+        else:
+            obj._host, obj._event = tensor.detach().float().clone(), None
+        return obj
+
+    def _value(self):
+        if self._event is not None:
+            self._event.synchronize()
+        return float(self._host)
+
+    def __float__(self):
+        return self._value()
+
+    def item(self):
+        return self._value()
+
+    def __format__(self, spec):
+        return format(self._value(), spec)
+
+    def __repr__(self):
+        return repr(self._value())
+
+    __str__ = __repr__
+
+    def __eq__(self, o):
+        return self._value() == float(o)
+
+    def __ne__(self, o):
+        return self._value() != float(o)
+
+    def __hash__(self):
+        return hash(self._value())
+
+    def __lt__(self, o):
+        return self._value() < float(o)
+
+    def __gt__(self, o):
+        return self._value() > float(o)
+
+    def __le__(self, o):
+        return self._value() <= float(o)
+
+    def __ge__(self, o):
+        return self._value() >= float(o)
+
+    def __abs__(self):
+        return abs(self._value())
+
+    def __add__(self, o):
+        return self._value() + float(o)
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return self._value() - float(o)
+
+    def __rsub__(self, o):
+        return float(o) - self._value()
+
+    def __mul__(self, o):
+        return self._value() * float(o)
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, o):
+        return self._value() / float(o)
+
+    def __rtruediv__(self, o):
+        return float(o) / self._value()
+
+
 class SyntheticTriples:
     """Endless (image, geometry_change, appearance_change) batches, uniform in [-1, 1], fp32, resident on the device."""
 
@@ -116,7 +199,7 @@ class WORKER(object):
         d_loss.backward()
         self.discriminator.sync_gradients()
         self.d_optimizer.step()
-        return d_loss.item()
+        return LazyLoss(d_loss)
 
     # ---- G step (worker.py:179-214) -----------------------------------------------------------------------------------
     def train_generator(self, epoch):
@@ -146,7 +229,7 @@ class WORKER(object):
         g_loss.backward()
         self.generator.sync_gradients()
         self.g_optimizer.step()
-        return g_loss.item()
+        return LazyLoss(g_loss)
 
     def ema_update(self, current_step):
         self.ema.update(current_step)

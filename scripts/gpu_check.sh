@@ -20,7 +20,7 @@ for s in "$@"; do
     smoke)   step smoke 300 python __graft_entry__.py --smoke ;;
     bench)   step bench 600 python bench.py --steps 5 --warmup 2 ;;
     benchq)  step benchq 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
-    prof)    cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+    prof)    export TMPDIR=/tmp
              step prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline ;;
   esac
 done

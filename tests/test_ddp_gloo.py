@@ -41,7 +41,7 @@ def _rank_main(rank, world, port, out_dir):
         real_step()
     w.d_optimizer.step = step
     loss_v = w.train_discriminator(1)                     # odd + R1: projection heads unused -> grad None
-    torch.save({"grads": captured, "params": {k: v.clone() for k, v in w.discriminator.module.state_dict().items()}, "loss": loss_v},
+    torch.save({"grads": captured, "params": {k: v.clone() for k, v in w.discriminator.module.state_dict().items()}, "loss": float(loss_v)},
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
