@@ -342,19 +342,21 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
       if (q + 1 < total) b_load(q + 1);
       const int toff = ((tt.dy[t] - hy0) * hw + (tt.dx[t] - hx0)) * HROW;
       const __bf16* Bc = Bt + cur * TILE;
+      bf16x8 af[2][2], bf[2][2];                                  // all 8 fragments of this tap first, then the 8 MFMAs
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 af[2], bf[2];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) af[mi] = *(const bf16x8*)(halo + abase[mi] + toff + ks * 16);
+        for (int mi = 0; mi < 2; ++mi) af[ks][mi] = *(const bf16x8*)(halo + abase[mi] + toff + ks * 16);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) bf[ni] = *(const bf16x8*)(Bc + bbase + ni * 32 * HROW + ks * 16);
+        for (int ni = 0; ni < 2; ++ni) bf[ks][ni] = *(const bf16x8*)(Bc + bbase + ni * 32 * HROW + ks * 16);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
-      }
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mi], bf[ks][ni], acc[mi][ni], 0, 0, 0);
       if (t == ntaps - 1 && c + 1 < nchunks) {
         __syncthreads();                                           // every wave is done reading this chunk's halo
         halo_store();
@@ -364,28 +366,54 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
     }
   }
 
-  // ---- epilogue ----------------------------------------------------------------------------------------------------------
+  // ---- epilogue: demod/bias/act in registers -> bf16 tile in LDS -> 16-byte coalesced stores (+ residual) ----------------
+  // (the main loop ended with a barrier, so the staging buffers are free)
+  constexpr int OROW = BN + 8;                                     // bf16 per output row in LDS (272 B: conflict-light)
+  __bf16* ot = (__bf16*)smem;                                      // [256][OROW]
+  if (a.residual) {                                                // stage the residual tile with coalesced 16-byte loads
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int idx = tid + k * 512;
+      const int row = idx >> 4, vv = idx & 15;
+      const int py = ty * HT + (row >> 4), px = tx * HT + (row & 15);
+      const int n = n0 + vv * 8;
+      bf16x8 rr = zero_bf16x8();
+      if (py < a.Hm && px < a.Wm && n < a.Cout) {
+        const int oy = py * a.out_mul + (phase >> 1), ox = px * a.out_mul + (phase & 1);
+        rr = *(const bf16x8*)(a.residual + ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n);
+      }
+      *(bf16x8*)(ot + row * OROW + vv * 8) = rr;
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-      const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
-      const bool nalloc = n < a.Cout, nlog = n < a.N;
+      const int nl = wn * 64 + ni * 32 + (lane & 31), n = n0 + nl;
+      const bool nlog = n < a.N;
       const float bv = (a.bias && nlog) ? a.bias[n] * a.bias_scale : 0.f;
-      const float pv = (a.post && nalloc) ? a.post[(size_t)b * a.Cout + n] : 1.f;
+      const float pv = (a.post && n < a.Cout) ? a.post[(size_t)b * a.Cout + n] : 1.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int py = ty * HT + (row >> 4), px = tx * HT + (row & 15);
-        if (py >= a.Hm || px >= a.Wm || !nalloc) continue;
-        const int oy = py * a.out_mul + (phase >> 1), ox = px * a.out_mul + (phase & 1);
         float v = acc[mi][ni][r] * pv + bv;
         v = (a.act == ACT_LRELU ? (v > 0.f ? v : v * LRELU_SLOPE) : v) * a.gain;
-        const size_t off = ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n;
-        if (a.residual) v += (float)a.residual[off];
-        a.y[off] = (__bf16)v;
+        if (a.residual) v += (float)ot[row * OROW + nl];           // same thread reads and rewrites this element: one rounding
+        ot[row * OROW + nl] = (__bf16)v;
       }
     }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int idx = tid + k * 512;                                 // 256 rows x 16 vectors
+    const int row = idx >> 4, vv = idx & 15;
+    const int py = ty * HT + (row >> 4), px = tx * HT + (row & 15);
+    const int n = n0 + vv * 8;
+    if (py >= a.Hm || px >= a.Wm || n >= a.Cout) continue;
+    const int oy = py * a.out_mul + (phase >> 1), ox = px * a.out_mul + (phase & 1);
+    *(bf16x8*)(a.y + ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n) = *(const bf16x8*)(ot + row * OROW + vv * 8);
+  }
 }
 
 // host side: returns true when the halo kernel was launched for this geometry
@@ -413,7 +441,7 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   }
   if (max_halo * 4 > (in_mul == 1 ? 3 : 9) * 512) return false;
   a.halo_elems = max_halo * HROW;
-  const size_t smem = ((size_t)a.halo_elems + 2 * TILE) * sizeof(__bf16);
+  const size_t smem = std::max(((size_t)a.halo_elems + 2 * TILE) * sizeof(__bf16), (size_t)256 * (BN + 8) * sizeof(__bf16));
   dim3 grid(c.B * a.tiles_x * a.tiles_y, cdiv(c.Cout, BN), nphase);
   if (in_mul == 1) {
     static bool set1 = false;

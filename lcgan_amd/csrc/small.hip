@@ -263,6 +263,65 @@ __global__ void avg_latent_kernel(const float* __restrict__ w, float* __restrict
   avg[d] = m + beta * (avg[d] - m);
 }
 
+// ---- Householder QR of an n x n matrix (n <= 64) in ONE workgroup, LAPACK convention (geqr2 + orgqr: R_jj = -sign(alpha)*norm),
+// i.e. what torch.qr / torch.linalg.qr(mode='reduced') return for the 64 x 64 basis of MappingNetwork (custom_layers.py:274-276).
+// Replaces ~200 rocSOLVER micro-launches per call.  One thread per column; matrix and Q live in LDS.
+constexpr int QR_MAX = 64;
+__global__ __launch_bounds__(QR_MAX) void qr_householder_kernel(const float* __restrict__ A, float* __restrict__ Q,
+                                                                 float* __restrict__ R, int n) {
+  __shared__ float a[QR_MAX][QR_MAX + 1];
+  __shared__ float q[QR_MAX][QR_MAX + 1];
+  __shared__ float tau[QR_MAX];
+  const int c = threadIdx.x;
+  for (int i = 0; i < n; ++i) {
+    if (c < n) { a[i][c] = A[i * n + c]; q[i][c] = (i == c) ? 1.f : 0.f; }
+  }
+  __syncthreads();
+  for (int j = 0; j < n; ++j) {
+    if (c == j) {                                           // dlarfg on column j, rows j..n-1
+      const float alpha = a[j][j];
+      float xn2 = 0.f;
+      for (int i = j + 1; i < n; ++i) xn2 += a[i][j] * a[i][j];
+      if (xn2 == 0.f) {
+        tau[j] = 0.f;
+      } else {
+        const float beta = -copysignf(sqrtf(alpha * alpha + xn2), alpha);
+        tau[j] = (beta - alpha) / beta;
+        const float sc = 1.f / (alpha - beta);
+        for (int i = j + 1; i < n; ++i) a[i][j] *= sc;      // v (v_j = 1 implicit)
+        a[j][j] = beta;
+      }
+    }
+    __syncthreads();
+    if (c > j && c < n) {                                   // A[j:, c] -= tau v (v^T A[j:, c])
+      const float t = tau[j];
+      float wv = a[j][c];
+      for (int i = j + 1; i < n; ++i) wv += a[i][j] * a[i][c];
+      wv *= t;
+      a[j][c] -= wv;
+      for (int i = j + 1; i < n; ++i) a[i][c] -= a[i][j] * wv;
+    }
+    __syncthreads();
+  }
+  for (int j = n - 1; j >= 0; --j) {                        // Q = H_0 ... H_{n-1} I  (dorg2r, backward accumulation)
+    if (c >= j && c < n) {
+      const float t = tau[j];
+      float wv = q[j][c];
+      for (int i = j + 1; i < n; ++i) wv += a[i][j] * q[i][c];
+      wv *= t;
+      q[j][c] -= wv;
+      for (int i = j + 1; i < n; ++i) q[i][c] -= a[i][j] * wv;
+    }
+    __syncthreads();
+  }
+  if (c < n) {
+    for (int i = 0; i < n; ++i) {
+      Q[i * n + c] = q[i][c];
+      R[i * n + c] = (i <= c) ? a[i][c] : 0.f;
+    }
+  }
+}
+
 // ---- multi-tensor kernels: one launch walks a device table of tensors in 64K-element chunks ----------------
 struct MTDesc { void* p0; void* p1; void* p2; void* p3; long long n; float f0; float f1; };
 constexpr int MT_CHUNK = 65536;
@@ -405,6 +464,14 @@ int lcgan_powsum_bwd(const float* x, long long n, int pw, float coef, const floa
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(KID_SMALL, 0, 8.0 * n, s);
   hipLaunchKernelGGL(powsum_bwd_kernel, dim3(cdiv(n, TPB)), dim3(TPB), 0, s, x, n, pw, coef, gout, g);
+  return launch_status();
+}
+// Q, R of the reduced QR of the row-major n x n matrix A (n <= 64), LAPACK Householder convention
+int lcgan_qr_householder(const float* A, float* Q, float* R, int n, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n < 1 || n > QR_MAX) return LCGAN_EINVAL;
+  ProfScope p(KID_SMALL, 0, 0, s);
+  hipLaunchKernelGGL(qr_householder_kernel, dim3(1), dim3(QR_MAX), 0, s, A, Q, R, n);
   return launch_status();
 }
 int lcgan_avg_latent(const float* w, float* avg, int B, int D, float beta, void* stream) {

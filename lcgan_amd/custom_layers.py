@@ -243,8 +243,10 @@ class DiscriminatorEpilogue(nn.Module):
 
 
 def _qr_q(matrix: torch.Tensor) -> torch.Tensor:
-    """Q of the reduced Householder QR (torch.qr(...)[0], custom_layers.py:274-276): a 64x64 library call on the
-    parameter matrix, O(microseconds) -- left to torch.linalg (hipSOLVER), as SURVEY.md section 7 plans."""
+    """Q of the reduced Householder QR (torch.qr(...)[0], custom_layers.py:274-276).  Matrices up to 64 x 64 (the reference's
+    noise dimensions) run in ONE HIP workgroup (rocSOLVER needs ~200 micro-launches for the same factorisation)."""
+    if matrix.shape[0] <= 64:
+        return ops.QrQFn.apply(matrix)
     return torch.linalg.qr(matrix, mode="reduced")[0]
 
 

@@ -383,6 +383,15 @@ class HipKernels:
         self._call("lcgan_powsum_bwd", x.data_ptr(), x.numel(), pw, float(coef), gout.data_ptr(), g.data_ptr(), self._stream())
         return g
 
+    def qr(self, A: Tensor) -> Tuple[Tensor, Tensor]:
+        """(Q, R) of the reduced Householder QR of a square matrix (n <= 64), LAPACK sign convention"""
+        self._chk(A)
+        n = A.shape[0]
+        assert A.shape == (n, n) and n <= 64 and A.dtype == torch.float32
+        Q, R = torch.empty_like(A), torch.empty_like(A)
+        self._call("lcgan_qr_householder", A.data_ptr(), Q.data_ptr(), R.data_ptr(), n, self._stream())
+        return Q, R
+
     def avg_latent(self, w: Tensor, avg: Tensor, beta: float) -> None:
         self._chk(w, avg)
         B, Dd = w.shape

@@ -482,6 +482,25 @@ class WarpFn(Function):
         return gx, gflow, None
 
 
+class QrQFn(Function):
+    """Q of the reduced Householder QR of a square matrix (torch.qr(.)[0], custom_layers.py:274-276) in one HIP workgroup.
+    Backward (Q only, A = QR square and invertible): with G = Q^T gQ,  gA = Q tril(G - G^T, -1) R^{-T}
+    (from Q^T dA R^{-1} = Q^T dQ + dR R^{-1}: antisymmetric + upper-triangular); a 64 x 64 triangular solve of torch glue."""
+
+    @staticmethod
+    def forward(ctx, A):
+        Q, R = _K().qr(A.contiguous())
+        ctx.save_for_backward(Q, R)
+        return Q
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gQ):
+        Q, R = ctx.saved_tensors
+        G = Q.t() @ gQ
+        return torch.linalg.solve_triangular(R.t(), Q @ torch.tril(G - G.t(), -1), upper=False, left=False)
+
+
 # =====================================================================================================
 # losses (first-order)
 # =====================================================================================================

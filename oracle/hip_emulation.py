@@ -318,6 +318,9 @@ class EmulatedKernels:
     def powsum_bwd(self, x, pw, coef, gout):
         return gout * coef * (torch.sign(x) if pw == 1 else 2 * x)
 
+    def qr(self, A):
+        return torch.linalg.qr(A, mode="reduced")
+
     def avg_latent(self, w, avg, beta):
         m = w.mean(0)
         avg.copy_(m + beta * (avg - m))

@@ -330,3 +330,14 @@ def test_losses(H):
     avg_ref, avg_got = avg.clone(), avg.clone().cuda()
     E.avg_latent(w, avg_ref, 0.998), H.avg_latent(w.cuda(), avg_got, 0.998)
     check(avg_got, avg_ref, f32, "avg latent")
+
+
+@pytest.mark.parametrize("n", [6, 33, 64])
+def test_qr_householder(H, n):
+    """One-workgroup Householder QR against LAPACK (torch.linalg.qr on the CPU), incl. the sign convention."""
+    A = torch.tanh(torch.randn(n, n, generator=torch.Generator().manual_seed(121)))
+    Qr, Rr = torch.linalg.qr(A, mode="reduced")
+    Qg, Rg = H.qr(A.cuda())
+    check(Qg, Qr, torch.float32, "Q")
+    check(Rg, Rr, torch.float32, "R")
+    assert (torch.sign(torch.diagonal(Rg.cpu())) == torch.sign(torch.diagonal(Rr))).all()

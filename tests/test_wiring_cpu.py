@@ -155,3 +155,15 @@ def test_product_has_no_cpu_fallback():
             ops.Box3Fn.apply(torch.zeros(1, 4, 4, 8))
     finally:
         KM.set_backend(EmulatedKernels())
+
+
+def test_qr_backward_formula_matches_torch():
+    """ops.QrQFn's hand-derived backward (gA = Q tril(G - G^T, -1) R^-T) against autograd through torch.linalg.qr."""
+    from lcgan_amd import ops
+    A = torch.tanh(seeded_tensor((24, 24), 5)).requires_grad_(True)
+    gQ = seeded_tensor((24, 24), 6)
+    (torch.linalg.qr(A, mode="reduced")[0] * gQ).sum().backward()
+    ref = A.grad.clone()
+    A.grad = None
+    (ops.QrQFn.apply(A) * gQ).sum().backward()
+    assert rel(A.grad, ref) <= 1e-4
