@@ -25,6 +25,7 @@
 namespace {
 
 int g_use_halo = 1;                       // lcgan_set_option(0, ...): bf16 halo-tile fast path on/off (A/B testing)
+int g_use_splitk = 1;                     // lcgan_set_option(1, ...): split-K for small-M convolutions
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDS_ROW = 40;               // bf16 per staged row: 32 + 8 pad (80 B stride: conflict-free ds_read_b128)
@@ -42,6 +43,7 @@ struct ConvArgs {
   int in_mul, out_mul;
   int pre_stride, post_stride;
   float bias_scale, gain; int act;
+  int nsplit; float* ws;                     // split-K: blockIdx.z = phase * nsplit + split; raw fp32 partials are atomically added to ws [M_out pixels][Cout]
   TapTable taps[4];
 };
 
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, phase = blockIdx.z;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, phase = blockIdx.z / a.nsplit, split = blockIdx.z - phase * a.nsplit;
   const TapTable& tt = a.taps[phase];
   const int HWm = a.Hm * a.Wm;
   const T* __restrict__ x = (const T*)a.x;
@@ -183,16 +185,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   };
 
   // ---- main loop: register-staged double buffering, one barrier per K chunk ---------------------------
-  const int nq = tt.n * a.kc_per_tap;
-  gload(0);
-  sstore(0);
+  const int nq_all = tt.n * a.kc_per_tap;
+  const int per = (nq_all + a.nsplit - 1) / a.nsplit;
+  const int q0 = split * per, nq = min(q0 + per, nq_all);
+  if (q0 < nq) {
+    gload(q0);
+    sstore(0);
+  }
   __syncthreads();
-  for (int q = 0; q < nq; ++q) {
-    const int cur = q & 1;
+  for (int q = q0; q < nq; ++q) {
+    const int cur = (q - q0) & 1;
     if (q + 1 < nq) gload(q + 1);
     compute(cur);
     if (q + 1 < nq) sstore(cur ^ 1);
     __syncthreads();
+  }
+
+  if (a.nsplit > 1) {                       // split-K: raw partial sums; lcgan finalize kernel applies the epilogue
+    if (q0 >= nq) return;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int ro = row_off[row];
+          if (ro >= 0 && n < a.Cout) atomicAdd(a.ws + (size_t)ro * a.Cout + n, acc[mi][ni][r]);
+        }
+      }
+    return;
   }
 
   // ---- epilogue: demod * acc + bias -> act * gain (+ residual) -----------------------------------------
@@ -815,6 +838,35 @@ __global__ void unprep_wgrad_kernel(const float* __restrict__ gwp, int A, int Bc
   }
 }
 
+// epilogue of a split-K convolution: y = act(post * ws + bias) * gain + residual   over [B*Hout*Wout][Cout]
+template <typename T>
+__global__ void conv_finalize_kernel(const float* __restrict__ ws, T* __restrict__ y, const float* __restrict__ post,
+                                     const float* __restrict__ bias, const T* __restrict__ residual,
+                                     long long npix, int pix_per_sample, int Cout, int N, float bias_scale, float gain, int act) {
+  const int nvec = Cout >> 3;
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= npix * nvec) return;
+  const int v = (int)(gid % nvec);
+  const long long pix = gid / nvec;
+  const int b = (int)(pix / pix_per_sample);
+  const size_t off = (size_t)pix * Cout + v * 8;
+  F8 s = Feat<float>::load(ws + off);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int n = v * 8 + j;
+    float t = s.v[j];
+    if (post) t *= post[(size_t)b * Cout + n];
+    if (bias && n < N) t += bias[n] * bias_scale;
+    s.v[j] = act_fwd(t, act) * gain;
+  }
+  if (residual) {
+    const F8 r = Feat<T>::load(residual + off);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s.v[j] += r.v[j];
+  }
+  Feat<T>::store(y + off, s);
+}
+
 template <typename T, int NS>
 int launch_igemm(const ConvArgs& a, int nphase, hipStream_t s) {
   constexpr int NT = 2 * NS;
@@ -824,13 +876,44 @@ int launch_igemm(const ConvArgs& a, int nphase, hipStream_t s) {
     hipFuncSetAttribute((const void*)conv_igemm_kernel<T, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  dim3 grid(cdiv(a.M, BM), cdiv(a.Cout, BN), nphase);
+  dim3 grid(cdiv(a.M, BM), cdiv(a.Cout, BN), nphase * a.nsplit);
   hipLaunchKernelGGL((conv_igemm_kernel<T, NS>), grid, dim3(256), smem, s, a);
+  if (a.nsplit > 1) {
+    const long long npix = (long long)a.B * a.Hout * a.Wout, nthr = npix * (a.Cout / 8);
+    hipLaunchKernelGGL((conv_finalize_kernel<T>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a.ws, (T*)a.y, a.post, a.bias,
+                       (const T*)a.residual, npix, a.Hout * a.Wout, a.Cout, a.N, a.bias_scale, a.gain, a.act);
+  }
   return launch_status();
 }
 
-int dispatch_igemm(const ConvArgs& a, int nphase, int dtype, hipStream_t s) {
+// Small-M layers (4x4 ... 16x16 grids) are weight-streaming bound and would occupy a handful of CUs: split the (tap, chunk)
+// loop over blockIdx.z so >= ~256 workgroups stream disjoint weight slices; partials meet in an fp32 workspace.
+float* g_splitk_ws = nullptr;
+size_t g_splitk_ws_bytes = 0;
+
+int dispatch_igemm(const ConvArgs& a_in, int nphase, int dtype, hipStream_t s) {
+  ConvArgs a = a_in;
+  a.nsplit = 1; a.ws = nullptr;
   if (dtype == DT_BF16 && g_use_halo && try_launch_halo(a, nphase, a.in_mul, s)) return launch_status();
+  const int wgs = cdiv(a.M, BM) * cdiv(a.Cout, BN) * nphase;
+  int nq_min = 1 << 30;
+  for (int p = 0; p < nphase; ++p) nq_min = std::min(nq_min, a.taps[p].n * a.kc_per_tap);
+  if (g_use_splitk && wgs < 128 && nq_min >= 8) {
+    int ns = std::min(nq_min / 4, (256 + wgs - 1) / wgs);
+    if (ns > 1) {
+      const size_t bytes = (size_t)a.B * a.Hout * a.Wout * a.Cout * sizeof(float);
+      if (bytes > g_splitk_ws_bytes) {
+        // grow-only scratch owned by the library (small layers only: <= a few MB); allocation happens outside any capture
+        if (g_splitk_ws) hipFree(g_splitk_ws);
+        g_splitk_ws_bytes = std::max(bytes, (size_t)8 << 20);
+        if (hipMalloc((void**)&g_splitk_ws, g_splitk_ws_bytes) != hipSuccess) { g_splitk_ws = nullptr; g_splitk_ws_bytes = 0; ns = 1; }
+      }
+      if (ns > 1) {
+        hipMemsetAsync(g_splitk_ws, 0, bytes, s);
+        a.nsplit = ns; a.ws = g_splitk_ws;
+      }
+    }
+  }
   if (dtype == DT_BF16) return launch_igemm<__bf16, 1>(a, nphase, s);
   if (dtype == DT_F32) return launch_igemm<float, 3>(a, nphase, s);
   return LCGAN_EINVAL;
@@ -846,6 +929,7 @@ extern "C" {
 // option 0: use the halo-tile conv kernel for bf16 (1 = default) ; returns the previous value
 int lcgan_set_option(int option, int value) {
   if (option == 0) { const int old = g_use_halo; g_use_halo = value; return old; }
+  if (option == 1) { const int old = g_use_splitk; g_use_splitk = value; return old; }
   return LCGAN_EINVAL;
 }
 

@@ -42,5 +42,7 @@ class Ema(object):
         if self._table is None:
             self._build()
         KM.K.multi_tensor(self._table, MT_EMA, decay)            # p_ema <- p + decay * (p_ema - p)   (ema.py:26-32)
+        from . import ops
+        ops.bump_weight_epoch()
         for b_ema, b in self._copy_buffers:
             b_ema.copy_(b)

@@ -31,6 +31,40 @@ def _need_lo(x: Tensor) -> bool:
     return x.dtype == torch.float32
 
 
+# ---- prepared-weight cache -------------------------------------------------------------------------------------------
+# A conv weight is used several times per iteration (D runs 2-3 forwards and as many backwards between two optimiser
+# steps); its bf16 GEMM-layout copy only changes when the parameter does.  Valid for (parameter object, torch version counter,
+# weight epoch); the epoch is bumped by everything that rewrites parameters through raw pointers (Adam / EMA kernels).
+# Only nn.Parameters are cached (identified by object identity, guarded by a weakref): temporaries such as the cotangents of
+# the double-backward, or parameters of a later-built module, may reuse a storage address.
+_weight_epoch = 0
+_prep_cache: dict = {}      # id(param) -> [weakref(param), version, epoch, {(scale, transpose, need_lo): (PreparedWeight, wsq)}]
+
+
+def bump_weight_epoch() -> None:
+    global _weight_epoch
+    _weight_epoch += 1
+
+
+def _prep(w: Tensor, scale: float, transpose: bool, need_lo: bool, want_wsq: bool = False):
+    import weakref
+    K = _K()
+    if not isinstance(w, torch.nn.Parameter):
+        return K.prep_weight(w, scale, transpose, need_lo, want_wsq)
+    ent = _prep_cache.get(id(w))
+    if ent is None or ent[0]() is not w or ent[1] != w._version or ent[2] != _weight_epoch:
+        if len(_prep_cache) > 4096:                       # parameters of dead modules: drop everything, it refills in one step
+            _prep_cache.clear()
+        ent = [weakref.ref(w), w._version, _weight_epoch, {}]
+        _prep_cache[id(w)] = ent
+    key = (float(scale), bool(transpose), bool(need_lo))
+    hit = ent[3].get(key)
+    if hit is None or (want_wsq and hit[1] is None):
+        hit = K.prep_weight(w, scale, transpose, need_lo, want_wsq or (hit is not None and hit[1] is not None))
+        ent[3][key] = hit
+    return hit
+
+
 # =====================================================================================================
 # double-differentiable convolution triple (EqualizedConv2d, custom_layers.py:28-44)
 # =====================================================================================================
@@ -43,7 +77,7 @@ class Conv2dFn(Function):
         assert act != ACT_NONE or gain == 1.0, "fold the gain of an act-free conv into wscale"
         K = _K()
         A = w.shape[0]
-        pw, _ = K.prep_weight(w, wscale, False, _need_lo(x))
+        pw, _ = _prep(w, wscale, False, _need_lo(x))
         y = K.conv_fwd(x, pw, A, k, stride, bias=bias, bias_scale=bias_scale, act=act, gain=gain, residual=residual)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.cfg = (k, stride, act, gain, wscale, bias_scale, bias is not None, residual is not None)
@@ -72,7 +106,7 @@ class ConvTransposeFn(Function):
     @staticmethod
     def forward(ctx, g, w, k, stride, wscale, cin_alloc):
         K = _K()
-        pw, _ = K.prep_weight(w, wscale, True, _need_lo(g))
+        pw, _ = _prep(w, wscale, True, _need_lo(g))
         gx = K.conv_bwd_data(g, pw, w.shape[1], k, stride)
         assert gx.shape[-1] == cin_alloc
         ctx.save_for_backward(g, w)
@@ -395,7 +429,7 @@ class ModConvFn(Function):
         O, Cin, k, _ = w.shape
         c_eq = 1.0 / math.sqrt(Cin * k * k)
         s = s.contiguous()
-        pw, wsq = K.prep_weight(w, c_eq, False, _need_lo(x), want_wsq=True)     # [t][O][Cin] serves conv AND up-conv forward
+        pw, wsq = _prep(w, c_eq, False, _need_lo(x), want_wsq=True)             # [t][O][Cin] serves conv AND up-conv forward
         d = K.demod_fwd(s, wsq, ceil8(O))
         if up == 2:
             y = K.conv_bwd_data(x, pw, O, k, 2, pre=s, post=d, bias=bias, bias_scale=1.0, act=act, gain=gain)
@@ -418,7 +452,7 @@ class ModConvFn(Function):
                                        want_gbias=True, want_gdq=True)
         if gz is None:
             gz = gy
-        pwT, _ = K.prep_weight(w, c_eq, True, _need_lo(x))                       # [t][Cin][O]
+        pwT, _ = _prep(w, c_eq, True, _need_lo(x))                               # [t][Cin][O]
         if up == 2:
             u = K.conv_fwd(gz, pwT, Cin, k, 2, pre=d)                            # adjoint of the transposed conv
         else:

@@ -76,6 +76,8 @@ class Adam:
             rows.append((p.data, g, self.exp_avg[i], self.exp_avg_sq[i], self.lr / bc1, 1.0 / math.sqrt(bc2)))
         if rows:
             KM.K.multi_tensor(TensorTable(rows, self.params[0].device), MT_ADAM, self.beta1, self.beta2, self.eps)
+            from . import ops
+            ops.bump_weight_epoch()                          # parameters changed behind torch's version counters
 
     def state_dict(self):
         return {"steps": list(self.steps), "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
