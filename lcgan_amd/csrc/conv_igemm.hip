@@ -324,15 +324,15 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
       if (loff[k] >= 0) *(bf16x8*)(halo + loff[k]) = hreg[k];
   };
 
-  // ---- weight tile: 128 rows x 4 vectors = 512 items, one per thread ---------------------------------------------------
+  // ---- weight tile: 128 rows x 4 vectors = 512 items, one per thread; prefetched TWO taps ahead in two named registers ----
   const int brow = tid >> 2;
-  bf16x8 breg;
-  auto b_load = [&](int q) {                  // q = chunk * ntaps + tap
-    const int c = q / tt.n, t = q - c * tt.n;
-    const int n = n0 + brow;
-    breg = (n < a.N) ? *(const bf16x8*)(a.w + ((size_t)tt.wt[t] * a.N + n) * a.Kpad + c * BK + hvec * 8) : zero_bf16x8();
+  const int ntaps = tt.n, nchunks = a.kc_per_tap, total = ntaps * nchunks;
+  const size_t wrow = (size_t)(n0 + brow) * a.Kpad + hvec * 8;
+  const bool bvalid = n0 + brow < a.N;
+  auto b_load = [&](int c, int t) -> bf16x8 {
+    return bvalid ? *(const bf16x8*)(a.w + (size_t)tt.wt[t] * a.N * a.Kpad + wrow + c * BK) : zero_bf16x8();
   };
-  auto b_store = [&](int buf) { *(bf16x8*)(Bt + buf * TILE + brow * HROW + hvec * 8) = breg; };
+  auto b_store = [&](int buf, const bf16x8& r) { *(bf16x8*)(Bt + buf * TILE + brow * HROW + hvec * 8) = r; };
 
   // ---- per-lane fragment bases ---------------------------------------------------------------------------------------
   int abase[2];
@@ -351,42 +351,52 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(HaloArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int ntaps = tt.n, nchunks = a.kc_per_tap, total = ntaps * nchunks;
+  // (c, t) of the tile two steps ahead of the one being computed
+  int lc = 0, lt = 0;
+  auto advance = [&]() { if (++lt == ntaps) { lt = 0; ++lc; } };
+
   halo_load(0);
   halo_store();
-  b_load(0);
-  b_store(0);
+  b_store(0, b_load(0, 0));
+  advance();                                                   // -> tile 1
+  bf16x8 r0 = (1 < total) ? b_load(lc, lt) : zero_bf16x8();    // tile 1 in flight
+  advance();                                                   // -> tile 2
+  bf16x8 r1 = zero_bf16x8();
   __syncthreads();
-  int q = 0;
-  for (int c = 0; c < nchunks; ++c) {
-    if (c + 1 < nchunks) halo_load((c + 1) * BK);                  // in flight during the taps of chunk c
-    for (int t = 0; t < ntaps; ++t, ++q) {
-      const int cur = q & 1;
-      if (q + 1 < total) b_load(q + 1);
-      const int toff = ((tt.dy[t] - hy0) * hw + (tt.dx[t] - hx0)) * HROW;
-      const __bf16* Bc = Bt + cur * TILE;
-      bf16x8 af[2][2], bf[2][2];                                  // all 8 fragments of this tap first, then the 8 MFMAs
+
+  int c = 0, t = 0;
+  // one step: compute tile q from buffer (q & 1); `rs` holds tile q+1 (loaded one step ago), `rl` receives tile q+2
+  auto step = [&](int q, bf16x8& rs, bf16x8& rl) {
+    if (t == 0 && c + 1 < nchunks) halo_load((c + 1) * BK);    // next chunk's halo: in flight during this chunk's taps
+    if (q + 2 < total) { rl = b_load(lc, lt); advance(); }
+    const int toff = ((tt.dy[t] - hy0) * hw + (tt.dx[t] - hx0)) * HROW;
+    const __bf16* Bc = Bt + (q & 1) * TILE;
+    bf16x8 af[2][2], bf[2][2];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) af[ks][mi] = *(const bf16x8*)(halo + abase[mi] + toff + ks * 16);
+      for (int mi = 0; mi < 2; ++mi) af[ks][mi] = *(const bf16x8*)(halo + abase[mi] + toff + ks * 16);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) bf[ks][ni] = *(const bf16x8*)(Bc + bbase + ni * 32 * HROW + ks * 16);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mi], bf[ks][ni], acc[mi][ni], 0, 0, 0);
-      if (t == ntaps - 1 && c + 1 < nchunks) {
-        __syncthreads();                                           // every wave is done reading this chunk's halo
-        halo_store();
-      }
-      if (q + 1 < total) b_store(cur ^ 1);
-      __syncthreads();
+      for (int ni = 0; ni < 2; ++ni) bf[ks][ni] = *(const bf16x8*)(Bc + bbase + ni * 32 * HROW + ks * 16);
     }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mi], bf[ks][ni], acc[mi][ni], 0, 0, 0);
+    if (t == ntaps - 1 && c + 1 < nchunks) {
+      __syncthreads();                                         // every wave is done reading this chunk's halo
+      halo_store();
+    }
+    if (q + 1 < total) b_store((q + 1) & 1, rs);
+    __syncthreads();
+    if (++t == ntaps) { t = 0; ++c; }
+  };
+  for (int q = 0; q < total; q += 2) {
+    step(q, r0, r1);
+    if (q + 1 < total) step(q + 1, r1, r0);
   }
 
   // ---- epilogue: demod/bias/act in registers -> bf16 tile in LDS -> 16-byte coalesced stores (+ residual) ----------------

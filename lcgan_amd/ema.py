@@ -43,6 +43,6 @@ class Ema(object):
             self._build()
         KM.K.multi_tensor(self._table, MT_EMA, decay)            # p_ema <- p + decay * (p_ema - p)   (ema.py:26-32)
         from . import ops
-        ops.bump_weight_epoch()
+        ops.invalidate_weights(self.target.parameters())
         for b_ema, b in self._copy_buffers:
             b_ema.copy_(b)

@@ -42,8 +42,16 @@ _prep_cache: dict = {}      # id(param) -> [weakref(param), version, epoch, {(sc
 
 
 def bump_weight_epoch() -> None:
+    """Invalidate every cached prepared weight."""
     global _weight_epoch
     _weight_epoch += 1
+
+
+def invalidate_weights(params) -> None:
+    """Invalidate the prepared copies of exactly these parameters (called by the Adam / EMA kernels' wrappers, which rewrite
+    parameters through raw pointers without touching torch's version counters)."""
+    for p in params:
+        _prep_cache.pop(id(p), None)
 
 
 def _prep(w: Tensor, scale: float, transpose: bool, need_lo: bool, want_wsq: bool = False):

@@ -77,7 +77,7 @@ class Adam:
         if rows:
             KM.K.multi_tensor(TensorTable(rows, self.params[0].device), MT_ADAM, self.beta1, self.beta2, self.eps)
             from . import ops
-            ops.bump_weight_epoch()                          # parameters changed behind torch's version counters
+            ops.invalidate_weights(p for p in self.params if p.grad is not None)   # changed behind torch's version counters
 
     def state_dict(self):
         return {"steps": list(self.steps), "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}
