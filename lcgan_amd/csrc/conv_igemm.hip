@@ -26,6 +26,8 @@ namespace {
 
 int g_use_halo = 1;                       // lcgan_set_option(0, ...): bf16 halo-tile fast path on/off (A/B testing)
 int g_use_splitk = 1;                     // lcgan_set_option(1, ...): split-K for small-M convolutions
+int g_wgrad3_wgs = 1536;                  // lcgan_set_option(2, ...): target workgroup count of the row-segment wgrad kernel
+int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): TIMING EXPERIMENTS ONLY: skip the wgrad epilogue atomics
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDS_ROW = 40;               // bf16 per staged row: 32 + 8 pad (80 B stride: conflict-free ds_read_b128)
@@ -500,6 +502,8 @@ struct WgradArgs {
   int B, Hx, Wx, Cx, Hm, Wm, Cg, A, Bc, M;
   int stride, k, pad;
   int chunks_per_split, nsplit, nchunks;
+  int parts;                                 // wgrad3: split = sample * parts + part
+  int dbg_no_atomics;
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -671,8 +675,12 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
   const int a0 = blockIdx.x * 128, c0 = blockIdx.y * 128;
   const int ky = blockIdx.z / a.nsplit, split = blockIdx.z - ky * a.nsplit;
   const int segs = a.Wm >> 5;
-  const int q_begin = split * a.chunks_per_split;
-  const int q_end = min(q_begin + a.chunks_per_split, a.nchunks);
+  // split = (sample, part): a workgroup's chunk range lies inside ONE sample, so the per-sample style / demod scales can be
+  // applied once to the fp32 accumulator in the epilogue instead of to every staged operand vector
+  const int bsmp = split / a.parts, part = split - bsmp * a.parts;
+  const int cps = a.Hm * segs;                                   // chunks per sample
+  const int q_begin = bsmp * cps + part * a.chunks_per_split;
+  const int q_end = min(q_begin + a.chunks_per_split, (bsmp + 1) * cps);
   if (q_begin >= q_end) return;
   const __bf16* __restrict__ x = (const __bf16*)a.x;
   const __bf16* __restrict__ g = (const __bf16*)a.g;
@@ -691,21 +699,8 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
     decode(q, b, row, j0);
     const int yy = row * STRIDE + ky - 1;
     if ((unsigned)yy >= (unsigned)a.Hx) return false;        // this kernel row only meets padding here: contributes nothing
-    float sg[8], sx[8];
-    if (a.pre_g) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) sg[j] = ga_ok ? a.pre_g[(size_t)b * a.Cg + a0 + lvec * 8 + j] : 0.f;
-    }
-    if (a.pre_x) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) sx[j] = xc_ok ? a.pre_x[(size_t)b * a.Cx + c0 + lvec * 8 + j] : 0.f;
-    }
     const size_t gbase = ((size_t)(b * a.Hm + row) * a.Wm + j0) * a.Cg + a0 + lvec * 8;
     rg = ga_ok ? *(const bf16x8*)(g + gbase + (size_t)lpos * a.Cg) : zero_bf16x8();
-    if (a.pre_g) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) rg[j] = (__bf16)((float)rg[j] * sg[j]);
-    }
     const int xx0 = j0 * STRIDE - 1;
     const size_t xrow = (size_t)(b * a.Hx + yy) * a.Wx;
 #pragma unroll
@@ -714,10 +709,6 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
       const int xx = xx0 + r;
       const bool ok = r < XR && xc_ok && (unsigned)xx < (unsigned)a.Wx;
       rx[k] = ok ? *(const bf16x8*)(x + (xrow + xx) * a.Cx + c0 + lvec * 8) : zero_bf16x8();
-      if (a.pre_x) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) rx[k][j] = (__bf16)((float)rx[k][j] * sx[j]);
-      }
     }
     return true;
   };
@@ -788,10 +779,14 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int cc = c0 + wn * 32 + (lane & 31);
+      const float sxv = (a.pre_x && cc < a.Cx) ? a.pre_x[(size_t)bsmp * a.Cx + cc] : 1.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int aa = a0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (aa < a.A && cc < a.Bc) atomicAdd(a.gwp + ((size_t)(ky * 3 + kx) * a.A + aa) * a.Bc + cc, acc[kx][mi][r]);
+        if (aa < a.A && cc < a.Bc && !a.dbg_no_atomics) {
+          const float sgv = a.pre_g ? a.pre_g[(size_t)bsmp * a.Cg + aa] : 1.f;
+          atomicAdd(a.gwp + ((size_t)(ky * 3 + kx) * a.A + aa) * a.Bc + cc, acc[kx][mi][r] * sxv * sgv);
+        }
       }
     }
 }
@@ -940,6 +935,8 @@ extern "C" {
 int lcgan_set_option(int option, int value) {
   if (option == 0) { const int old = g_use_halo; g_use_halo = value; return old; }
   if (option == 1) { const int old = g_use_splitk; g_use_splitk = value; return old; }
+  if (option == 2) { const int old = g_wgrad3_wgs; g_wgrad3_wgs = value; return old; }
+  if (option == 3) { const int old = g_dbg_no_atomics; g_dbg_no_atomics = value; return old; }
   return LCGAN_EINVAL;
 }
 
@@ -1075,11 +1072,14 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
       (long long)B * Hx * Wx * Cx < (1ll << 31) && (long long)B * Hg * Wg * Cg < (1ll << 31)) {
     // row-segment kernel: chunk = (sample, row, 32-position segment); grid.z = kernel row x split
     a.nchunks = B * Hg * (Wg >> 5);
+    a.dbg_no_atomics = g_dbg_no_atomics;
     const int tiles3 = cdiv(A, 128) * cdiv(Bc, 128) * 3;
-    int ns = (1536 + tiles3 - 1) / tiles3;
-    ns = max(1, min(ns, a.nchunks / 8 > 0 ? a.nchunks / 8 : 1));
-    a.chunks_per_split = cdiv(a.nchunks, ns);
-    a.nsplit = cdiv(a.nchunks, a.chunks_per_split);
+    const int cps = Hg * (Wg >> 5);                             // chunks per sample
+    int parts = (g_wgrad3_wgs + tiles3 * B - 1) / (tiles3 * B);   // parts per sample so that ~g_wgrad3_wgs workgroups exist
+    parts = max(1, min(parts, cps / 4 > 0 ? cps / 4 : 1));
+    a.chunks_per_split = cdiv(cps, parts);
+    a.parts = cdiv(cps, a.chunks_per_split);
+    a.nsplit = B * a.parts;
     dim3 grid3(cdiv(A, 128), cdiv(Bc, 128), 3 * a.nsplit);
     const size_t smem3 = 2 * (size_t)(32 + 32 * stride + 2) * WG_ROW * sizeof(__bf16);
     if (stride == 1) {

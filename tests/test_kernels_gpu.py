@@ -132,8 +132,12 @@ def test_conv_wgrad(H, dtype, case):
     ref = E.conv_wgrad(x, g, Co, Ci, k, stride)
     check(H.conv_wgrad(x.cuda(), g.cuda(), Co, Ci, k, stride), ref, dtype, "plain")
     px, pg = vec((B, ceil8(Ci)), 23), vec((B, ceil8(Co)), 24)
-    check(H.conv_wgrad(x.cuda(), g.cuda(), Co, Ci, k, stride, pre_x=px.cuda(), pre_g=pg.cuda()),
-          E.conv_wgrad(x, g, Co, Ci, k, stride, pre_x=px, pre_g=pg), dtype, "prescaled")
+    got, ref_p = H.conv_wgrad(x.cuda(), g.cuda(), Co, Ci, k, stride, pre_x=px.cuda(), pre_g=pg.cuda()), E.conv_wgrad(x, g, Co, Ci, k, stride, pre_x=px, pre_g=pg)
+    if dtype == torch.float32:
+        check(got, ref_p, dtype, "prescaled")
+    else:   # the generic bf16 kernel rounds the prescaled operands to bf16 (2^-9 per operand): L2 up to ~3e-3
+        e_l2 = float((got.float().cpu() - ref_p).norm() / ref_p.norm())
+        assert e_l2 <= 4e-3, e_l2
     # un-prep, both orientations, with the demod term
     w = torch.randn(Co, Ci, k, k, generator=torch.Generator().manual_seed(25))
     gwsq = torch.randn(Co, Ci, generator=torch.Generator().manual_seed(26))
