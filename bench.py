@@ -41,6 +41,7 @@ def cpu_baseline(res: int, batch: int):
     ONE odd+R1 iteration (G step + D step, no optimiser) at `batch` images."""
     from oracle import lcgan_ref as O
     from oracle.weights import seeded_state, seeded_tensor
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))        # the CPU share of a one-GPU box
     GP, DP = seeded_state(O.g_param_shapes(res), 1001), seeded_state(O.d_param_shapes(res), 1002)
     z = tuple(seeded_tensor((batch, 64), 10 + i) for i in range(4))
     real = tuple(seeded_tensor((batch, 3, res, res), 20 + i, "uniform_pm1") for i in range(3))

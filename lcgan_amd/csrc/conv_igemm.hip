@@ -1076,7 +1076,7 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
     const int tiles3 = cdiv(A, 128) * cdiv(Bc, 128) * 3;
     const int cps = Hg * (Wg >> 5);                             // chunks per sample
     int parts = (g_wgrad3_wgs + tiles3 * B - 1) / (tiles3 * B);   // parts per sample so that ~g_wgrad3_wgs workgroups exist
-    parts = max(1, min(parts, cps / 4 > 0 ? cps / 4 : 1));
+    parts = max(1, min(parts, cps / 64 > 0 ? cps / 64 : 1));      // >= 64 chunks per workgroup: the 49K-element atomic epilogue must stay amortised
     a.chunks_per_split = cdiv(cps, parts);
     a.parts = cdiv(cps, a.chunks_per_split);
     a.nsplit = B * a.parts;

@@ -135,16 +135,22 @@ __global__ void demod_fwd_kernel(const float* __restrict__ s, const float* __res
   if (lane == 0) d[(size_t)b * Os + o] = rsqrtf(acc + eps);
 }
 // gq[b,o] = -0.5 * gdq[b,o] * d[b,o]^2 ;  gs[b,c] += 2 s[b,c] sum_o gq[b,o] wsq[o,c]
+// block = (256 channels c, sample b, chunk of 64 outputs o): gq of the chunk sits in LDS, partial sums meet through atomics
 __global__ void demod_bwd_s_kernel(const float* __restrict__ gdq, const float* __restrict__ d, const float* __restrict__ s,
                                    const float* __restrict__ wsq, float* __restrict__ gs, int B, int C, int O, int Os) {
-  const int c = blockIdx.x * TPB + threadIdx.x, b = blockIdx.y;
+  __shared__ float gq[64];
+  const int c = blockIdx.x * TPB + threadIdx.x, b = blockIdx.y, o0 = blockIdx.z * 64;
+  const int oc = min(64, O - o0);
+  if (threadIdx.x < oc) {
+    const float dv = d[(size_t)b * Os + o0 + threadIdx.x];
+    gq[threadIdx.x] = -0.5f * gdq[(size_t)b * Os + o0 + threadIdx.x] * dv * dv;
+  }
+  __syncthreads();
   if (c >= C) return;
   float acc = 0.f;
-  for (int o = 0; o < O; ++o) {
-    const float dv = d[(size_t)b * Os + o];
-    acc += -0.5f * gdq[(size_t)b * Os + o] * dv * dv * wsq[(size_t)o * C + c];
-  }
-  gs[(size_t)b * C + c] += 2.f * s[(size_t)b * C + c] * acc;
+#pragma unroll 16
+  for (int o = 0; o < oc; ++o) acc += gq[o] * wsq[(size_t)(o0 + o) * C + c];
+  atomicAdd(gs + (size_t)b * C + c, 2.f * s[(size_t)b * C + c] * acc);
 }
 // gwsq[o,c] = sum_b gq[b,o] s[b,c]^2
 __global__ void demod_bwd_w_kernel(const float* __restrict__ gdq, const float* __restrict__ d, const float* __restrict__ s,
@@ -269,55 +275,58 @@ __global__ void avg_latent_kernel(const float* __restrict__ w, float* __restrict
 constexpr int QR_MAX = 64;
 __global__ __launch_bounds__(QR_MAX) void qr_householder_kernel(const float* __restrict__ A, float* __restrict__ Q,
                                                                  float* __restrict__ R, int n) {
-  __shared__ float a[QR_MAX][QR_MAX + 1];
-  __shared__ float q[QR_MAX][QR_MAX + 1];
-  __shared__ float tau[QR_MAX];
+  // thread c owns column c of the working matrix and of Q in REGISTERS (fully unrolled, predicated loops keep the indices
+  // static); only the current Householder vector travels through LDS (broadcast reads).
+  __shared__ float vs[QR_MAX][QR_MAX];      // v_j for every step (row j: the reflector of step j), needed again to form Q
+  __shared__ float taus[QR_MAX];
   const int c = threadIdx.x;
-  for (int i = 0; i < n; ++i) {
-    if (c < n) { a[i][c] = A[i * n + c]; q[i][c] = (i == c) ? 1.f : 0.f; }
-  }
-  __syncthreads();
+  float a[QR_MAX], q[QR_MAX];
+#pragma unroll
+  for (int i = 0; i < QR_MAX; ++i) { a[i] = (i < n && c < n) ? A[i * n + c] : 0.f; q[i] = (i == c) ? 1.f : 0.f; }
   for (int j = 0; j < n; ++j) {
     if (c == j) {                                           // dlarfg on column j, rows j..n-1
-      const float alpha = a[j][j];
-      float xn2 = 0.f;
-      for (int i = j + 1; i < n; ++i) xn2 += a[i][j] * a[i][j];
-      if (xn2 == 0.f) {
-        tau[j] = 0.f;
-      } else {
-        const float beta = -copysignf(sqrtf(alpha * alpha + xn2), alpha);
-        tau[j] = (beta - alpha) / beta;
-        const float sc = 1.f / (alpha - beta);
-        for (int i = j + 1; i < n; ++i) a[i][j] *= sc;      // v (v_j = 1 implicit)
-        a[j][j] = beta;
+      float alpha = 0.f, xn2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < QR_MAX; ++i) { if (i == j) alpha = a[i]; if (i > j && i < n) xn2 += a[i] * a[i]; }
+      float tau = 0.f, beta = alpha, sc = 0.f;
+      if (xn2 != 0.f) {
+        beta = -copysignf(sqrtf(alpha * alpha + xn2), alpha);
+        tau = (beta - alpha) / beta;
+        sc = 1.f / (alpha - beta);
       }
+#pragma unroll
+      for (int i = 0; i < QR_MAX; ++i) {
+        const float vi = (i == j) ? 1.f : ((i > j && i < n) ? a[i] * sc : 0.f);
+        vs[j][i] = vi;
+        if (i == j) a[i] = beta; else if (i > j) a[i] = vi;   // R_jj and v stored like LAPACK (v below the diagonal)
+      }
+      taus[j] = tau;
     }
     __syncthreads();
-    if (c > j && c < n) {                                   // A[j:, c] -= tau v (v^T A[j:, c])
-      const float t = tau[j];
-      float wv = a[j][c];
-      for (int i = j + 1; i < n; ++i) wv += a[i][j] * a[i][c];
-      wv *= t;
-      a[j][c] -= wv;
-      for (int i = j + 1; i < n; ++i) a[i][c] -= a[i][j] * wv;
+    if (c > j && c < n) {                                   // A[:, c] -= tau v (v^T A[:, c])
+      float wv = 0.f;
+#pragma unroll
+      for (int i = 0; i < QR_MAX; ++i) wv += vs[j][i] * a[i];
+      wv *= taus[j];
+#pragma unroll
+      for (int i = 0; i < QR_MAX; ++i) a[i] -= vs[j][i] * wv;
     }
-    __syncthreads();
   }
+  __syncthreads();
   for (int j = n - 1; j >= 0; --j) {                        // Q = H_0 ... H_{n-1} I  (dorg2r, backward accumulation)
-    if (c >= j && c < n) {
-      const float t = tau[j];
-      float wv = q[j][c];
-      for (int i = j + 1; i < n; ++i) wv += a[i][j] * q[i][c];
-      wv *= t;
-      q[j][c] -= wv;
-      for (int i = j + 1; i < n; ++i) q[i][c] -= a[i][j] * wv;
+    if (c < n) {
+      float wv = 0.f;
+#pragma unroll
+      for (int i = 0; i < QR_MAX; ++i) wv += vs[j][i] * q[i];
+      wv *= taus[j];
+#pragma unroll
+      for (int i = 0; i < QR_MAX; ++i) q[i] -= vs[j][i] * wv;
     }
-    __syncthreads();
   }
   if (c < n) {
-    for (int i = 0; i < n; ++i) {
-      Q[i * n + c] = q[i][c];
-      R[i * n + c] = (i <= c) ? a[i][c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < QR_MAX; ++i) {
+      if (i < n) { Q[i * n + c] = q[i]; R[i * n + c] = (i <= c) ? a[i] : 0.f; }
     }
   }
 }
@@ -409,7 +418,7 @@ int lcgan_demod_bwd(const float* gdq, const float* d, const float* sv, const flo
                     int B, int C, int O, int Os, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(KID_SMALL, 0, 0, s);
-  hipLaunchKernelGGL(demod_bwd_s_kernel, dim3(cdiv(C, TPB), B), dim3(TPB), 0, s, gdq, d, sv, wsq, gs, B, C, O, Os);
+  hipLaunchKernelGGL(demod_bwd_s_kernel, dim3(cdiv(C, TPB), B, cdiv(O, 64)), dim3(TPB), 0, s, gdq, d, sv, wsq, gs, B, C, O, Os);
   hipLaunchKernelGGL(demod_bwd_w_kernel, dim3(cdiv(C, TPB), O), dim3(TPB), 0, s, gdq, d, sv, gwsq, B, C, O, Os);
   return launch_status();
 }
