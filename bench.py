@@ -29,8 +29,28 @@ D_FWD = {256: 93.063e9, 512: 123.178e9, 1024: 153.344e9}
 PEAK_BF16_DENSE = 2.5e15          # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 
 
+def _analytic_fwd_flops(res: int):
+    """2*MAC of the conv layers for resolutions outside the SURVEY table (dry runs); within 1 % of the table at 256."""
+    import math
+    nb = int(math.log2(res)) - 2
+    base = 32 if res == 1024 else 64 if res == 512 else 128
+    g, cin, h = 0.0, 512, 4
+    for i in range(nb):
+        cout = min(base * 2 ** (nb - i - 1), 512)
+        g += 2 * 9 * cin * cout * h * h + 2 * 9 * cout * cout * (2 * h) ** 2 + 2 * cin * cout * h * h + 2 * 9 * cin * 2 * h * h
+        cin, h = cout, 2 * h
+    g += 2 * 9 * cin * cin * h * h + 2 * cin * 3 * h * h
+    d, h = 2 * 3 * base * res * res, res
+    for i in range(nb):
+        ci, co = min(base * 2 ** i, 512), min(base * 2 ** (i + 1), 512)
+        d += 2 * 9 * ci * ci * h * h + 2 * 9 * ci * co * (h // 2) ** 2 + 2 * ci * co * (h // 2) ** 2
+        h //= 2
+    d += 2 * 9 * 513 * 512 * 16 + 2 * 8192 * 512
+    return g, d
+
+
 def flops_per_image(res: int, epoch: int) -> float:
-    g, d = G_FWD[res], D_FWD[res]
+    g, d = (G_FWD[res], D_FWD[res]) if res in G_FWD else _analytic_fwd_flops(res)
     if epoch % 2 == 0:
         return 10 * g + 18 * d + 15 * 0.072e9
     return 4 * g + (11 if epoch % 8 == 1 else 8) * d
@@ -70,11 +90,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)                  # (ranks > devices only happens in the single-GPU dry run below)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("LCGAN_DIST_BACKEND", "nccl")      # "nccl" == RCCL; "gloo" lets two ranks share one GPU for a dry run
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from lcgan_amd import config, kernels, loader, worker
     from tests.helpers import make_args
@@ -82,7 +108,7 @@ def main():
     assert kernels.backend_name() == "hip"
     args = make_args(a.res, a.batch)
     torch.manual_seed(0)                                   # identical reference-style init on every rank
-    w = worker.WORKER(args, local_rank, world)
+    w = worker.WORKER(args, local_rank, world, device=dev)
     torch.manual_seed(1 + rank)                            # different latents per rank
 
     def epoch_of(i):
