@@ -156,8 +156,16 @@ def main():
         K.prof_enable(False)
         ig, wg = prof["conv_igemm"], prof["conv_wgrad"]
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
-        out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel", "achieved": ach, "peak": PEAK_BF16_DENSE / 1e12,
-                           "unit": "TFLOP/s", "frac": ach / (PEAK_BF16_DENSE / 1e12), "traffic": None,
+        traffic = None                                      # HBM bytes per launch from the PMC passes (scripts/pmc_traffic.py; FETCH_SIZE x2 on gfx950)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            n = sum(pmc[k]["launches"] for k in ("conv_halo", "conv_igemm") if k in pmc)
+            traffic = sum(pmc[k]["bytes_per_launch"] * pmc[k]["launches"] for k in ("conv_halo", "conv_igemm") if k in pmc) / max(n, 1)
+        except Exception:  # noqa: BLE001
+            pass
+        out["roofline"] = {"bound": "mfma", "kernel": "conv_halo_kernel + conv_igemm_kernel (forward / data-gradient convolutions)",
+                           "achieved": ach, "peak": PEAK_BF16_DENSE / 1e12,
+                           "unit": "TFLOP/s", "frac": ach / (PEAK_BF16_DENSE / 1e12), "traffic": traffic,
                            "launches": ig["count"], "avg_launch_ms": ig["ms"] / max(ig["count"], 1),
                            "flops_per_launch": ig["flops"] / max(ig["count"], 1)}
         out["kernel_ms"] = {k: round(v["ms"], 3) for k, v in prof.items()}

@@ -673,7 +673,9 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 2, wn = wid & 3;                    // 8 waves: 2 (a) x 4 (c), wave tile 64 x 32
   const int a0 = blockIdx.x * 128, c0 = blockIdx.y * 128;
-  const int ky = blockIdx.z / a.nsplit, split = blockIdx.z - ky * a.nsplit;
+  // the 3 kernel rows of one chunk range are neighbours in dispatch order: they read the same G rows and overlapping X rows,
+  // so the 2nd and 3rd reads are served by the Infinity Cache instead of HBM
+  const int split = blockIdx.z / 3, ky = blockIdx.z - split * 3;
   const int segs = a.Wm >> 5;
   // split = (sample, part): a workgroup's chunk range lies inside ONE sample, so the per-sample style / demod scales can be
   // applied once to the fp32 accumulator in the epilogue instead of to every staged operand vector
