@@ -662,12 +662,13 @@ __device__ __forceinline__ bf16x8 tr_frag_rows(const __bf16* tile, int row_a, in
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int STRIDE>
+template <int STRIDE, int SEG>
 __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int XR = 32 * STRIDE + 2;                       // halo pixels per segment
+  constexpr int XR = SEG * STRIDE + 2;                      // halo pixels per segment
+  constexpr int NG = SEG / 32;                              // G items (position, vec) per thread
   constexpr int NX = (XR * 16 + 511) / 512;                  // X items (pixel, vec) per thread (512 threads)
-  constexpr int STAGE = (32 + XR) * WG_ROW;                  // elements per stage: G then X
+  constexpr int STAGE = (SEG + XR) * WG_ROW;                 // elements per stage: G then X
   __bf16* lds = (__bf16*)smem;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
   // the 3 kernel rows of one chunk range are neighbours in dispatch order: they read the same G rows and overlapping X rows,
   // so the 2nd and 3rd reads are served by the Infinity Cache instead of HBM
   const int split = blockIdx.z / 3, ky = blockIdx.z - split * 3;
-  const int segs = a.Wm >> 5;
+  const int segs = a.Wm / SEG;
   // split = (sample, part): a workgroup's chunk range lies inside ONE sample, so the per-sample style / demod scales can be
   // applied once to the fp32 accumulator in the epilogue instead of to every staged operand vector
   const int bsmp = split / a.parts, part = split - bsmp * a.parts;
@@ -689,39 +690,41 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
   const int lpos = tid >> 4, lvec = tid & 15;
   const bool ga_ok = a0 + lvec * 8 < a.Cg, xc_ok = c0 + lvec * 8 < a.Cx;
 
-  bf16x8 rg, rx[NX];
-  bool live = false;                                         // does the chunk in the registers carry any data?
+  struct Stage { bf16x8 g[NG]; bf16x8 x[NX]; };
 
   auto decode = [&](int q, int& b, int& row, int& j0) {
     const int seg = q % segs, t = q / segs;
-    row = t % a.Hm; b = t / a.Hm; j0 = seg << 5;
+    row = t % a.Hm; b = t / a.Hm; j0 = seg * SEG;
   };
-  auto gload = [&](int q) -> bool {
+  // stage loads of chunk q (rows that only meet padding load zeros: the loop stays regular, 1/Hm of the chunks)
+  auto gload = [&](int q, Stage& st) {
     int b, row, j0;
     decode(q, b, row, j0);
     const int yy = row * STRIDE + ky - 1;
-    if ((unsigned)yy >= (unsigned)a.Hx) return false;        // this kernel row only meets padding here: contributes nothing
+    const bool rowok = (unsigned)yy < (unsigned)a.Hx;
     const size_t gbase = ((size_t)(b * a.Hm + row) * a.Wm + j0) * a.Cg + a0 + lvec * 8;
-    rg = ga_ok ? *(const bf16x8*)(g + gbase + (size_t)lpos * a.Cg) : zero_bf16x8();
+#pragma unroll
+    for (int i = 0; i < NG; ++i)
+      st.g[i] = (ga_ok && rowok) ? *(const bf16x8*)(g + gbase + (size_t)(lpos + 32 * i) * a.Cg) : zero_bf16x8();
     const int xx0 = j0 * STRIDE - 1;
-    const size_t xrow = (size_t)(b * a.Hx + yy) * a.Wx;
+    const size_t xrow = (size_t)(b * a.Hx + (rowok ? yy : 0)) * a.Wx;
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
       const int r = lpos + 32 * k;                           // halo pixel index (tid>>4 + 32k)
       const int xx = xx0 + r;
-      const bool ok = r < XR && xc_ok && (unsigned)xx < (unsigned)a.Wx;
-      rx[k] = ok ? *(const bf16x8*)(x + (xrow + xx) * a.Cx + c0 + lvec * 8) : zero_bf16x8();
+      const bool ok = rowok && r < XR && xc_ok && (unsigned)xx < (unsigned)a.Wx;
+      st.x[k] = ok ? *(const bf16x8*)(x + (xrow + xx) * a.Cx + c0 + lvec * 8) : zero_bf16x8();
     }
-    return true;
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, const Stage& st) {
     __bf16* G = lds + buf * STAGE;
-    __bf16* X = G + 32 * WG_ROW;
-    *(bf16x8*)(G + lpos * WG_ROW + lvec * 8) = rg;
+    __bf16* X = G + SEG * WG_ROW;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) *(bf16x8*)(G + (lpos + 32 * i) * WG_ROW + lvec * 8) = st.g[i];
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
       const int r = lpos + 32 * k;
-      if (r < XR) *(bf16x8*)(X + r * WG_ROW + lvec * 8) = rx[k];
+      if (r < XR) *(bf16x8*)(X + r * WG_ROW + lvec * 8) = st.x[k];
     }
   };
 
@@ -739,9 +742,9 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
 
   auto compute = [&](int buf) {
     const __bf16* G = lds + buf * STAGE;
-    const __bf16* X = G + 32 * WG_ROW;
+    const __bf16* X = G + SEG * WG_ROW;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < SEG / 16; ++ks) {
       const int p = ks * 16 + trow;                          // position (within the segment) of this lane's first row block
       bf16x8 af[2];
 #pragma unroll
@@ -756,24 +759,22 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
     }
   };
 
-  // software pipeline over the chunks that carry data
-  int q = q_begin;
-  while (q < q_end && !gload(q)) ++q;
-  if (q < q_end) {
-    sstore(0);
+  // software pipeline: chunk q computes from LDS buffer (q - q_begin) & 1 while chunk q+1 sits in one register stage and the
+  // loads of chunk q+2 are in flight in the other (two named stages -> static register indexing)
+  Stage s0, s1;
+  gload(q_begin, s0);
+  sstore(0, s0);
+  if (q_begin + 1 < q_end) gload(q_begin + 1, s0);
+  __syncthreads();
+  auto step = [&](int q, Stage& rs, Stage& rl) {
+    if (q + 2 < q_end) gload(q + 2, rl);
+    compute((q - q_begin) & 1);
+    if (q + 1 < q_end) sstore(((q - q_begin) & 1) ^ 1, rs);
     __syncthreads();
-    int cur = 0;
-    while (true) {
-      int qn = q + 1;
-      bool have_next = false;
-      while (qn < q_end) { if (gload(qn)) { have_next = true; break; } ++qn; }
-      compute(cur);
-      if (!have_next) break;
-      sstore(cur ^ 1);
-      __syncthreads();
-      cur ^= 1;
-      q = qn;
-    }
+  };
+  for (int q = q_begin; q < q_end; q += 2) {
+    step(q, s0, s1);
+    if (q + 1 < q_end) step(q + 1, s1, s0);
   }
 
 #pragma unroll
@@ -1072,25 +1073,31 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
   ProfScope p(KID_CONV_WGRAD, 2.0 * M * A * Bc * k * k, 0, s);
   if (dtype == DT_BF16 && g_use_halo && k == 3 && (Wg & 31) == 0 &&
       (long long)B * Hx * Wx * Cx < (1ll << 31) && (long long)B * Hg * Wg * Cg < (1ll << 31)) {
-    // row-segment kernel: chunk = (sample, row, 32-position segment); grid.z = kernel row x split
-    a.nchunks = B * Hg * (Wg >> 5);
+    // row-segment kernel: chunk = (sample, row, SEG-position segment); grid.z = split x kernel row
+    const int seg = (Wg & 63) == 0 ? 64 : 32;                   // 64-position segments halve the barriers per MFMA
     a.dbg_no_atomics = g_dbg_no_atomics;
     const int tiles3 = cdiv(A, 128) * cdiv(Bc, 128) * 3;
-    const int cps = Hg * (Wg >> 5);                             // chunks per sample
+    const int cps = Hg * (Wg / seg);                            // chunks per sample
+    a.nchunks = B * cps;
     int parts = (g_wgrad3_wgs + tiles3 * B - 1) / (tiles3 * B);   // parts per sample so that ~g_wgrad3_wgs workgroups exist
-    parts = max(1, min(parts, cps / 64 > 0 ? cps / 64 : 1));      // >= 64 chunks per workgroup: the 49K-element atomic epilogue must stay amortised
+    const int min_chunks = 2048 / seg;                          // >= 2048 positions per workgroup: the 49K-element atomic epilogue must stay amortised
+    parts = max(1, min(parts, cps / min_chunks > 0 ? cps / min_chunks : 1));
     a.chunks_per_split = cdiv(cps, parts);
     a.parts = cdiv(cps, a.chunks_per_split);
     a.nsplit = B * a.parts;
     dim3 grid3(cdiv(A, 128), cdiv(Bc, 128), 3 * a.nsplit);
-    const size_t smem3 = 2 * (size_t)(32 + 32 * stride + 2) * WG_ROW * sizeof(__bf16);
-    if (stride == 1) {
-      hipLaunchKernelGGL((conv_wgrad3_kernel<1>), grid3, dim3(512), smem3, s, a);
-    } else {
-      static bool set = false;
-      if (!set) { hipFuncSetAttribute((const void*)conv_wgrad3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3); set = true; }
-      hipLaunchKernelGGL((conv_wgrad3_kernel<2>), grid3, dim3(512), smem3, s, a);
+    const size_t smem3 = 2 * (size_t)(seg + seg * stride + 2) * WG_ROW * sizeof(__bf16);
+#define LAUNCH_WG3(ST, SG)                                                                                              \
+    {                                                                                                                   \
+      static bool set = false;                                                                                          \
+      if (!set) { hipFuncSetAttribute((const void*)conv_wgrad3_kernel<ST, SG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
+      hipLaunchKernelGGL((conv_wgrad3_kernel<ST, SG>), grid3, dim3(512), smem3, s, a);                                  \
     }
+    if (stride == 1 && seg == 64) LAUNCH_WG3(1, 64)
+    else if (stride == 1) LAUNCH_WG3(1, 32)
+    else if (seg == 64) LAUNCH_WG3(2, 64)
+    else LAUNCH_WG3(2, 32)
+#undef LAUNCH_WG3
   } else if (dtype == DT_BF16) {
     const size_t smem = 2 * 2 * WG_TILE * sizeof(__bf16);
     hipLaunchKernelGGL((conv_wgrad_kernel<__bf16, 1>), grid, dim3(256), smem, s, a);
