@@ -173,7 +173,7 @@ def main():
     elif world > 1 and not a.no_roofline:
         loader.train_iteration(w, args, epoch_of(a.warmup + a.steps))       # keep the ranks in lock-step
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.res, 2)
+        out["cpu_baseline"] = cpu_baseline(a.res, 4)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
