@@ -18,39 +18,35 @@ constexpr int TPB = 256;
 constexpr int MT = 32;     // rows of the small-M GEMMs handled per block
 
 // y[m,o] = act(scale * sum_i x[m,i] w[o,i] + bias[o]*bias_scale) * gain
-// Block = 8 output columns x 32 rows of x.  The x tile is staged TRANSPOSED in LDS ([i][m], padded) so the inner loop is
-// one broadcast weight load (16 B per 4 i) + one conflict-free LDS read per FMA; weights (the big operand) are read once.
-constexpr int LIN_IC = 512;                 // i-chunk staged per pass (512 x 33 floats = 66 KB)
+// Block = 8 output columns x 32 rows of x.  Per 256-wide i-chunk BOTH operands are staged in LDS with all loads issued at once
+// (x transposed [i][m] padded, the 8 weight rows [o][i]); the inner loop then runs from LDS only (weight reads are broadcasts).
+// The first version chained 128 dependent global weight loads per thread (~50 us per launch for a 512x512 layer).
+constexpr int LIN_IC = 256;
 __global__ __launch_bounds__(TPB) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           int M, int I, int O, float scale, float bias_scale, int act, float gain) {
-  extern __shared__ float xs[];              // [LIN_IC][33]
+  __shared__ float xs[LIN_IC * 33];
+  __shared__ float ws[8 * LIN_IC];
   const int m = threadIdx.x & 31, ol = threadIdx.x >> 5;
-  const int o = blockIdx.x * 8 + ol, m0 = blockIdx.y * MT;
-  const int mrow = m0 + m;
-  const bool ovalid = o < O;
-  const float* wr = w + (size_t)(ovalid ? o : 0) * I;
+  const int o0 = blockIdx.x * 8, m0 = blockIdx.y * MT;
   float acc = 0.f;
   for (int i0 = 0; i0 < I; i0 += LIN_IC) {
     const int ic = min(LIN_IC, I - i0);
     __syncthreads();
-    for (int idx = threadIdx.x; idx < MT * ic; idx += TPB) {          // coalesced along i, transposed into LDS
-      const int mm = idx / ic, ii = idx - mm * ic;
-      xs[ii * 33 + mm] = (m0 + mm < M) ? x[(size_t)(m0 + mm) * I + i0 + ii] : 0.f;
+    // staging: thread t walks column ii = t (+256 ...) of every row: no integer division, coalesced along i
+    for (int ii = threadIdx.x; ii < ic; ii += TPB) {
+#pragma unroll 8
+      for (int mm = 0; mm < MT; ++mm) xs[ii * 33 + mm] = (m0 + mm < M) ? x[(size_t)(m0 + mm) * I + i0 + ii] : 0.f;
+#pragma unroll
+      for (int oo = 0; oo < 8; ++oo) ws[oo * LIN_IC + ii] = (o0 + oo < O) ? w[(size_t)(o0 + oo) * I + i0 + ii] : 0.f;
     }
     __syncthreads();
-    if (ovalid) {
-      int ii = 0;
-      if (((I | i0) & 3) == 0) {
-        for (; ii + 4 <= ic; ii += 4) {
-          const f32x4 wv = *(const f32x4*)(wr + i0 + ii);
-          acc += wv[0] * xs[ii * 33 + m] + wv[1] * xs[(ii + 1) * 33 + m] + wv[2] * xs[(ii + 2) * 33 + m] + wv[3] * xs[(ii + 3) * 33 + m];
-        }
-      }
-      for (; ii < ic; ++ii) acc += wr[i0 + ii] * xs[ii * 33 + m];
-    }
+    const float* wr = ws + ol * LIN_IC;
+#pragma unroll 8
+    for (int ii = 0; ii < ic; ++ii) acc += wr[ii] * xs[ii * 33 + m];
   }
-  if (ovalid && mrow < M) {
+  const int o = o0 + ol, mrow = m0 + m;
+  if (o < O && mrow < M) {
     const float bv = bias ? bias[o] * bias_scale : 0.f;
     y[(size_t)mrow * O + o] = act_fwd(acc * scale + bv, act) * gain;
   }
@@ -372,10 +368,7 @@ int lcgan_linear_fwd(const float* x, const float* w, const float* bias, float* y
   hipStream_t s = (hipStream_t)stream;
   if (M <= 0) return LCGAN_EINVAL;
   ProfScope p(KID_LINEAR, 2.0 * M * I * O, 4.0 * I * O, s);
-  const size_t smem = (size_t)std::min(LIN_IC, I) * 33 * sizeof(float);
-  static bool set = false;
-  if (!set) { hipFuncSetAttribute((const void*)linear_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LIN_IC * 33 * 4); set = true; }
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3(cdiv(O, 8), cdiv(M, MT)), dim3(TPB), smem, s, x, w, bias, y, M, I, O, scale, bias_scale, act, gain);
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(cdiv(O, 8), cdiv(M, MT)), dim3(TPB), 0, s, x, w, bias, y, M, I, O, scale, bias_scale, act, gain);
   return launch_status();
 }
 int lcgan_linear_bwd_data(const float* gy, const float* w, float* gx, int M, int I, int O, float scale, void* stream) {

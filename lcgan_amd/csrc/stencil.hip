@@ -22,32 +22,46 @@ static inline dim3 grid1d(long long n) { return dim3((unsigned)((n + TPB - 1) / 
 // ------------------------------------------------------------------------------------------------------------
 // box filter (3x3 mean, zero padding, always /9) fused with activation
 // ------------------------------------------------------------------------------------------------------------
+// Separable sliding window: a thread owns one (column w, 8-channel vector) and walks BOX_RH consecutive rows, keeping the
+// last three horizontal 3-sums in registers: 3 vector loads per output instead of 9 (the 9-tap version was L1-bound, 2.3x
+// off the HBM roofline).
+constexpr int BOX_RH = 8;
 template <typename T>
 __global__ void box3_act_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int act, float gain) {
   const int nvec = C >> 3;
-  const long long total = (long long)B * H * W * nvec;
+  const int strips = (H + BOX_RH - 1) / BOX_RH;
+  const long long total = (long long)B * strips * W * nvec;
   const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
   if (gid >= total) return;
   const int v = (int)(gid % nvec);
-  const long long pix = gid / nvec;
-  const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
-  F8 s = f8_zero();
-#pragma unroll
-  for (int dy = -1; dy <= 1; ++dy) {
-    const int yy = h + dy;
-    if ((unsigned)yy >= (unsigned)H) continue;
+  long long t = gid / nvec;
+  const int w = (int)(t % W); t /= W;
+  const int strip = (int)(t % strips), b = (int)(t / strips);
+  const int h0 = strip * BOX_RH, h1 = min(h0 + BOX_RH, H);
+  const T* xb = x + (size_t)b * H * W * C + v * 8;
+  auto rowsum = [&](int hh) {
+    F8 s = f8_zero();
+    if ((unsigned)hh >= (unsigned)H) return s;
+    const T* row = xb + (size_t)hh * W * C;
 #pragma unroll
     for (int dx = -1; dx <= 1; ++dx) {
       const int xx = w + dx;
       if ((unsigned)xx >= (unsigned)W) continue;
-      const F8 t = Feat<T>::load(x + (((size_t)b * H + yy) * W + xx) * C + v * 8);
+      const F8 q = Feat<T>::load(row + (size_t)xx * C);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s.v[j] += t.v[j];
+      for (int j = 0; j < 8; ++j) s.v[j] += q.v[j];
     }
-  }
+    return s;
+  };
+  F8 r0 = rowsum(h0 - 1), r1 = rowsum(h0);
+  for (int hh = h0; hh < h1; ++hh) {
+    const F8 r2 = rowsum(hh + 1);
+    F8 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) s.v[j] = act_fwd(s.v[j] * (1.f / 9.f), act) * gain;
-  Feat<T>::store(y + (size_t)pix * C + v * 8, s);
+    for (int j = 0; j < 8; ++j) o.v[j] = act_fwd((r0.v[j] + r1.v[j] + r2.v[j]) * (1.f / 9.f), act) * gain;
+    Feat<T>::store(y + (((size_t)b * H + hh) * W + w) * C + v * 8, o);
+    r0 = r1; r1 = r2;
+  }
 }
 
 // gx = box3(gy * act'(y))   (box3 is self-adjoint)
@@ -758,7 +772,8 @@ int lcgan_box3_act(const void* x, void* y, int B, int H, int W, int C, int act, 
   if (C & 7) return LCGAN_EINVAL;
   const long long n = (long long)B * H * W * (C / 8);
   ProfScope p(KID_STENCIL, 0, (double)n * 8 * 2 * (dtype == DT_BF16 ? 2 : 4), s);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(box3_act_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)x, (T*)y, B, H, W, C, act, gain));
+  const long long nthr = (long long)B * ((H + BOX_RH - 1) / BOX_RH) * W * (C / 8);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(box3_act_kernel<T>, grid1d(nthr), dim3(TPB), 0, s, (const T*)x, (T*)y, B, H, W, C, act, gain));
   return launch_status();
 }
 
