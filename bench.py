@@ -125,6 +125,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         loader.train_iteration(w, args, epoch_of(a.warmup + i))
+    w.flush()                                              # postponed all-reduce wait + Adam of the last D step (N > 1)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:

@@ -68,11 +68,13 @@ def load_worker(local_rank, args, gpus_per_node, port_number):
                     f.write("epoch:{}, elapsed:{}, g_loss:{:.6f}, d_loss:{:.6f} \n".format(epoch, elapsed, g_loss, d_loss))
             _barrier(gan_worker)
         if epoch % args.save_interval == 0 and epoch > 0:                 # loader.py:75-80
+            gan_worker.flush()
             if local_rank == 0:
                 gan_worker.save_model()
                 with open(epoch_file_path, "w") as f:
                     f.write(str(epoch))
             _barrier(gan_worker)
         epoch += 1
+    gan_worker.flush()
     if dist.is_initialized():
         dist.destroy_process_group()

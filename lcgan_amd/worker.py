@@ -132,6 +132,29 @@ class WORKER(object):
         self.generator_ema = copy.deepcopy(self.generator)                            # worker.py:40 (keeps the `module.` prefix)
         self.ema = Ema(self.generator, self.generator_ema, self.args.g_ema_decay, self.args.g_ema_start)
         self.best_fid = 9999
+        # Deferred optimiser work (N > 1 only): after a backward the gradient bucket is all-reduced asynchronously (RCCL runs
+        # on its own stream) and the Adam step that needs it is postponed until the OTHER network's parameter-independent
+        # forward has been issued, so the reduction over xGMI overlaps compute (BASELINE.json north_star):
+        #   G all-reduce  ||  D(real) forward of the D step        D all-reduce  ||  G forward(s) of the next G step
+        self._pending = {"g": [], "d": []}
+
+    def flush(self, which=("g", "d")):
+        """Run postponed all-reduce waits / Adam / EMA for the given network(s) (no-op when nothing is pending)."""
+        for k in which:
+            todo, self._pending[k] = self._pending[k], []
+            for fn in todo:
+                fn()
+
+    def _after_backward(self, key, model, optimizer):
+        handle = model.sync_gradients(async_op=True)
+        if model.world_size == 1:
+            optimizer.step()
+            return
+
+        def finish():
+            handle.wait()
+            optimizer.step()
+        self._pending[key].append(finish)
 
     # ---- data -----------------------------------------------------------------------------------------------------
     def prepare_training_dataset(self):
@@ -173,52 +196,65 @@ class WORKER(object):
 
     # ---- D step (worker.py:137-177) -----------------------------------------------------------------------------------
     def train_discriminator(self, epoch):
+        self.flush(("d",))
         self.d_optimizer.zero_grad()
         image, geometry_change, appearance_change = self.sample_data_basket()
         rand1 = self._randn(self.args.geo_noise_dim)
         rand2 = self._randn(self.args.app_noise_dim)
-        with torch.no_grad():                      # G is frozen in this phase (loader.py:50); same numbers, no graph
-            fake_img = self.generator(rand1, rand2)
-        fake_logit, _, _ = self.discriminator(fake_img, False)
+        odd = epoch % 2 == 1
 
-        if epoch % 2 == 1:
+        # (1) everything that only needs D's parameters: the real-image passes.  With N > 1 these overlap G's gradient all-reduce.
+        if odd:
             image = image.detach().clone().requires_grad_(True)                       # worker.py:152
             real_logit, _, _ = self.discriminator(image, False)
-            d_loss = loss.bce_with_logits(real_logit, True) + loss.bce_with_logits(fake_logit, False)
-            if epoch % 8 == 1:
-                d_loss = d_loss + loss.cal_r1_reg(real_logit, image, self.device) * self.args.l_r1
         else:
             real_logit, geometry_feat, appearance_feat = self.discriminator(image, True)
             _, geometry_positive, appearance_negative = self.discriminator(geometry_change, True)
             _, geometry_negative, appearance_positive = self.discriminator(appearance_change, True)
+
+        # (2) G's postponed Adam + EMA (needs the reduced gradients), then the fake batch with the UPDATED generator (worker.py:145-149)
+        self.flush(("g",))
+        with torch.no_grad():                      # G is frozen in this phase (loader.py:50); same numbers, no graph
+            fake_img = self.generator(rand1, rand2)
+        fake_logit, _, _ = self.discriminator(fake_img, False)
+
+        if odd:
+            d_loss = loss.bce_with_logits(real_logit, True) + loss.bce_with_logits(fake_logit, False)
+            if epoch % 8 == 1:
+                d_loss = d_loss + loss.cal_r1_reg(real_logit, image, self.device) * self.args.l_r1
+        else:
             d_adv_loss = loss.bce_with_logits(real_logit, True) + loss.bce_with_logits(fake_logit, False)
             d_aug_loss = (loss.contrastive_loss(geometry_feat, geometry_positive, geometry_negative, self.args.tau)
                           + loss.contrastive_loss(appearance_feat, appearance_positive, appearance_negative, self.args.tau)) * self.args.l_aux
             d_loss = d_adv_loss + d_aug_loss
 
         d_loss.backward()
-        self.discriminator.sync_gradients()
-        self.d_optimizer.step()
+        self._after_backward("d", self.discriminator, self.d_optimizer)
         return LazyLoss(d_loss)
 
     # ---- G step (worker.py:179-214) -----------------------------------------------------------------------------------
     def train_generator(self, epoch):
+        self.flush(("g",))
         self.g_optimizer.zero_grad()
         rand1 = self._randn(self.args.geo_noise_dim)
         rand2 = self._randn(self.args.app_noise_dim)
         resample1 = self._randn(self.args.geo_noise_dim)
         resample2 = self._randn(self.args.app_noise_dim)
 
+        # G forwards need only G's parameters: with N > 1 they overlap the all-reduce of the previous D step's gradients
         if epoch % 2 == 1:
-            logit, _, _ = self.discriminator(self.generator(rand1, rand2), False)
+            images = (self.generator(rand1, rand2),)
+        else:
+            images = (self.generator(rand1, rand2), self.generator(resample1, rand2), self.generator(rand1, resample2))   # worker.py:194-196
+        self.flush(("d",))                         # D's postponed Adam must land before D is evaluated
+
+        if epoch % 2 == 1:
+            logit, _, _ = self.discriminator(images[0], False)
             g_loss = loss.bce_with_logits(logit, True)
         else:
-            anchor_image = self.generator(rand1, rand2)
-            resample_geometry = self.generator(resample1, rand2)
-            resample_appearance = self.generator(rand1, resample2)
-            logit, geometry_feat, appearance_feat = self.discriminator(anchor_image, True)
-            _, geometry_positive, appearance_negative = self.discriminator(resample_geometry, True)
-            _, geometry_negative, appearance_positive = self.discriminator(resample_appearance, True)
+            logit, geometry_feat, appearance_feat = self.discriminator(images[0], True)
+            _, geometry_positive, appearance_negative = self.discriminator(images[1], True)
+            _, geometry_negative, appearance_positive = self.discriminator(images[2], True)
             g_adv_loss = loss.bce_with_logits(logit, True)
             g_aug_loss = (loss.contrastive_loss(geometry_feat, geometry_positive, geometry_negative, self.args.tau)
                           + loss.contrastive_loss(appearance_feat, appearance_positive, appearance_negative, self.args.tau)) * self.args.l_aux
@@ -227,12 +263,14 @@ class WORKER(object):
             g_loss = g_adv_loss + g_aug_loss + g_sparsity_loss
 
         g_loss.backward()
-        self.generator.sync_gradients()
-        self.g_optimizer.step()
+        self._after_backward("g", self.generator, self.g_optimizer)
         return LazyLoss(g_loss)
 
     def ema_update(self, current_step):
-        self.ema.update(current_step)
+        if self._pending["g"]:                      # the EMA reads the UPDATED generator: keep it behind the postponed Adam
+            self._pending["g"].append(lambda: self.ema.update(current_step))
+        else:
+            self.ema.update(current_step)
 
     # ---- checkpoints (worker.py:219-253): `module.`-prefixed state_dicts, same file names ------------------------------
     def _paths(self, best=False):
@@ -241,6 +279,7 @@ class WORKER(object):
         return (f"{d}/gen_model{sfx}.ckpt", f"{d}/gen_ema_model{sfx}.ckpt", f"{d}/disc_model{sfx}.ckpt")
 
     def save_model(self, best=False):
+        self.flush()
         g, e, d = self._paths(best)
         torch.save(self.generator.state_dict(), g)
         torch.save(self.generator_ema.state_dict(), e)
@@ -250,6 +289,7 @@ class WORKER(object):
         self.save_model(best=True)
 
     def load_model(self):
+        self.flush()
         g, e, d = self._paths(bool(getattr(self.args, "best", False)))
         self.generator.load_state_dict(torch.load(g, map_location=self.device))
         self.generator_ema.load_state_dict(torch.load(e, map_location=self.device))

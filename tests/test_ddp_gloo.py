@@ -41,6 +41,7 @@ def _rank_main(rank, world, port, out_dir):
         real_step()
     w.d_optimizer.step = step
     loss_v = w.train_discriminator(1)                     # odd + R1: projection heads unused -> grad None
+    w.flush()                                             # the all-reduce wait + Adam are postponed when N > 1
     torch.save({"grads": captured, "params": {k: v.clone() for k, v in w.discriminator.module.state_dict().items()}, "loss": float(loss_v)},
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
@@ -87,3 +88,53 @@ def test_two_rank_gradient_mean_and_adam(tmp_path):
     for k in r0["params"]:
         assert torch.equal(r0["params"][k], r1["params"][k]), k     # replicas stay in lock-step after Adam
     assert r0["loss"] != r1["loss"]                                 # each rank saw its own half of the batch
+
+
+def _iter_main(rank, world, port, out_dir, defer):
+    import lcgan_amd.kernels as KM
+    from lcgan_amd import config, loader
+    from oracle.hip_emulation import EmulatedKernels
+    from tests.helpers import FixedFeed, make_args, seeded_worker
+    from oracle.weights import seeded_tensor
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    KM.set_backend(EmulatedKernels())
+    config.set_feature_dtype(torch.float32)
+    res, Bl = 16, 2
+    torch.manual_seed(0)                                      # the EMA copy starts from the (random) constructor weights
+    w = seeded_worker(res, Bl, "cpu", gpus=world)
+    w.ema = type(w.ema)(w.generator, w.generator_ema, 0.9, 0)     # re-copy the seeded weights, visible decay
+    feed = FixedFeed(w, Bl, res, "cpu")
+    feed.z = [seeded_tensor((Bl, 64), 700 + 10 * rank + i) for i in range(4)]
+    feed.real = tuple(seeded_tensor((Bl, 3, res, res), 800 + 10 * rank + i, "uniform_pm1") for i in range(3))
+    if not defer:                                             # reference behaviour: wait + step right after the backward
+        def sync_after(key, model, optimizer):
+            model.sync_gradients(async_op=False)
+            optimizer.step()
+        w._after_backward = sync_after
+    args = make_args(res, Bl * world)
+    for epoch in (0, 1, 2):
+        loader.train_iteration(w, args, epoch)
+    w.flush()
+    state = {"g": {k: v.clone() for k, v in w.generator.module.state_dict().items()},
+             "d": {k: v.clone() for k, v in w.discriminator.module.state_dict().items()},
+             "ema": {k: v.clone() for k, v in w.generator_ema.module.state_dict().items()}}
+    torch.save(state, os.path.join(out_dir, f"it_rank{rank}_{int(defer)}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_deferred_allreduce_equals_synchronous(tmp_path):
+    """Three iterations on two ranks: postponing the all-reduce wait + Adam + EMA behind the other network's forward
+    (worker.WORKER._after_backward) must give bit-identical parameters to waiting immediately, and identical replicas."""
+    world = 2
+    for defer in (True, False):
+        mp.spawn(_iter_main, args=(world, _free_port(), str(tmp_path), defer), nprocs=world, join=True)
+    a0, a1 = (torch.load(tmp_path / f"it_rank{r}_1.pt") for r in range(world))
+    b0 = torch.load(tmp_path / "it_rank0_0.pt")
+    for net in ("g", "d", "ema"):
+        for k in a0[net]:
+            if k.startswith("avg_latent"):
+                continue                                        # per-rank buffers
+            assert torch.equal(a0[net][k], a1[net][k]), (net, k)
+            assert torch.equal(a0[net][k], b0[net][k]), (net, k)

@@ -47,6 +47,7 @@ def _rank_main(rank, world, port, out_dir):
         real_step()
     w.g_optimizer.step = step
     loss_v = float(w.train_generator(1))
+    w.flush()
     torch.save({"grads": captured, "params": {k: v.cpu() for k, v in w.generator.module.state_dict().items()}, "loss": loss_v},
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
