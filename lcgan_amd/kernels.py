@@ -47,6 +47,10 @@ class HipKernels:
 
     def __init__(self):
         self.lib = _lib.load()
+        import os
+        for kv in filter(None, os.environ.get("LCGAN_OPTIONS", "").split(",")):     # tuning switches, e.g. LCGAN_OPTIONS="4=1,5=0"
+            k, v = kv.split("=")
+            self.lib.lcgan_set_option(int(k), int(v))
 
     # ------------------------------------------------------------------------------------------------
     @staticmethod

@@ -124,13 +124,21 @@ def test_conv_bwd_data(H, dtype, case):
 @pytest.mark.parametrize("case", CONV_CASES + [(2, 16, 16, 64, 2, 3, 2),
                                   # row-segment bf16 kernel (k = 3, output-side width a multiple of 32)
                                   (1, 64, 64, 128, 256, 3, 2), (1, 32, 64, 72, 40, 3, 1), (2, 32, 64, 64, 2, 3, 2),
-                                  (2, 32, 32, 256, 128, 3, 1)])
+                                  (2, 32, 32, 256, 128, 3, 1),
+                                  # narrow layers (several image rows per chunk) and 1x1 kernels on the row-segment kernel
+                                  (3, 16, 16, 128, 96, 3, 1), (2, 8, 8, 64, 128, 3, 1), (2, 32, 32, 64, 40, 3, 2), (2, 16, 16, 72, 64, 3, 2),
+                                  (2, 64, 64, 128, 256, 1, 1), (2, 16, 16, 256, 128, 1, 1), (1, 128, 128, 64, 32, 1, 1)])
 def test_conv_wgrad(H, dtype, case):
     B, Hh, W, Ci, Co, k, stride = case
     x = feat((B, Hh, W, ceil8(Ci)), dtype, 21, Ci)
     g = feat((B, Hh // stride, W // stride, ceil8(Co)), dtype, 22, Co)
     ref = E.conv_wgrad(x, g, Co, Ci, k, stride)
     check(H.conv_wgrad(x.cuda(), g.cuda(), Co, Ci, k, stride), ref, dtype, "plain")
+    old = H.lib.lcgan_set_option(5, 1)          # also exercise the (default-off) narrow / 1x1 routing of the row-segment kernel
+    try:
+        check(H.conv_wgrad(x.cuda(), g.cuda(), Co, Ci, k, stride), ref, dtype, "plain, narrow routing")
+    finally:
+        H.lib.lcgan_set_option(5, old)
     px, pg = vec((B, ceil8(Ci)), 23), vec((B, ceil8(Co)), 24)
     got, ref_p = H.conv_wgrad(x.cuda(), g.cuda(), Co, Ci, k, stride, pre_x=px.cuda(), pre_g=pg.cuda()), E.conv_wgrad(x, g, Co, Ci, k, stride, pre_x=px, pre_g=pg)
     if dtype == torch.float32:
