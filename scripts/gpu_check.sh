@@ -22,5 +22,7 @@ for s in "$@"; do
     benchq)  step benchq 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
     prof)    export TMPDIR=/tmp
              step prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline ;;
+    prof4)   export TMPDIR=/tmp
+             step prof4 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof4 -- python3 bench.py --steps 2 --warmup 1 --batch 4 --no-cpu-baseline --no-roofline ;;
   esac
 done
