@@ -94,6 +94,14 @@ int lcgan_linear_fwd(const float* x, const float* w, const float* bias, float* y
 int lcgan_linear_bwd_data(const float* gy, const float* w, float* gx, int M, int I, int O, float scale, void* stream);
 int lcgan_linear_wgrad(const float* gy, const float* x, float* gw, int M, int I, int O, float scale, void* stream);
 int lcgan_colsum(const float* gy, float* gb, int M, int O, float scale, void* stream);
+/* L <= 24 linear layers sharing their input x [M,I] -- the style affines of every synthesis layer (SynthesisLayer.linear,
+   custom_layers.py:100,108; all blocks receive the same latent, cnn.py:103-104) in ONE launch.  w/bias/y/gy/gw/gb are HOST
+   arrays of L device pointers, O/scale/bias_scale host arrays of L values; y_l = x w_l^T scale_l + bias_l*bias_scale_l.
+   The backward entry writes gx = sum_l gy_l w_l scale_l (if gx), gw_l = scale_l gy_l^T x (if gw), gb_l = bias_scale_l colsum(gy_l) (if gb). */
+int lcgan_linear_group_fwd(const float* x, const float* const* w, const float* const* bias, float* const* y, const int* O,
+                           const float* scale, const float* bias_scale, int L, int M, int I, int act, float gain, void* stream);
+int lcgan_linear_group_bwd(const float* const* gy, const float* x, const float* const* w, const int* O, const float* scale,
+                           const float* bias_scale, int L, int M, int I, float* gx, float* const* gw, float* const* gb, void* stream);
 int lcgan_act_bwd_f32(const float* gy, const float* y, float* gz, long long n, int act, float gain, void* stream);
 /* demodulation statistic custom_layers.py:67 : d[b,o] = rsqrt(sum_c s^2 wsq[o,c] + eps), d is [B][Os] */
 int lcgan_demod_fwd(const float* s, const float* wsq, float* d, int B, int C, int O, int Os, float eps, void* stream);

@@ -110,8 +110,14 @@ class Generator(torch.nn.Module):
             geometry_code = self.avg_latent1.lerp(geometry_code, w_psi)
             appearance_code = self.avg_latent2.lerp(appearance_code, w_psi)
 
-        # every block receives the SAME latents (the reference repeats them, cnn.py:103-104): pass them without copies
+        # every block receives the SAME latents (the reference repeats them, cnn.py:103-104), so the style affines of all
+        # layers (custom_layers.py:100,108) are two grouped launches: 6 flow layers on the geometry code, 14 on the appearance code
+        blocks = list(self.model)
+        g_styles = ops.grouped_linear(geometry_code, [b.flow_layer.linear for b in blocks])
+        a_styles = ops.grouped_linear(appearance_code, [l.linear for b in blocks for l in (b.modulated_conv0, b.modulated_conv1)]
+                                      + [self.rgb_layer.modulated_conv0.linear, self.rgb_layer.modulated_conv1.linear])
         x = ops.ConstInputFn.apply(self.const, batch_size, config.feature_dtype())     # cnn.py:106
-        for block in self.model:
-            x = block(x, (geometry_code,), (appearance_code, appearance_code))
-        return self.rgb_layer(x, (appearance_code, appearance_code))
+        for i, block in enumerate(blocks):
+            x = block(x, (geometry_code,), (appearance_code, appearance_code),
+                      styles=(g_styles[i], a_styles[2 * i], a_styles[2 * i + 1]))
+        return self.rgb_layer(x, (appearance_code, appearance_code), styles=(a_styles[-2], a_styles[-1]))

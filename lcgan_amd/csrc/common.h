@@ -21,7 +21,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define ACT_TANH 2
 #define LRELU_SLOPE 0.2f
 
-static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline __host__ __device__ int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- 8-wide feature vectors: the unit every NHWC kernel moves (16 B of bf16, 32 B of f32) -------------
 struct F8 { float v[8]; };

@@ -17,21 +17,40 @@ namespace {
 constexpr int TPB = 256;
 constexpr int MT = 32;     // rows of the small-M GEMMs handled per block
 
-// y[m,o] = act(scale * sum_i x[m,i] w[o,i] + bias[o]*bias_scale) * gain
+// A group of L linear layers that share their input x [M,I] (L = 1: a plain linear layer).  The table travels BY VALUE in the
+// kernel arguments, so a grouped launch costs no host->device copy: the 20 style affines of a generator pass are 2 launches.
+constexpr int LIN_MAXL = 24;
+struct LinGroup {
+  const float* w[LIN_MAXL];      // [O_l, I]
+  const float* aux[LIN_MAXL];    // forward: bias_l [O_l] (or null) ; backward: gy_l [M, O_l]
+  float* out[LIN_MAXL];          // forward: y_l [M, O_l] ; wgrad: gw_l [O_l, I] ; colsum: gb_l [O_l]
+  int O[LIN_MAXL];
+  float scale[LIN_MAXL];         // equalized-lr weight scale c_l
+  float bscale[LIN_MAXL];        // bias scale (lr_mul)
+};
+
+// y_l[m,o] = act(scale_l * sum_i x[m,i] w_l[o,i] + bias_l[o]*bscale_l) * gain
 // Block = 8 output columns x 32 rows of x.  Per 256-wide i-chunk BOTH operands are staged in LDS with all loads issued at once
 // (x transposed [i][m] padded, the 8 weight rows [o][i]); the inner loop then runs from LDS only (weight reads are broadcasts).
-// The first version chained 128 dependent global weight loads per thread (~50 us per launch for a 512x512 layer).
+// isplit > 1 (long rows: the discriminator epilogue's 8192-wide linear) spreads the i range over isplit blocks that add their
+// raw partial sums into a zeroed y; linear_finalize_kernel then applies bias / activation.
 constexpr int LIN_IC = 256;
-__global__ __launch_bounds__(TPB) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          const float* __restrict__ bias, float* __restrict__ y,
-                                                          int M, int I, int O, float scale, float bias_scale, int act, float gain) {
+__global__ __launch_bounds__(TPB) void linear_fwd_kernel(const float* __restrict__ x, const LinGroup g, int M, int I, int isplit,
+                                                          int act, float gain) {
   __shared__ float xs[LIN_IC * 33];
   __shared__ float ws[8 * LIN_IC];
+  const int l = blockIdx.z, O = g.O[l];
+  const int o0 = blockIdx.x * 8;
+  if (o0 >= O) return;
+  const float* __restrict__ w = g.w[l];
   const int m = threadIdx.x & 31, ol = threadIdx.x >> 5;
-  const int o0 = blockIdx.x * 8, m0 = blockIdx.y * MT;
+  const int mt = blockIdx.y / isplit, sp = blockIdx.y - mt * isplit;
+  const int m0 = mt * MT;
+  const int ilen = cdiv(cdiv(I, isplit), LIN_IC) * LIN_IC;
+  const int ibeg = sp * ilen, iend = min(I, ibeg + ilen);
   float acc = 0.f;
-  for (int i0 = 0; i0 < I; i0 += LIN_IC) {
-    const int ic = min(LIN_IC, I - i0);
+  for (int i0 = ibeg; i0 < iend; i0 += LIN_IC) {
+    const int ic = min(LIN_IC, iend - i0);
     __syncthreads();
     // staging: thread t walks column ii = t (+256 ...) of every row: no integer division, coalesced along i
     for (int ii = threadIdx.x; ii < ic; ii += TPB) {
@@ -47,69 +66,84 @@ __global__ __launch_bounds__(TPB) void linear_fwd_kernel(const float* __restrict
   }
   const int o = o0 + ol, mrow = m0 + m;
   if (o < O && mrow < M) {
-    const float bv = bias ? bias[o] * bias_scale : 0.f;
-    y[(size_t)mrow * O + o] = act_fwd(acc * scale + bv, act) * gain;
+    float* y = g.out[l] + (size_t)mrow * O + o;
+    if (isplit > 1) { atomicAdd(y, acc * g.scale[l]); return; }
+    const float bv = g.aux[l] ? g.aux[l][o] * g.bscale[l] : 0.f;
+    *y = act_fwd(acc * g.scale[l] + bv, act) * gain;
   }
 }
 
-// gx[m,i] = scale * sum_o gy[m,o] w[o,i]
-// Block = 64 columns i x 32 rows m (4 waves x 8 rows each).  gy is staged transposed in LDS ([o][m]) so each weight element
-// (coalesced along i) meets 8 broadcast LDS values; no atomics, gx is written once.
-constexpr int LIN_OC = 512;                 // o-chunk staged per pass (512 x 32 floats = 64 KB)
-__global__ __launch_bounds__(TPB) void linear_bwd_data_kernel(const float* __restrict__ gy, const float* __restrict__ w,
-                                                               float* __restrict__ gx, int M, int I, int O, float scale) {
-  extern __shared__ float gs[];              // [LIN_OC][32]
+__global__ void linear_finalize_kernel(float* __restrict__ y, const float* __restrict__ bias, float bscale, int M, int O, int act,
+                                       float gain) {
+  const int idx = blockIdx.x * TPB + threadIdx.x;
+  if (idx >= M * O) return;
+  const float bv = bias ? bias[idx % O] * bscale : 0.f;
+  y[idx] = act_fwd(y[idx] + bv, act) * gain;
+}
+
+// gx[m,i] (+)= sum_l scale_l * sum_o gy_l[m,o] w_l[o,i]
+// Block = 64 columns i x 32 rows m (4 waves x 8 rows each) x one 64-wide o-chunk of one layer: the chunk of gy is staged
+// transposed in LDS ([o][m]) so each weight element (coalesced along i) meets 8 broadcast LDS values.  All (layer, chunk)
+// blocks add into a zeroed gx; a single-chunk launch stores directly.  (The first version looped over all of O in 8 blocks:
+// 53 us for a 512x512 layer.)
+constexpr int LIN_OC = 64;
+__global__ __launch_bounds__(TPB) void linear_bwd_data_kernel(const LinGroup g, float* __restrict__ gx, int M, int I, int nchunk,
+                                                               int accumulate) {
+  __shared__ float gs[LIN_OC * 32];
+  const int l = blockIdx.y / nchunk, o0 = (blockIdx.y - l * nchunk) * LIN_OC, O = g.O[l];
+  if (o0 >= O) return;
+  const int oc = min(LIN_OC, O - o0);
+  const float* __restrict__ gy = g.aux[l];
   const int il = threadIdx.x & 63, mg = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + il, m0 = blockIdx.y * MT;
-  const bool ivalid = i < I;
+  const int i = blockIdx.x * 64 + il, m0 = blockIdx.z * MT;
+  for (int idx = threadIdx.x; idx < oc * MT; idx += TPB) {             // lanes walk m: conflict-free LDS writes
+    const int oo = idx >> 5, mm = idx & 31;
+    gs[idx] = (m0 + mm < M) ? gy[(size_t)(m0 + mm) * O + o0 + oo] : 0.f;
+  }
+  __syncthreads();
+  if (i >= I) return;
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  for (int o0 = 0; o0 < O; o0 += LIN_OC) {
-    const int oc = min(LIN_OC, O - o0);
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < oc * MT; idx += TPB) {           // lanes walk m: conflict-free LDS writes
-      const int oo = idx >> 5, mm = idx & 31;
-      gs[idx] = (m0 + mm < M) ? gy[(size_t)(m0 + mm) * O + o0 + oo] : 0.f;
-    }
-    __syncthreads();
-    if (ivalid) {
-      const float* wc = w + (size_t)o0 * I + i;
-#pragma unroll 4
-      for (int oo = 0; oo < oc; ++oo) {
-        const float wv = wc[(size_t)oo * I];
-        const f32x4 g0 = *(const f32x4*)(gs + oo * 32 + mg * 8), g1 = *(const f32x4*)(gs + oo * 32 + mg * 8 + 4);
-        acc[0] += g0[0] * wv; acc[1] += g0[1] * wv; acc[2] += g0[2] * wv; acc[3] += g0[3] * wv;
-        acc[4] += g1[0] * wv; acc[5] += g1[1] * wv; acc[6] += g1[2] * wv; acc[7] += g1[3] * wv;
-      }
-    }
+  const float* wc = g.w[l] + (size_t)o0 * I + i;
+#pragma unroll 8
+  for (int oo = 0; oo < oc; ++oo) {
+    const float wv = wc[(size_t)oo * I];
+    const f32x4 g0 = *(const f32x4*)(gs + oo * 32 + mg * 8), g1 = *(const f32x4*)(gs + oo * 32 + mg * 8 + 4);
+    acc[0] += g0[0] * wv; acc[1] += g0[1] * wv; acc[2] += g0[2] * wv; acc[3] += g0[3] * wv;
+    acc[4] += g1[0] * wv; acc[5] += g1[1] * wv; acc[6] += g1[2] * wv; acc[7] += g1[3] * wv;
   }
-  if (ivalid) {
+  const float sc = g.scale[l];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int mrow = m0 + mg * 8 + j;
-      if (mrow < M) gx[(size_t)mrow * I + i] = acc[j] * scale;
+  for (int j = 0; j < 8; ++j) {
+    const int mrow = m0 + mg * 8 + j;
+    if (mrow < M) {
+      if (accumulate) atomicAdd(gx + (size_t)mrow * I + i, acc[j] * sc);
+      else gx[(size_t)mrow * I + i] = acc[j] * sc;
     }
   }
 }
 
-// gw[o,i] = scale * sum_m gy[m,o] x[m,i]
-__global__ __launch_bounds__(TPB) void linear_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
-                                                            float* __restrict__ gw, int M, int I, int O, float scale) {
+// gw_l[o,i] = scale_l * sum_m gy_l[m,o] x[m,i]
+__global__ __launch_bounds__(TPB) void linear_wgrad_kernel(const LinGroup g, const float* __restrict__ x, int M, int I) {
+  const int l = blockIdx.z, O = g.O[l];
   const int i = blockIdx.x * TPB + threadIdx.x, o = blockIdx.y;
-  if (i >= I) return;
+  if (i >= I || o >= O) return;
+  const float* __restrict__ gy = g.aux[l];
   float acc = 0.f;
   for (int m = 0; m < M; ++m) acc += gy[(size_t)m * O + o] * x[(size_t)m * I + i];
-  gw[(size_t)o * I + i] = acc * scale;
+  g.out[l][(size_t)o * I + i] = acc * g.scale[l];
 }
 
-// gb[o] = bias_scale * sum_m gy[m,o]
-__global__ void colsum_kernel(const float* __restrict__ gy, float* __restrict__ gb, int M, int O, float scale) {
+// gb_l[o] = bscale_l * sum_m gy_l[m,o]
+__global__ void colsum_kernel(const LinGroup g, int M) {
+  const int l = blockIdx.y, O = g.O[l];
   const int o = blockIdx.x * TPB + threadIdx.x;
   if (o >= O) return;
+  const float* __restrict__ gy = g.aux[l];
   float acc = 0.f;
   for (int m = 0; m < M; ++m) acc += gy[(size_t)m * O + o];
-  gb[o] = acc * scale;
+  g.out[l][o] = acc * g.bscale[l];
 }
 
 // gz = gy * act'(y)   on fp32 vectors
@@ -363,34 +397,90 @@ __global__ __launch_bounds__(TPB) void multi_tensor_kernel(const MTDesc* __restr
 
 extern "C" {
 
+// ---- linear layers (single and grouped).  Grouped tables are host arrays of L device pointers / sizes.
+static int linear_group_fwd(const float* x, const LinGroup& g, int L, int maxO, int M, int I, int act, float gain, hipStream_t s) {
+  const int isplit = (L == 1 && I >= 2048) ? std::min(16, I / 1024) : 1;
+  if (isplit > 1) hipMemsetAsync(g.out[0], 0, (size_t)M * g.O[0] * sizeof(float), s);
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(cdiv(maxO, 8), cdiv(M, MT) * isplit, L), dim3(TPB), 0, s, x, g, M, I, isplit, act, gain);
+  if (isplit > 1)
+    hipLaunchKernelGGL(linear_finalize_kernel, dim3(cdiv(M * g.O[0], TPB)), dim3(TPB), 0, s, g.out[0], g.aux[0], g.bscale[0], M, g.O[0],
+                       act, gain);
+  return launch_status();
+}
+static int linear_group_bwd_data(const LinGroup& g, int L, int maxO, float* gx, int M, int I, hipStream_t s) {
+  const int nchunk = cdiv(maxO, LIN_OC);
+  const int acc = (L * nchunk > 1) ? 1 : 0;
+  if (acc) hipMemsetAsync(gx, 0, (size_t)M * I * sizeof(float), s);
+  hipLaunchKernelGGL(linear_bwd_data_kernel, dim3(cdiv(I, 64), L * nchunk, cdiv(M, MT)), dim3(TPB), 0, s, g, gx, M, I, nchunk, acc);
+  return launch_status();
+}
+
 int lcgan_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int I, int O,
                      float scale, float bias_scale, int act, float gain, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (M <= 0) return LCGAN_EINVAL;
   ProfScope p(KID_LINEAR, 2.0 * M * I * O, 4.0 * I * O, s);
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3(cdiv(O, 8), cdiv(M, MT)), dim3(TPB), 0, s, x, w, bias, y, M, I, O, scale, bias_scale, act, gain);
-  return launch_status();
+  LinGroup g = {};
+  g.w[0] = w; g.aux[0] = bias; g.out[0] = y; g.O[0] = O; g.scale[0] = scale; g.bscale[0] = bias_scale;
+  return linear_group_fwd(x, g, 1, O, M, I, act, gain, s);
 }
 int lcgan_linear_bwd_data(const float* gy, const float* w, float* gx, int M, int I, int O, float scale, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (M <= 0) return LCGAN_EINVAL;
   ProfScope p(KID_LINEAR, 2.0 * M * I * O, 4.0 * I * O, s);
-  const size_t smem = (size_t)std::min(LIN_OC, O) * 32 * sizeof(float);
-  static bool set = false;
-  if (!set) { hipFuncSetAttribute((const void*)linear_bwd_data_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LIN_OC * 32 * 4); set = true; }
-  hipLaunchKernelGGL(linear_bwd_data_kernel, dim3(cdiv(I, 64), cdiv(M, MT)), dim3(TPB), smem, s, gy, w, gx, M, I, O, scale);
-  return launch_status();
+  LinGroup g = {};
+  g.w[0] = w; g.aux[0] = gy; g.O[0] = O; g.scale[0] = scale;
+  return linear_group_bwd_data(g, 1, O, gx, M, I, s);
 }
 int lcgan_linear_wgrad(const float* gy, const float* x, float* gw, int M, int I, int O, float scale, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(KID_LINEAR, 2.0 * M * I * O, 4.0 * I * O, s);
-  hipLaunchKernelGGL(linear_wgrad_kernel, dim3(cdiv(I, TPB), O), dim3(TPB), 0, s, gy, x, gw, M, I, O, scale);
+  LinGroup g = {};
+  g.aux[0] = gy; g.out[0] = gw; g.O[0] = O; g.scale[0] = scale;
+  hipLaunchKernelGGL(linear_wgrad_kernel, dim3(cdiv(I, TPB), O, 1), dim3(TPB), 0, s, g, x, M, I);
   return launch_status();
 }
 int lcgan_colsum(const float* gy, float* gb, int M, int O, float scale, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(KID_SMALL, 0, 0, s);
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(O, TPB)), dim3(TPB), 0, s, gy, gb, M, O, scale);
+  LinGroup g = {};
+  g.aux[0] = gy; g.out[0] = gb; g.O[0] = O; g.bscale[0] = scale;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(O, TPB), 1), dim3(TPB), 0, s, g, M);
+  return launch_status();
+}
+int lcgan_linear_group_fwd(const float* x, const float* const* w, const float* const* bias, float* const* y, const int* O,
+                           const float* scale, const float* bias_scale, int L, int M, int I, int act, float gain, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (M <= 0 || L <= 0 || L > LIN_MAXL) return LCGAN_EINVAL;
+  LinGroup g = {};
+  int maxO = 0; double sumO = 0;
+  for (int l = 0; l < L; ++l) {
+    g.w[l] = w[l]; g.aux[l] = bias ? bias[l] : nullptr; g.out[l] = y[l]; g.O[l] = O[l]; g.scale[l] = scale[l];
+    g.bscale[l] = bias_scale[l]; maxO = std::max(maxO, O[l]); sumO += O[l];
+  }
+  ProfScope p(KID_LINEAR, 2.0 * M * I * sumO, 4.0 * I * sumO, s);
+  return linear_group_fwd(x, g, L, maxO, M, I, act, gain, s);
+}
+int lcgan_linear_group_bwd(const float* const* gy, const float* x, const float* const* w, const int* O, const float* scale,
+                           const float* bias_scale, int L, int M, int I, float* gx, float* const* gw, float* const* gb, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (M <= 0 || L <= 0 || L > LIN_MAXL) return LCGAN_EINVAL;
+  LinGroup g = {};
+  int maxO = 0; double sumO = 0;
+  for (int l = 0; l < L; ++l) {
+    g.w[l] = w[l]; g.aux[l] = gy[l]; g.O[l] = O[l]; g.scale[l] = scale[l]; g.bscale[l] = bias_scale[l];
+    maxO = std::max(maxO, O[l]); sumO += O[l];
+  }
+  ProfScope p(KID_LINEAR, (gx ? 2.0 : 0.0) * M * I * sumO + (gw ? 2.0 : 0.0) * M * I * sumO, 4.0 * I * sumO, s);
+  if (gx) { const int rc = linear_group_bwd_data(g, L, maxO, gx, M, I, s); if (rc) return rc; }
+  if (gw) {
+    for (int l = 0; l < L; ++l) g.out[l] = gw[l];
+    hipLaunchKernelGGL(linear_wgrad_kernel, dim3(cdiv(I, TPB), maxO, L), dim3(TPB), 0, s, g, x, M, I);
+  }
+  if (gb) {
+    for (int l = 0; l < L; ++l) g.out[l] = gb[l];
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(maxO, TPB), L), dim3(TPB), 0, s, g, M);
+  }
   return launch_status();
 }
 int lcgan_act_bwd_f32(const float* gy, const float* y, float* gz, long long n, int act, float gain, void* stream) {

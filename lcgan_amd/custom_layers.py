@@ -125,8 +125,8 @@ class SynthesisLayer(nn.Module):
         self.linear = EqualizedLinear(self.latent_dim, in_features, bias=1.0, lr_mul=1.0)
         self.modulated_conv = ModulatedConv2d(in_features, out_features, kernel_size, up=self.up, lr_mul=1.0)
 
-    def forward(self, x, latent, act=ACT_NONE, gain=1.0):
-        s = self.linear(latent)
+    def forward(self, x, latent, act=ACT_NONE, gain=1.0, style=None):
+        s = self.linear(latent) if style is None else style      # style: this layer's affine, precomputed by ops.grouped_linear
         if self.modulated_conv.kernel_size == 1:
             return self.modulated_conv.forward_to_rgb(x, s)
         return self.modulated_conv(x, s, act, gain)
@@ -156,14 +156,17 @@ class SynthesisBlock(nn.Module):
         self.gain = np.sqrt(2)
         self.skip_gain = np.sqrt(0.5)
 
-    def forward(self, x, g_latent, a_latent):
+    def style_layers(self):
+        return (self.flow_layer, self.modulated_conv0, self.modulated_conv1)
+
+    def forward(self, x, g_latent, a_latent, styles=(None, None, None)):
         (g_lat,) = _split_latents(g_latent, 1)
         a0, a1 = _split_latents(a_latent, 2)
         # flow field: up-conv (2 channels, padded to 8) -> box filter -> tanh                 :149-151
-        flow = ops.Box3ActFn.apply(self.flow_layer(x, g_lat), ACT_TANH, 1.0)
+        flow = ops.Box3ActFn.apply(self.flow_layer(x, g_lat, style=styles[0]), ACT_TANH, 1.0)
         # main branch: up-conv -> box filter -> lrelu*sqrt2 -> conv -> lrelu                    :153-158
-        h = ops.Box3ActFn.apply(self.modulated_conv0(x, a0), ACT_LRELU, SQRT2)
-        h = self.modulated_conv1(h, a1, ACT_LRELU, 1.0)
+        h = ops.Box3ActFn.apply(self.modulated_conv0(x, a0, style=styles[1]), ACT_LRELU, SQRT2)
+        h = self.modulated_conv1(h, a1, ACT_LRELU, 1.0, style=styles[2])
         # skip branch: 1x1 conv * sqrt(.5) at low res, then nearest x2 + box filter fused with the add     :145-147,159
         skip = self.skip_layer(x, ACT_NONE, SQRT_HALF)
         y = ops.Up2BoxAddFn.apply(skip, h)
@@ -181,10 +184,10 @@ class ToRGBBlock(nn.Module):
         self.modulated_conv0 = SynthesisLayer(in_features, in_features, a_latent_dim, resolution, use_noise=self.use_noise)
         self.modulated_conv1 = SynthesisLayer(in_features, out_features, a_latent_dim, resolution, kernel_size=1, use_noise=False)
 
-    def forward(self, x, a_latent):
+    def forward(self, x, a_latent, styles=(None, None)):
         a0, a1 = _split_latents(a_latent, 2)
-        x = self.modulated_conv0(x, a0, ACT_LRELU, 1.0)
-        return self.modulated_conv1(x, a1)
+        x = self.modulated_conv0(x, a0, ACT_LRELU, 1.0, style=styles[0])
+        return self.modulated_conv1(x, a1, style=styles[1])
 
 
 class DiscriminatorBlock(nn.Module):

@@ -42,11 +42,35 @@ class PreparedWeight:
         self.buf, self.parts, self.N, self.Kpad, self.k = buf, parts, N, Kpad, k
 
 
+class _ZeroPool:
+    """Zero-initialised fp32 scratch carved out of one pre-cleared slab: the atomically accumulated outputs (weight / bias /
+    style gradients) are many and small, and one fill per 64 MB replaces ~370 fill launches per iteration.  A slice keeps
+    its slab alive through torch's storage refcount, so a slab is only recycled by the caching allocator once every
+    tensor carved from it is gone."""
+    SLAB = 1 << 24          # floats
+
+    def __init__(self):
+        self.buf, self.off = None, 0
+
+    def take(self, shape, device) -> Tensor:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if n > self.SLAB // 4:
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        if self.buf is None or self.off + n > self.SLAB or self.buf.device != device:
+            self.buf, self.off = torch.zeros(self.SLAB, dtype=torch.float32, device=device), 0
+        v = self.buf[self.off:self.off + n].view(shape)
+        self.off += (n + 63) // 64 * 64                     # keep every slice 256-byte aligned
+        return v
+
+
 class HipKernels:
     name = "hip"
 
     def __init__(self):
         self.lib = _lib.load()
+        self._zeros = _ZeroPool()
         import os
         for kv in filter(None, os.environ.get("LCGAN_OPTIONS", "").split(",")):     # tuning switches, e.g. LCGAN_OPTIONS="4=1,5=0"
             k, v = kv.split("=")
@@ -113,7 +137,7 @@ class HipKernels:
         self._chk(x, g, pre_x, pre_g)
         B, Hx, Wx, Cx = x.shape
         _, Hg, Wg, Cg = g.shape
-        gwp = torch.zeros((k * k, A, Bc), dtype=torch.float32, device=x.device)
+        gwp = self._zeros.take((k * k, A, Bc), x.device)
         self._call("lcgan_conv_wgrad", x.data_ptr(), g.data_ptr(), gwp.data_ptr(), B, Hx, Wx, Cx, Hg, Wg, Cg, A, Bc, k, stride,
                    _p(pre_x), _p(pre_g), dt_code(x.dtype), self._stream())
         return gwp
@@ -168,8 +192,8 @@ class HipKernels:
         self._chk(gy, y, bias)
         B, H, W, Cc = gy.shape
         gz = torch.empty_like(gy) if want_gz else None
-        gbias = torch.zeros((clog,), dtype=torch.float32, device=gy.device) if want_gbias else None
-        gdq = torch.zeros((B, Cc), dtype=torch.float32, device=gy.device) if want_gdq else None
+        gbias = self._zeros.take((clog,), gy.device) if want_gbias else None
+        gdq = self._zeros.take((B, Cc), gy.device) if want_gdq else None
         self._call("lcgan_act_bwd_reduce", gy.data_ptr(), _p(y), _p(gz), _p(bias), float(bias_scale), _p(gbias), _p(gdq),
                    B, H * W, Cc, clog, act, float(gain), dt_code(gy.dtype), self._stream())
         return gz, gbias, gdq
@@ -178,7 +202,7 @@ class HipKernels:
         """u <- s*u IN PLACE; returns (u, gs[b,c] = sum_p x*u_old)"""
         self._chk(u, x, s)
         B, H, W, Cc = u.shape
-        gs = torch.zeros((B, Cc), dtype=torch.float32, device=u.device)
+        gs = self._zeros.take((B, Cc), u.device)
         self._call("lcgan_scale_reduce", u.data_ptr(), x.data_ptr(), s.data_ptr(), gs.data_ptr(), B, H * W, Cc, dt_code(u.dtype),
                    self._stream())
         return u, gs
@@ -250,7 +274,7 @@ class HipKernels:
     def rgb_wgrad(self, img: Tensor, feat: Tensor, per_sample: bool) -> Tensor:
         self._chk(img, feat)
         B, H, W, Cc = feat.shape
-        gw = torch.zeros((B if per_sample else 1, 3, Cc), dtype=torch.float32, device=feat.device)
+        gw = self._zeros.take((B if per_sample else 1, 3, Cc), feat.device)
         self._call("lcgan_rgb_wgrad", img.data_ptr(), feat.data_ptr(), gw.data_ptr(), B, H * W, Cc, int(per_sample),
                    dt_code(feat.dtype), self._stream())
         return gw
@@ -306,6 +330,49 @@ class HipKernels:
         self._call("lcgan_colsum", gy.data_ptr(), gb.data_ptr(), M, O, float(scale), self._stream())
         return gb
 
+    @staticmethod
+    def _ptr_array(ts):
+        import ctypes as C
+        return (C.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+    def linear_group_fwd(self, x: Tensor, ws, biases, scales, bias_scales, act: int = ACT_NONE, gain: float = 1.0):
+        """L linear layers sharing x [M,I]: -> [y_l [M,O_l]] from one launch"""
+        import ctypes as C
+        self._chk(x, *ws, *biases)
+        M, I = x.shape
+        L = len(ws)
+        Os = [int(w.shape[0]) for w in ws]
+        flat = torch.empty((M * sum(Os),), dtype=torch.float32, device=x.device)
+        ys, off = [], 0
+        for O in Os:
+            ys.append(flat[off:off + M * O].view(M, O))
+            off += M * O
+        self._call("lcgan_linear_group_fwd", x.data_ptr(), self._ptr_array(ws), self._ptr_array(biases), self._ptr_array(ys),
+                   (C.c_int * L)(*Os), (C.c_float * L)(*scales), (C.c_float * L)(*bias_scales), L, M, I, act, float(gain),
+                   self._stream())
+        return ys
+
+    def linear_group_bwd(self, gys, x: Tensor, ws, scales, bias_scales, want_gx: bool = True):
+        """-> (gx [M,I] | None, [gw_l [O_l,I]], [gb_l [O_l]])"""
+        import ctypes as C
+        self._chk(x, *gys, *ws)
+        M, I = x.shape
+        L = len(ws)
+        Os = [int(w.shape[0]) for w in ws]
+        gx = torch.empty((M, I), dtype=torch.float32, device=x.device) if want_gx else None
+        flat = torch.empty((sum(Os) * (I + 1),), dtype=torch.float32, device=x.device)
+        gws, gbs, off = [], [], 0
+        for O in Os:
+            gws.append(flat[off:off + O * I].view(O, I))
+            off += O * I
+        for O in Os:
+            gbs.append(flat[off:off + O])
+            off += O
+        self._call("lcgan_linear_group_bwd", self._ptr_array(gys), x.data_ptr(), self._ptr_array(ws), (C.c_int * L)(*Os),
+                   (C.c_float * L)(*scales), (C.c_float * L)(*bias_scales), L, M, I, _p(gx), self._ptr_array(gws),
+                   self._ptr_array(gbs), self._stream())
+        return gx, gws, gbs
+
     def act_bwd_f32(self, gy: Tensor, y: Tensor, act: int, gain: float) -> Tensor:
         self._chk(gy, y)
         gz = torch.empty_like(gy)
@@ -316,7 +383,7 @@ class HipKernels:
         self._chk(s, wsq)
         B, Cc = s.shape
         O = wsq.shape[0]
-        d = torch.zeros((B, ostride), dtype=torch.float32, device=s.device)
+        d = self._zeros.take((B, ostride), s.device)
         self._call("lcgan_demod_fwd", s.data_ptr(), wsq.data_ptr(), d.data_ptr(), B, Cc, O, ostride, float(eps), self._stream())
         return d
 
@@ -377,7 +444,7 @@ class HipKernels:
 
     def powsum(self, x: Tensor, pw: int, coef: float) -> Tensor:
         self._chk(x)
-        out = torch.zeros((), dtype=torch.float32, device=x.device)
+        out = self._zeros.take((), x.device)
         self._call("lcgan_powsum", x.data_ptr(), x.numel(), pw, float(coef), out.data_ptr(), self._stream())
         return out
 

@@ -374,6 +374,45 @@ class LinearFn(Function):
         return gx, gw, gb, None, None, None, None
 
 
+class GroupedLinearFn(Function):
+    """y_l = scale_l * x @ w_l^T + bias_l * bias_scale_l for L layers sharing x (the generator's style affines: every block gets
+    the same latent, cnn.py:103-104).  One launch forward, three backward (gx, all gw_l, all gb_l); first order only -- the
+    R1 double backward never reaches the generator."""
+
+    @staticmethod
+    def forward(ctx, x, scales, bias_scales, *wb):
+        ws, bs = wb[0::2], wb[1::2]
+        ctx.save_for_backward(x, *ws)
+        ctx.cfg = (tuple(scales), tuple(bias_scales))
+        return tuple(_K().linear_group_fwd(x, ws, bs, scales, bias_scales, ACT_NONE, 1.0))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gys):
+        x, *ws = ctx.saved_tensors
+        scales, bias_scales = ctx.cfg
+        gys = [torch.zeros((x.shape[0], w.shape[0]), dtype=torch.float32, device=x.device) if g is None else g.contiguous()
+               for g, w in zip(gys, ws)]
+        gx, gws, gbs = _K().linear_group_bwd(gys, x, ws, scales, bias_scales, want_gx=ctx.needs_input_grad[0])
+        out = [gx, None, None]
+        for gw, gb in zip(gws, gbs):
+            out += [gw, gb]
+        return tuple(out)
+
+
+def grouped_linear(x, linears):
+    """[EqualizedLinear(x) for each module] through GroupedLinearFn (in slices of 24 layers)."""
+    x = x.contiguous()
+    ys = []
+    for i in range(0, len(linears), 24):
+        part = linears[i:i + 24]
+        wb = []
+        for m in part:
+            wb += [m.weight.weight, m.bias]
+        ys += list(GroupedLinearFn.apply(x, [m.weight.c for m in part], [m.lr_mul for m in part], *wb))
+    return ys
+
+
 class LinearTFn(Function):
     """gx = scale * g @ w"""
 

@@ -277,6 +277,19 @@ class EmulatedKernels:
     def colsum(self, gy, scale):
         return gy.sum(0) * scale
 
+    def linear_group_fwd(self, x, ws, biases, scales, bias_scales, act=0, gain=1.0):
+        return [self.linear_fwd(x, w, b, sc, bs, act, gain) for w, b, sc, bs in zip(ws, biases, scales, bias_scales)]
+
+    def linear_group_bwd(self, gys, x, ws, scales, bias_scales, want_gx=True):
+        gx = None
+        if want_gx:
+            gx = torch.zeros_like(x)
+            for gy, w, sc in zip(gys, ws, scales):
+                gx = gx + self.linear_bwd_data(gy, w, sc)
+        gws = [self.linear_wgrad(gy, x, sc) for gy, sc in zip(gys, scales)]
+        gbs = [self.colsum(gy, bs) for gy, bs in zip(gys, bias_scales)]
+        return gx, gws, gbs
+
     def act_bwd_f32(self, gy, y, act, gain):
         return gy * act_grad_from_out(y, act, gain)
 

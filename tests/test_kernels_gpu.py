@@ -297,6 +297,29 @@ def test_linear(H, M, I, O):
     check(H.act_bwd_f32(gy.cuda(), x[:, :1].expand(M, O).contiguous().cuda(), 1, 1.0), E.act_bwd_f32(gy, x[:, :1].expand(M, O), 1, 1.0), f32, "act bwd")
 
 
+@pytest.mark.parametrize("M,I,Os", [(32, 512, [512, 512, 256, 128, 8]), (4, 64, [64] * 24), (37, 100, [3, 130])])
+def test_linear_group(H, M, I, Os):
+    """grouped launches (the generator's style affines) against the per-layer emulation"""
+    g = torch.Generator().manual_seed(92)
+    x = torch.randn(M, I, generator=g)
+    ws = [torch.randn(O, I, generator=g) for O in Os]
+    bs = [torch.randn(O, generator=g) for O in Os]
+    scs = [1 / math.sqrt(I) * (1 + 0.1 * l) for l in range(len(Os))]
+    bss = [1.0 - 0.01 * l for l in range(len(Os))]
+    f32 = torch.float32
+    ys = H.linear_group_fwd(x.cuda(), [w.cuda() for w in ws], [b.cuda() for b in bs], scs, bss)
+    for l, (y, e) in enumerate(zip(ys, E.linear_group_fwd(x, ws, bs, scs, bss))):
+        check(y, e, f32, f"fwd {l}")
+    gys = [torch.randn(M, O, generator=g) for O in Os]
+    gx, gws, gbs = H.linear_group_bwd([t.cuda() for t in gys], x.cuda(), [w.cuda() for w in ws], scs, bss)
+    ex, ews, ebs = E.linear_group_bwd(gys, x, ws, scs, bss)
+    check(gx, ex, f32, "gx")
+    for l in range(len(Os)):
+        check(gws[l], ews[l], f32, f"gw {l}")
+        check(gbs[l], ebs[l], f32, f"gb {l}")
+    assert H.linear_group_bwd([t.cuda() for t in gys], x.cuda(), [w.cuda() for w in ws], scs, bss, want_gx=False)[0] is None
+
+
 def test_demod(H):
     g = torch.Generator().manual_seed(101)
     B, C, O = 4, 64, 24
