@@ -30,7 +30,7 @@ int g_mfma16 = 0;                         // lcgan_set_option(4, ...): halo kern
                                           // measured 8-10 % faster here -- the 16x16 form needs 140 VGPRs and loses the second workgroup per CU)
 int g_wgrad3_small = 0;                   // lcgan_set_option(5, ...): row-segment wgrad kernel also for 16/8-wide layers and 1x1 kernels
                                           // (default off: measured 0.5 ms/iteration SLOWER than the generic kernel on those shapes)
-int g_wgrad3_wgs = 1536;                  // lcgan_set_option(2, ...): target workgroup count of the row-segment wgrad kernel
+int g_wgrad3_wgs = 0;                     // lcgan_set_option(2, ...): 0 = cost-model split of the row-segment wgrad kernel, > 0 = explicit workgroup target
 int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): TIMING EXPERIMENTS ONLY: skip the wgrad epilogue atomics
 
 constexpr int BM = 128, BN = 128, BK = 32;
@@ -522,6 +522,9 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
     max_halo = std::max(max_halo, a.hh[p] * a.hw[p]);
   }
   if (max_halo * 4 > (in_mul == 1 ? 3 : 9) * 512) return false;
+  // a launch that cannot cover half the CUs (small local batch x low resolution: 16..64 tiles, each walking the full K =
+  // 9*Cin reduction) goes to the split-K implicit GEMM instead, which spreads the reduction over ~256 workgroups
+  if (g_use_splitk && c.B * a.tiles_x * a.tiles_y * cdiv(c.Cout, BN) * nphase < 128 && c.taps[0].n * c.kc_per_tap >= 8) return false;
   a.halo_elems = max_halo * HROW;
   const size_t smem = std::max(((size_t)a.halo_elems + 2 * TILE) * sizeof(__bf16), (size_t)256 * (BN + 8) * sizeof(__bf16));
   dim3 grid(c.B * a.tiles_x * a.tiles_y, cdiv(c.Cout, BN), nphase);
@@ -959,7 +962,7 @@ int dispatch_igemm(const ConvArgs& a_in, int nphase, int dtype, hipStream_t s) {
   const int wgs = cdiv(a.M, BM) * cdiv(a.Cout, BN) * nphase;
   int nq_min = 1 << 30;
   for (int p = 0; p < nphase; ++p) nq_min = std::min(nq_min, a.taps[p].n * a.kc_per_tap);
-  if (g_use_splitk && wgs < 128 && nq_min >= 8) {
+  if (g_use_splitk && wgs <= 192 && nq_min >= 8) {
     int ns = std::min(nq_min / 4, (256 + wgs - 1) / wgs);
     if (ns > 1) {
       const size_t bytes = (size_t)a.B * a.Hout * a.Wout * a.Cout * sizeof(float);
@@ -1135,15 +1138,31 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
     const int tiles3 = cdiv(A, 128) * cdiv(Bc, 128) * nkx;
     const int cps = (Hg / rows) * (Wg / segw);                  // chunks per sample
     a.nchunks = B * cps;
-    int parts = (g_wgrad3_wgs + tiles3 * B - 1) / (tiles3 * B);   // parts per sample so that ~g_wgrad3_wgs workgroups exist
-    const int min_chunks = 2048 / seg;                          // >= 2048 positions per workgroup: the 49K-element atomic epilogue must stay amortised
-    parts = max(1, min(parts, cps / min_chunks > 0 ? cps / min_chunks : 1));
+    const int xw = segw * stride + (k == 3 ? 2 : 0);
+    const size_t smem3 = 2 * (size_t)(seg + rows * xw) * WG_ROW * sizeof(__bf16);
+    // parts per sample.  A workgroup costs a fixed ~32 us (prologue + the 49K-element atomic epilogue) plus ~31 us per 1024
+    // positions, and workgroups run in rounds of (256 CUs x occupancy): pick the split that minimises rounds x per-workgroup
+    // cost, which lands the grid on whole rounds (1536 workgroups of one-per-CU occupancy were 6 rounds; 768 are 3 longer ones).
+    int parts = 1;
+    if (g_wgrad3_wgs > 0) {                                       // explicit target (tuning experiments)
+      parts = (g_wgrad3_wgs + tiles3 * B - 1) / (tiles3 * B);
+      const int min_chunks = 2048 / seg;
+      parts = max(1, min(parts, cps / min_chunks > 0 ? cps / min_chunks : 1));
+    } else {
+      const int occ = smem3 * 2 <= 160 * 1024 ? 2 : 1;
+      const int max_parts = max(1, cps / (1024 / seg));
+      double best = 1e30;
+      for (int pt = 1; pt <= max_parts; ++pt) {
+        const int cpsplit = cdiv(cps, pt), real_parts = cdiv(cps, cpsplit);
+        const long long rounds = ((long long)tiles3 * B * real_parts + 256 * occ - 1) / (256 * occ);
+        const double cost = (double)rounds * (1024.0 + (double)cpsplit * seg);
+        if (cost < best) { best = cost; parts = real_parts; }
+      }
+    }
     a.chunks_per_split = cdiv(cps, parts);
     a.parts = cdiv(cps, a.chunks_per_split);
     a.nsplit = B * a.parts;
     dim3 grid3(cdiv(A, 128), cdiv(Bc, 128), nkx * a.nsplit);
-    const int xw = segw * stride + (k == 3 ? 2 : 0);
-    const size_t smem3 = 2 * (size_t)(seg + rows * xw) * WG_ROW * sizeof(__bf16);
 #define LAUNCH_WG3(ST, SG, SW, NK)                                                                                      \
     {                                                                                                                   \
       static bool set = false;                                                                                          \
