@@ -49,6 +49,7 @@ struct ConvArgs {
   int in_mul, out_mul;
   int pre_stride, post_stride;
   float bias_scale, gain; int act;
+  int res_half;                              // residual is [B,Hout/2,Wout/2,Cout]: add 0.25 * residual[oy/2][ox/2] (avg_pool2d adjoint)
   int nsplit; float* ws;                     // split-K: blockIdx.z = phase * nsplit + split; raw fp32 partials are atomically added to ws [M_out pixels][Cout]
   TapTable taps[4];
 };
@@ -244,7 +245,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         v += bv;
         v = act_fwd(v, a.act) * a.gain;
         const size_t off = (size_t)ro * a.Cout + n;
-        if (res) v += Feat<T>::ld1(res + off);
+        if (res) {
+          if (a.res_half) {
+            const int ox = ro % a.Wout, t = ro / a.Wout, oy = t % a.Hout, bb = t / a.Hout;
+            v += 0.25f * Feat<T>::ld1(res + ((size_t)(bb * (a.Hout >> 1) + (oy >> 1)) * (a.Wout >> 1) + (ox >> 1)) * a.Cout + n);
+          } else {
+            v += Feat<T>::ld1(res + off);
+          }
+        }
         Feat<T>::st1(y + off, v);
       }
     }
@@ -262,7 +270,7 @@ constexpr int HROW = 40;                      // bf16 per staged pixel row (32 c
 
 struct HaloArgs {
   const __bf16* x; const __bf16* w; __bf16* y;
-  const float* pre; const float* post; const float* bias; const __bf16* residual;
+  const float* pre; const float* post; const float* bias; const __bf16* residual; int res_half;
   int B, Hin, Win, Cin, Hout, Wout, Cout, Hm, Wm, N, Kpad, kc_per_tap;
   int out_mul, tiles_x, tiles_y;
   float bias_scale, gain; int act;
@@ -445,7 +453,8 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
       bf16x8 rr = zero_bf16x8();
       if (py < a.Hm && px < a.Wm && n < a.Cout) {
         const int oy = py * a.out_mul + (phase >> 1), ox = px * a.out_mul + (phase & 1);
-        rr = *(const bf16x8*)(a.residual + ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n);
+        rr = a.res_half ? *(const bf16x8*)(a.residual + ((size_t)(b * (a.Hout >> 1) + (oy >> 1)) * (a.Wout >> 1) + (ox >> 1)) * a.Cout + n)
+                        : *(const bf16x8*)(a.residual + ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n);
       }
       *(bf16x8*)(ot + row * OROW + vv * 8) = rr;
     }
@@ -456,10 +465,11 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
     bv = (a.bias && n < a.N) ? a.bias[n] * a.bias_scale : 0.f;
     pv = (a.post && n < a.Cout) ? a.post[(size_t)b * a.Cout + n] : 1.f;
   };
+  const float res_scale = a.res_half ? 0.25f : 1.f;
   auto emit = [&](int row, int nl, float accv, float bv, float pv) {
     float v = accv * pv + bv;
     v = (a.act == ACT_LRELU ? (v > 0.f ? v : v * LRELU_SLOPE) : v) * a.gain;
-    if (a.residual) v += (float)ot[row * OROW + nl];               // same thread reads and rewrites this element: one rounding
+    if (a.residual) v += res_scale * (float)ot[row * OROW + nl];   // same thread reads and rewrites this element: one rounding
     ot[row * OROW + nl] = (__bf16)v;
   };
   if (M16) {
@@ -504,7 +514,7 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   if ((long long)c.B * c.Hin * c.Win * c.Cin >= (1ll << 31) || (long long)c.B * c.Hout * c.Wout * c.Cout >= (1ll << 31)) return false;
   HaloArgs a = {};
   a.x = (const __bf16*)c.x; a.w = c.w; a.y = (__bf16*)c.y; a.pre = c.pre; a.post = c.post; a.bias = c.bias;
-  a.residual = (const __bf16*)c.residual;
+  a.residual = (const __bf16*)c.residual; a.res_half = c.res_half;
   a.B = c.B; a.Hin = c.Hin; a.Win = c.Win; a.Cin = c.Cin; a.Hout = c.Hout; a.Wout = c.Wout; a.Cout = c.Cout;
   a.Hm = c.Hm; a.Wm = c.Wm; a.N = c.N; a.Kpad = c.Kpad; a.kc_per_tap = c.kc_per_tap; a.out_mul = c.out_mul;
   a.tiles_x = cdiv(c.Wm, HT); a.tiles_y = cdiv(c.Hm, HT);
@@ -906,7 +916,8 @@ __global__ void unprep_wgrad_kernel(const float* __restrict__ gwp, int A, int Bc
 template <typename T>
 __global__ void conv_finalize_kernel(const float* __restrict__ ws, T* __restrict__ y, const float* __restrict__ post,
                                      const float* __restrict__ bias, const T* __restrict__ residual,
-                                     long long npix, int pix_per_sample, int Cout, int N, float bias_scale, float gain, int act) {
+                                     long long npix, int pix_per_sample, int Cout, int N, float bias_scale, float gain, int act,
+                                     int res_half, int Wout) {
   const int nvec = Cout >> 3;
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= npix * nvec) return;
@@ -924,9 +935,16 @@ __global__ void conv_finalize_kernel(const float* __restrict__ ws, T* __restrict
     s.v[j] = act_fwd(t, act) * gain;
   }
   if (residual) {
-    const F8 r = Feat<T>::load(residual + off);
+    size_t roff = off;
+    float rs = 1.f;
+    if (res_half) {                                               // [B][Hout/2][Wout/2][Cout] residual, nearest x2, * 1/4
+      const int Hout = pix_per_sample / Wout, p = (int)(pix - (long long)b * pix_per_sample), oy = p / Wout, ox = p - oy * Wout;
+      roff = ((size_t)(b * (Hout >> 1) + (oy >> 1)) * (Wout >> 1) + (ox >> 1)) * Cout + v * 8;
+      rs = 0.25f;
+    }
+    const F8 r = Feat<T>::load(residual + roff);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s.v[j] += r.v[j];
+    for (int j = 0; j < 8; ++j) s.v[j] += rs * r.v[j];
   }
   Feat<T>::store(y + off, s);
 }
@@ -945,7 +963,7 @@ int launch_igemm(const ConvArgs& a, int nphase, hipStream_t s) {
   if (a.nsplit > 1) {
     const long long npix = (long long)a.B * a.Hout * a.Wout, nthr = npix * (a.Cout / 8);
     hipLaunchKernelGGL((conv_finalize_kernel<T>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a.ws, (T*)a.y, a.post, a.bias,
-                       (const T*)a.residual, npix, a.Hout * a.Wout, a.Cout, a.N, a.bias_scale, a.gain, a.act);
+                       (const T*)a.residual, npix, a.Hout * a.Wout, a.Cout, a.N, a.bias_scale, a.gain, a.act, a.res_half, a.Wout);
   }
   return launch_status();
 }
@@ -1028,19 +1046,22 @@ int lcgan_conv_wgrad_unprep(const float* gwp, int A, int Bc, int k, float scale,
 // (parity mode, dtype f32, expects weights prepared with parts = 3; bf16 with parts = 1)
 // Forward convolution  y[b,ho,wo,n] = act(post[b,n] * sum_{t,c} pre[b,c] x[b, ho*stride+ky-pad, wo*stride+kx-pad, c] wp[t][n][c]
 //                                        + bias[n]*bias_scale) * gain + residual
+// residual: [B,Hout,Wout,Cout], or with residual_half = 1 [B,Hout/2,Wout/2,Cout] added as 0.25 * residual[ho/2][wo/2]
+// (the adjoint of avg_pool2d(2), custom_layers.py:202: the gradient of a block's pooled skip branch)
 // x: [B,Hin,Win,Cin]  wp: lcgan_conv_weight_prep(transpose=0)  y: [B,Hout,Wout,Cout], Hout = ceil(Hin/stride)
 int lcgan_conv_fwd(const void* x, const void* wp, void* y,
                    int B, int Hin, int Win, int Cin, int Cout, int N, int k, int stride,
                    const float* pre, const float* post, const float* bias, float bias_scale,
-                   int act, float gain, const void* residual, int dtype, void* stream) {
+                   int act, float gain, const void* residual, int residual_half, int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || (Cin & 7) || (Cout & 7) || N > Cout) return LCGAN_EINVAL;
   ConvArgs a = {};
   a.x = x; a.w = (const __bf16*)wp; a.y = y;
-  a.pre = pre; a.post = post; a.bias = bias; a.residual = residual;
+  a.pre = pre; a.post = post; a.bias = bias; a.residual = residual; a.res_half = residual ? residual_half : 0;
   a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin;
   a.Hout = (Hin + stride - 1) / stride; a.Wout = (Win + stride - 1) / stride; a.Cout = Cout;
   a.Hm = a.Hout; a.Wm = a.Wout;
+  if (a.res_half && ((a.Hout | a.Wout) & 1)) return LCGAN_EINVAL;
   const long long M = (long long)B * a.Hm * a.Wm;
   if (M <= 0 || M >= (1ll << 31) || (long long)B * Hin * Win >= (1ll << 31)) return LCGAN_EINVAL;
   a.M = (int)M; a.N = N; a.Kpad = (Cin + 31) / 32 * 32; a.kc_per_tap = a.Kpad / BK;
@@ -1063,16 +1084,17 @@ int lcgan_conv_fwd(const void* x, const void* wp, void* y,
 int lcgan_conv_bwd_data(const void* g, const void* wpT, void* gx,
                         int B, int Hg, int Wg, int Cg, int Cout, int N, int k, int stride,
                         const float* pre, const float* post, const float* bias, float bias_scale,
-                        int act, float gain, const void* residual, int dtype, void* stream) {
+                        int act, float gain, const void* residual, int residual_half, int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || (Cg & 7) || (Cout & 7) || N > Cout) return LCGAN_EINVAL;
   if (stride == 2 && k != 3) return LCGAN_EINVAL;
   ConvArgs a = {};
   a.x = g; a.w = (const __bf16*)wpT; a.y = gx;
-  a.pre = pre; a.post = post; a.bias = bias; a.residual = residual;
+  a.pre = pre; a.post = post; a.bias = bias; a.residual = residual; a.res_half = residual ? residual_half : 0;
   a.B = B; a.Hin = Hg; a.Win = Wg; a.Cin = Cg;
   a.Hout = Hg * stride; a.Wout = Wg * stride; a.Cout = Cout;
   a.Hm = Hg; a.Wm = Wg;
+  if (a.res_half && ((a.Hout | a.Wout) & 1)) return LCGAN_EINVAL;
   const long long M = (long long)B * a.Hm * a.Wm;
   if (M <= 0 || (long long)B * a.Hout * a.Wout >= (1ll << 31)) return LCGAN_EINVAL;
   a.M = (int)M; a.N = N; a.Kpad = (Cg + 31) / 32 * 32; a.kc_per_tap = a.Kpad / BK;

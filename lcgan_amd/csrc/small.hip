@@ -299,22 +299,26 @@ __global__ void avg_latent_kernel(const float* __restrict__ w, float* __restrict
   avg[d] = m + beta * (avg[d] - m);
 }
 
-// ---- Householder QR of an n x n matrix (n <= 64) in ONE workgroup, LAPACK convention (geqr2 + orgqr: R_jj = -sign(alpha)*norm),
+// ---- Householder QR of an n x n matrix (n <= 64) in ONE workgroup, LAPACK convention (geqr2: R_jj = -sign(alpha)*norm),
 // i.e. what torch.qr / torch.linalg.qr(mode='reduced') return for the 64 x 64 basis of MappingNetwork (custom_layers.py:274-276).
-// Replaces ~200 rocSOLVER micro-launches per call.  One thread per column; matrix and Q live in LDS.
+// Replaces ~200 rocSOLVER micro-launches per call.  The reflectors are applied to the augmented matrix [A | I]:
+// H_{n-1}..H_0 [A | I] = [R | Q^T], so R and Q come out of the SAME n steps (two waves: thread c < 64 owns column c of A,
+// thread 64+r owns column r of the identity block = row r of Q) instead of a second, serial backward accumulation.
+// Columns live in registers (fully unrolled, predicated loops keep the indices static); only the current reflector travels
+// through LDS, double-buffered so one barrier per step suffices, and is read back as 16 broadcast ds_read_b128.
 constexpr int QR_MAX = 64;
-__global__ __launch_bounds__(QR_MAX) void qr_householder_kernel(const float* __restrict__ A, float* __restrict__ Q,
-                                                                 float* __restrict__ R, int n) {
-  // thread c owns column c of the working matrix and of Q in REGISTERS (fully unrolled, predicated loops keep the indices
-  // static); only the current Householder vector travels through LDS (broadcast reads).
-  __shared__ float vs[QR_MAX][QR_MAX];      // v_j for every step (row j: the reflector of step j), needed again to form Q
-  __shared__ float taus[QR_MAX];
-  const int c = threadIdx.x;
-  float a[QR_MAX], q[QR_MAX];
+__global__ __launch_bounds__(2 * QR_MAX) void qr_householder_kernel(const float* __restrict__ A, float* __restrict__ Q,
+                                                                     float* __restrict__ R, int n) {
+  __shared__ __attribute__((aligned(16))) float vrow[2][QR_MAX];
+  __shared__ float taus[2];
+  const int c = threadIdx.x & (QR_MAX - 1);
+  const bool isq = threadIdx.x >= QR_MAX;
+  float a[QR_MAX];
 #pragma unroll
-  for (int i = 0; i < QR_MAX; ++i) { a[i] = (i < n && c < n) ? A[i * n + c] : 0.f; q[i] = (i == c) ? 1.f : 0.f; }
+  for (int i = 0; i < QR_MAX; ++i) a[i] = isq ? ((i == c) ? 1.f : 0.f) : ((i < n && c < n) ? A[i * n + c] : 0.f);
   for (int j = 0; j < n; ++j) {
-    if (c == j) {                                           // dlarfg on column j, rows j..n-1
+    const int buf = j & 1;
+    if (!isq && c == j) {                                   // dlarfg on column j, rows j..n-1
       float alpha = 0.f, xn2 = 0.f;
 #pragma unroll
       for (int i = 0; i < QR_MAX; ++i) { if (i == j) alpha = a[i]; if (i > j && i < n) xn2 += a[i] * a[i]; }
@@ -327,36 +331,34 @@ __global__ __launch_bounds__(QR_MAX) void qr_householder_kernel(const float* __r
 #pragma unroll
       for (int i = 0; i < QR_MAX; ++i) {
         const float vi = (i == j) ? 1.f : ((i > j && i < n) ? a[i] * sc : 0.f);
-        vs[j][i] = vi;
-        if (i == j) a[i] = beta; else if (i > j) a[i] = vi;   // R_jj and v stored like LAPACK (v below the diagonal)
+        vrow[buf][i] = vi;
+        if (i == j) a[i] = beta;                            // R_jj ; rows below the diagonal are not part of R
       }
-      taus[j] = tau;
+      taus[buf] = tau;
     }
     __syncthreads();
-    if (c > j && c < n) {                                   // A[:, c] -= tau v (v^T A[:, c])
-      float wv = 0.f;
+    if (c < n && (isq || c > j)) {                          // column -= tau v (v^T column)
+      float v[QR_MAX];
 #pragma unroll
-      for (int i = 0; i < QR_MAX; ++i) wv += vs[j][i] * a[i];
-      wv *= taus[j];
+      for (int k = 0; k < QR_MAX / 4; ++k) {
+        const f32x4 t = *(const f32x4*)(&vrow[buf][4 * k]);
+        v[4 * k] = t[0]; v[4 * k + 1] = t[1]; v[4 * k + 2] = t[2]; v[4 * k + 3] = t[3];
+      }
+      float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
 #pragma unroll
-      for (int i = 0; i < QR_MAX; ++i) a[i] -= vs[j][i] * wv;
-    }
-  }
-  __syncthreads();
-  for (int j = n - 1; j >= 0; --j) {                        // Q = H_0 ... H_{n-1} I  (dorg2r, backward accumulation)
-    if (c < n) {
-      float wv = 0.f;
+      for (int i = 0; i < QR_MAX; i += 4) { w0 += v[i] * a[i]; w1 += v[i + 1] * a[i + 1]; w2 += v[i + 2] * a[i + 2]; w3 += v[i + 3] * a[i + 3]; }
+      const float wv = ((w0 + w1) + (w2 + w3)) * taus[buf];
 #pragma unroll
-      for (int i = 0; i < QR_MAX; ++i) wv += vs[j][i] * q[i];
-      wv *= taus[j];
-#pragma unroll
-      for (int i = 0; i < QR_MAX; ++i) q[i] -= vs[j][i] * wv;
+      for (int i = 0; i < QR_MAX; ++i) a[i] -= v[i] * wv;
     }
   }
   if (c < n) {
 #pragma unroll
     for (int i = 0; i < QR_MAX; ++i) {
-      if (i < n) { Q[i * n + c] = q[i]; R[i * n + c] = (i <= c) ? a[i] : 0.f; }
+      if (i < n) {
+        if (isq) Q[c * n + i] = a[i];                       // thread 64+r holds column r of Q^T = row r of Q
+        else R[i * n + c] = (i <= c) ? a[i] : 0.f;
+      }
     }
   }
 }
@@ -563,7 +565,7 @@ int lcgan_qr_householder(const float* A, float* Q, float* R, int n, void* stream
   hipStream_t s = (hipStream_t)stream;
   if (n < 1 || n > QR_MAX) return LCGAN_EINVAL;
   ProfScope p(KID_SMALL, 0, 0, s);
-  hipLaunchKernelGGL(qr_householder_kernel, dim3(1), dim3(QR_MAX), 0, s, A, Q, R, n);
+  hipLaunchKernelGGL(qr_householder_kernel, dim3(1), dim3(2 * QR_MAX), 0, s, A, Q, R, n);
   return launch_status();
 }
 int lcgan_avg_latent(const float* w, float* avg, int B, int D, float beta, void* stream) {

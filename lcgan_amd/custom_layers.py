@@ -74,6 +74,12 @@ class EqualizedConv2d(nn.Module):
         return ops.Conv2dFn.apply(x, self.weight.weight, bias, residual, self.kernel_size, self.stride, act, gain, wscale,
                                   self.lr_mul)
 
+    def forward_with_pool(self, x, act=ACT_NONE, gain=1.0):
+        """(self(x, act, gain), avg_pool2d(x, 2)) as ONE autograd node (see ops.ConvPoolFn)"""
+        assert self.stride == 1 and act != ACT_NONE
+        bias = None if self.no_bias else self.bias
+        return ops.ConvPoolFn.apply(x, self.weight.weight, bias, self.kernel_size, act, gain, self.weight.c, self.lr_mul)
+
     def forward_rgb(self, img, act=ACT_NONE, gain=1.0):
         w = self.weight.weight
         C = w.shape[0]
@@ -204,12 +210,14 @@ class DiscriminatorBlock(nn.Module):
             self.skip_gain = np.sqrt(0.5)
 
     def forward(self, x):
-        h = self.conv0(x, ACT_LRELU, SQRT2 if self.skip else 1.0)              # :204-205 / :212-213
+        if self.skip:
+            h, pooled = self.conv0.forward_with_pool(x, ACT_LRELU, SQRT2)      # :202, :204-205 (one node: see ops.ConvPoolFn)
+        else:
+            h = self.conv0(x, ACT_LRELU, 1.0)                                   # :212-213
         h = ops.Box3Fn.apply(h)                                                 # :206
         h = self.conv1(h, ACT_LRELU, 1.0)                                       # :207-208
         if not self.skip:
             return h
-        pooled = ops.AvgPool2Fn.apply(x)                                        # :202
         return self.skip_layer(pooled, ACT_NONE, SQRT_HALF, residual=h)         # :203, :209 (add fused in the epilogue)
 
 

@@ -112,25 +112,28 @@ class HipKernels:
         return gw
 
     def conv_fwd(self, x: Tensor, pw: PreparedWeight, N: int, k: int, stride: int, pre=None, post=None, bias=None,
-                 bias_scale: float = 1.0, act: int = ACT_NONE, gain: float = 1.0, residual=None) -> Tensor:
+                 bias_scale: float = 1.0, act: int = ACT_NONE, gain: float = 1.0, residual=None, residual_half: bool = False) -> Tensor:
         self._chk(x, pre, post, bias, residual)
         B, H, W, Cin = x.shape
         Cout = ceil8(N)
         y = torch.empty((B, (H + stride - 1) // stride, (W + stride - 1) // stride, Cout), dtype=x.dtype, device=x.device)
         assert pw.parts == (3 if x.dtype == torch.float32 else 1)
         self._call("lcgan_conv_fwd", x.data_ptr(), pw.buf.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, N, k, stride,
-                   _p(pre), _p(post), _p(bias), float(bias_scale), act, float(gain), _p(residual), dt_code(x.dtype), self._stream())
+                   _p(pre), _p(post), _p(bias), float(bias_scale), act, float(gain), _p(residual), int(residual_half), dt_code(x.dtype),
+                   self._stream())
         return y
 
     def conv_bwd_data(self, g: Tensor, pw: PreparedWeight, N: int, k: int, stride: int, pre=None, post=None, bias=None,
-                      bias_scale: float = 1.0, act: int = ACT_NONE, gain: float = 1.0, residual=None) -> Tensor:
+                      bias_scale: float = 1.0, act: int = ACT_NONE, gain: float = 1.0, residual=None, residual_half: bool = False) -> Tensor:
+        """residual_half: residual is [B,H/2,W/2,C] of gx's grid and enters as 0.25 * nearest-x2 (avg_pool2d adjoint)"""
         self._chk(g, pre, post, bias, residual)
         B, H, W, Cg = g.shape
         Cout = ceil8(N)
         gx = torch.empty((B, H * stride, W * stride, Cout), dtype=g.dtype, device=g.device)
         assert pw.parts == (3 if g.dtype == torch.float32 else 1)
         self._call("lcgan_conv_bwd_data", g.data_ptr(), pw.buf.data_ptr(), gx.data_ptr(), B, H, W, Cg, Cout, N, k, stride,
-                   _p(pre), _p(post), _p(bias), float(bias_scale), act, float(gain), _p(residual), dt_code(g.dtype), self._stream())
+                   _p(pre), _p(post), _p(bias), float(bias_scale), act, float(gain), _p(residual), int(residual_half), dt_code(g.dtype),
+                   self._stream())
         return gx
 
     def conv_wgrad(self, x: Tensor, g: Tensor, A: int, Bc: int, k: int, stride: int, pre_x=None, pre_g=None) -> Tensor:

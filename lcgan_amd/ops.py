@@ -102,20 +102,21 @@ class Conv2dFn(Function):
             gz, gb = ActBwdFn.apply(gy, y, act, gain, A, want_gb, bias_scale)
         else:
             gz, gb = gy, None
-        gx = ConvTransposeFn.apply(gz, w, k, stride, wscale, x.shape[-1]) if ctx.needs_input_grad[0] else None
+        gx = ConvTransposeFn.apply(gz, w, k, stride, wscale, x.shape[-1], None) if ctx.needs_input_grad[0] else None
         gw = ConvWeightGradFn.apply(x, gz, k, stride, wscale, w.shape[0], w.shape[1]) if ctx.needs_input_grad[1] else None
         gres = gy if (has_res and ctx.needs_input_grad[3]) else None
         return gx, gw, (gb if want_gb else None), gres, None, None, None, None, None, None
 
 
 class ConvTransposeFn(Function):
-    """gx = adjoint of conv_{k,stride}(., w*wscale) applied to g  (stride 2: the 4-phase transposed convolution)."""
+    """gx = adjoint of conv_{k,stride}(., w*wscale) applied to g  (stride 2: the 4-phase transposed convolution)
+    (+ 0.25 * nearest-x2(res_half): the adjoint of avg_pool2d, fused into the epilogue)."""
 
     @staticmethod
-    def forward(ctx, g, w, k, stride, wscale, cin_alloc):
+    def forward(ctx, g, w, k, stride, wscale, cin_alloc, res_half):
         K = _K()
         pw, _ = _prep(w, wscale, True, _need_lo(g))
-        gx = K.conv_bwd_data(g, pw, w.shape[1], k, stride)
+        gx = K.conv_bwd_data(g, pw, w.shape[1], k, stride, residual=res_half, residual_half=res_half is not None)
         assert gx.shape[-1] == cin_alloc
         ctx.save_for_backward(g, w)
         ctx.cfg = (k, stride, wscale)
@@ -128,7 +129,44 @@ class ConvTransposeFn(Function):
         ggx = ggx.contiguous()
         gg = Conv2dFn.apply(ggx, w, None, None, k, stride, ACT_NONE, 1.0, wscale, 0.0) if ctx.needs_input_grad[0] else None
         gw = ConvWeightGradFn.apply(ggx, g, k, stride, wscale, w.shape[0], w.shape[1]) if ctx.needs_input_grad[1] else None
-        return gg, gw, None, None, None, None
+        gres = AvgPool2Fn.apply(ggx) if ctx.needs_input_grad[6] else None
+        return gg, gw, None, None, None, None, gres
+
+
+class ConvPoolFn(Function):
+    """(h, pooled) = (act(conv_k(x, w*wscale) + bias*bias_scale) * gain, avg_pool2d(x, 2)): the two consumers of a
+    DiscriminatorBlock's input (custom_layers.py:202,204).  Owning both lets the backward pass fold the pooled branch's
+    gradient into the epilogue of the conv's data-gradient kernel instead of up-sampling it and adding two
+    full-resolution tensors (3 ms per iteration at 256x256, batch 32)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, k, act, gain, wscale, bias_scale):
+        K = _K()
+        pw, _ = _prep(w, wscale, False, _need_lo(x))
+        y = K.conv_fwd(x, pw, w.shape[0], k, 1, bias=bias, bias_scale=bias_scale, act=act, gain=gain)
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.cfg = (k, act, gain, wscale, bias_scale, bias is not None)
+        return y, K.avgpool2(x)
+
+    @staticmethod
+    def backward(ctx, gy, gpooled):
+        x, w, y = ctx.saved_tensors
+        k, act, gain, wscale, bias_scale, has_bias = ctx.cfg
+        A = w.shape[0]
+        want_gb = has_bias and ctx.needs_input_grad[2]
+        if gy is None:                                                   # only the pooled branch was used
+            gx = AvgPool2TFn.apply(gpooled.contiguous()) if ctx.needs_input_grad[0] else None
+            return gx, None, None, None, None, None, None, None
+        gy = gy.contiguous()
+        if act != ACT_NONE or want_gb:
+            gz, gb = ActBwdFn.apply(gy, y, act, gain, A, want_gb, bias_scale)
+        else:
+            gz, gb = gy, None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = ConvTransposeFn.apply(gz, w, k, 1, wscale, x.shape[-1], None if gpooled is None else gpooled.contiguous())
+        gw = ConvWeightGradFn.apply(x, gz, k, 1, wscale, w.shape[0], w.shape[1]) if ctx.needs_input_grad[1] else None
+        return gx, gw, (gb if want_gb else None), None, None, None, None, None
 
 
 class ConvWeightGradFn(Function):
@@ -148,7 +186,7 @@ class ConvWeightGradFn(Function):
         x, g = ctx.saved_tensors
         k, stride, wscale = ctx.cfg
         ggw = ggw.contiguous()
-        gx = ConvTransposeFn.apply(g, ggw, k, stride, wscale, x.shape[-1]) if ctx.needs_input_grad[0] else None
+        gx = ConvTransposeFn.apply(g, ggw, k, stride, wscale, x.shape[-1], None) if ctx.needs_input_grad[0] else None
         gg = Conv2dFn.apply(x, ggw, None, None, k, stride, ACT_NONE, 1.0, wscale, 0.0) if ctx.needs_input_grad[1] else None
         return gx, gg, None, None, None, None, None
 

@@ -97,7 +97,15 @@ class EmulatedKernels:
             y = y + residual.float()
         return y.to(dtype)
 
-    def conv_fwd(self, x, pw, N, k, stride, pre=None, post=None, bias=None, bias_scale=1.0, act=ACT_NONE, gain=1.0, residual=None):
+    @staticmethod
+    def _res(residual, half):
+        if residual is None or not half:
+            return residual
+        return nhwc(F.interpolate(nchw(residual), scale_factor=2, mode="nearest") * 0.25, torch.float32)
+
+    def conv_fwd(self, x, pw, N, k, stride, pre=None, post=None, bias=None, bias_scale=1.0, act=ACT_NONE, gain=1.0, residual=None,
+                 residual_half=False):
+        residual = self._res(residual, residual_half)
         Kc = pw.P4.shape[1]
         xs = nchw(x)[:, :Kc]
         if pre is not None:
@@ -105,7 +113,9 @@ class EmulatedKernels:
         v = F.conv2d(xs, pw.P4, stride=stride, padding=k // 2)
         return self._epilogue(v, N, post, bias, bias_scale, act, gain, residual, x.dtype)
 
-    def conv_bwd_data(self, g, pw, N, k, stride, pre=None, post=None, bias=None, bias_scale=1.0, act=ACT_NONE, gain=1.0, residual=None):
+    def conv_bwd_data(self, g, pw, N, k, stride, pre=None, post=None, bias=None, bias_scale=1.0, act=ACT_NONE, gain=1.0, residual=None,
+                      residual_half=False):
+        residual = self._res(residual, residual_half)
         Kc = pw.P4.shape[1]
         gs = nchw(g)[:, :Kc]
         if pre is not None:

@@ -118,6 +118,10 @@ def test_conv_bwd_data(H, dtype, case):
     bias = torch.randn(Ci, generator=torch.Generator().manual_seed(15))
     check(H.conv_bwd_data(g.cuda(), pw_h, Ci, k, stride, pre=pre.cuda(), post=post.cuda(), bias=bias.cuda(), act=1, gain=1.2),
           E.conv_bwd_data(g, pw_e, Ci, k, stride, pre=pre, post=post, bias=bias, act=1, gain=1.2), dtype, "mod+bias+act")
+    if Hh % 2 == 0 and W % 2 == 0:         # pooled-branch gradient folded into the epilogue (0.25 * nearest-x2 of a half-res tensor)
+        rh = feat((B, Hh // 2, W // 2, ceil8(Ci)), dtype, 16, Ci)
+        check(H.conv_bwd_data(g.cuda(), pw_h, Ci, k, stride, residual=rh.cuda(), residual_half=True),
+              E.conv_bwd_data(g, pw_e, Ci, k, stride, residual=rh, residual_half=True), dtype, "half-res residual")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

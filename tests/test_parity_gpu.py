@@ -177,7 +177,9 @@ def test_full_size_properties_256():
             logit, _, _ = D(img, False)
             return float(loss.cal_r1_reg(logit, img))
         a = r1_of()
-        assert abs(a - r1_of()) <= 1e-3 * a          # repeatable up to the order of the float atomics in the reductions
+        # repeatable up to the order of the fp32 atomics (split-K convs, linear data gradients): an ulp-level difference in an
+        # fp32 partial sum can flip a bf16 rounding downstream (2^-9 relative on that element), hence a few 1e-3 on the total
+        assert abs(a - r1_of()) <= 5e-3 * a
         with torch.no_grad():
             D.module.logit_mapper.mlp[0].weight.weight.mul_(2.0)
         b = r1_of()
