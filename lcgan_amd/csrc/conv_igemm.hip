@@ -28,7 +28,7 @@ int g_use_halo = 1;                       // lcgan_set_option(0, ...): bf16 halo
 int g_use_splitk = 1;                     // lcgan_set_option(1, ...): split-K for small-M convolutions
 int g_mfma16 = 0;                         // lcgan_set_option(4, ...): halo kernel uses v_mfma_f32_16x16x32_bf16 (1) or 32x32x16 (0, default:
                                           // measured 8-10 % faster here -- the 16x16 form needs 140 VGPRs and loses the second workgroup per CU)
-int g_wgrad3_small = 0;                   // lcgan_set_option(5, ...): row-segment wgrad kernel also for 16/8-wide layers and 1x1 kernels
+int g_wgrad3_small = 0;                   // lcgan_set_option(5, ...): row-segment wgrad kernel for 16/8-wide layers and 1x1 kernels: 0 = only without per-sample scales (multi-sample splits), 1 = always, 2 = never
                                           // (default off: measured 0.5 ms/iteration SLOWER than the generic kernel on those shapes)
 int g_wgrad3_wgs = 0;                     // lcgan_set_option(2, ...): 0 = cost-model split of the row-segment wgrad kernel, > 0 = explicit workgroup target
 int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): TIMING EXPERIMENTS ONLY: skip the wgrad epilogue atomics
@@ -564,7 +564,8 @@ struct WgradArgs {
   int B, Hx, Wx, Cx, Hm, Wm, Cg, A, Bc, M;
   int stride, k, pad;
   int chunks_per_split, nsplit, nchunks;
-  int parts;                                 // wgrad3: split = sample * parts + part
+  int parts;                                 // wgrad3: split = group * parts + part
+  int cps_group;                             // wgrad3: chunks per group (group = one sample when per-sample scales exist, else the whole batch)
   int dbg_no_atomics;
 };
 
@@ -746,10 +747,11 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
   const int split = blockIdx.z / NKX, ky = blockIdx.z - split * NKX;
   const int segs = a.Wm / SEGW;                              // segments per image row (1 for narrow layers)
   const int rgroups = a.Hm / ROWS;                           // row groups per sample
-  // split = (sample, part): a workgroup's chunk range lies inside ONE sample, so the per-sample style / demod scales can be
-  // applied once to the fp32 accumulator in the epilogue instead of to every staged operand vector
+  // split = (group, part).  With per-sample style / demod scales a group is ONE sample, so the scales can be applied once to
+  // the fp32 accumulator in the epilogue instead of to every staged operand vector; without scales (discriminator convs) the
+  // whole batch is one group and a workgroup's chunk range may span samples (low-resolution layers: few chunks per sample).
   const int bsmp = split / a.parts, part = split - bsmp * a.parts;
-  const int cps = rgroups * segs;                            // chunks per sample
+  const int cps = a.cps_group;
   const int q_begin = bsmp * cps + part * a.chunks_per_split;
   const int q_end = min(q_begin + a.chunks_per_split, (bsmp + 1) * cps);
   if (q_begin >= q_end) return;
@@ -1152,14 +1154,17 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
   dim3 grid(cdiv(A, 128), cdiv(Bc, 128), k * k * a.nsplit);
   ProfScope p(KID_CONV_WGRAD, 2.0 * M * A * Bc * k * k, 0, s);
   const int segw = (Wg & 63) == 0 ? 64 : (Wg & 31) == 0 ? 32 : (Wg == 16 ? 16 : (Wg == 8 ? 8 : 0));
-  if (dtype == DT_BF16 && g_use_halo && segw != 0 && Hg * Wg >= 64 && (Hg & 3) == 0 && (g_wgrad3_small || (k == 3 && segw >= 32)) &&
+  if (dtype == DT_BF16 && g_use_halo && segw != 0 && Hg * Wg >= 64 && (Hg & 3) == 0 && (g_wgrad3_small == 1 || (k == 3 && segw >= 32) || (g_wgrad3_small == 0 && !(pre_x || pre_g))) &&
       (long long)B * Hx * Wx * Cx < (1ll << 31) && (long long)B * Hg * Wg * Cg < (1ll << 31)) {
     // row-segment kernel: chunk = (sample, row group, SEGW-column segment) of `seg` positions; grid.z = split x kernel row
     const int seg = segw == 64 ? 64 : 32, rows = seg / segw, nkx = k;
     a.dbg_no_atomics = g_dbg_no_atomics;
     const int tiles3 = cdiv(A, 128) * cdiv(Bc, 128) * nkx;
-    const int cps = (Hg / rows) * (Wg / segw);                  // chunks per sample
-    a.nchunks = B * cps;
+    const bool scaled = pre_x || pre_g;
+    const int groups = scaled ? B : 1;
+    const int cps = (Hg / rows) * (Wg / segw) * (scaled ? 1 : B);   // chunks per group
+    a.cps_group = cps;
+    a.nchunks = groups * cps;
     const int xw = segw * stride + (k == 3 ? 2 : 0);
     const size_t smem3 = 2 * (size_t)(seg + rows * xw) * WG_ROW * sizeof(__bf16);
     // parts per sample.  A workgroup costs a fixed ~32 us (prologue + the 49K-element atomic epilogue) plus ~31 us per 1024
@@ -1167,7 +1172,7 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
     // cost, which lands the grid on whole rounds (1536 workgroups of one-per-CU occupancy were 6 rounds; 768 are 3 longer ones).
     int parts = 1;
     if (g_wgrad3_wgs > 0) {                                       // explicit target (tuning experiments)
-      parts = (g_wgrad3_wgs + tiles3 * B - 1) / (tiles3 * B);
+      parts = (g_wgrad3_wgs + tiles3 * groups - 1) / (tiles3 * groups);
       const int min_chunks = 2048 / seg;
       parts = max(1, min(parts, cps / min_chunks > 0 ? cps / min_chunks : 1));
     } else {
@@ -1176,14 +1181,14 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
       double best = 1e30;
       for (int pt = 1; pt <= max_parts; ++pt) {
         const int cpsplit = cdiv(cps, pt), real_parts = cdiv(cps, cpsplit);
-        const long long rounds = ((long long)tiles3 * B * real_parts + 256 * occ - 1) / (256 * occ);
+        const long long rounds = ((long long)tiles3 * groups * real_parts + 256 * occ - 1) / (256 * occ);
         const double cost = (double)rounds * (1024.0 + (double)cpsplit * seg);
         if (cost < best) { best = cost; parts = real_parts; }
       }
     }
     a.chunks_per_split = cdiv(cps, parts);
     a.parts = cdiv(cps, a.chunks_per_split);
-    a.nsplit = B * a.parts;
+    a.nsplit = groups * a.parts;
     dim3 grid3(cdiv(A, 128), cdiv(Bc, 128), nkx * a.nsplit);
 #define LAUNCH_WG3(ST, SG, SW, NK)                                                                                      \
     {                                                                                                                   \
