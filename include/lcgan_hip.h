@@ -57,6 +57,10 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
  * box filter F.avg_pool2d(3,1,1) custom_layers.py:136-138,196-198 fused with leaky_relu*gain / tanh (:150-155,:205-206) */
 int lcgan_box3_act(const void* x, void* y, int B, int H, int W, int C, int act, float gain, int dtype, void* stream);
 int lcgan_box3_act_bwd(const void* gy, const void* y, void* gx, int B, int H, int W, int C, int act, float gain, int dtype, void* stream);
+/* backward of  act(conv + bias) -> 3x3 box filter  (DiscriminatorBlock conv0 -> blur, custom_layers.py:204-206) in one pass:
+   gz = box3(gy) * act'(y), gbias[c] += sum gz (gbias optional, accumulated) */
+int lcgan_box3_actbwd_reduce(const void* gy, const void* y, void* gz, float* gbias, int B, int H, int W, int C, int Clog,
+                             int act, float gain, int dtype, void* stream);
 /* F.interpolate(x2, nearest) + box filter (+ residual), custom_layers.py:146-147,159 ; x [B,H,W,C] -> y [B,2H,2W,C] */
 int lcgan_up2box(const void* x, const void* residual, void* y, int B, int H, int W, int C, int dtype, void* stream);
 int lcgan_up2box_bwd(const void* gy, void* gx, int B, int H, int W, int C, int dtype, void* stream);

@@ -22,6 +22,7 @@ SIGNATURES = {
     "lcgan_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P, I, P],
     "lcgan_box3_act": [P, P, I, I, I, I, I, F, I, P],
     "lcgan_box3_act_bwd": [P, P, P, I, I, I, I, I, F, I, P],
+    "lcgan_box3_actbwd_reduce": [P, P, P, P, I, I, I, I, I, I, F, I, P],
     "lcgan_up2box": [P, P, P, I, I, I, I, I, P],
     "lcgan_up2box_bwd": [P, P, I, I, I, I, I, P],
     "lcgan_avgpool2": [P, P, I, I, I, I, I, P],

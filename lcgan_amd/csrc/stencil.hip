@@ -64,6 +64,72 @@ __global__ void box3_act_kernel(const T* __restrict__ x, T* __restrict__ y, int 
   }
 }
 
+// gz = box3(gy) * act'(y) ; gbias[c] += sum_{b,p} gz     -- the backward of  y = act(conv + bias) -> box3(y)  up to the conv's
+// pre-activation (DiscriminatorBlock conv0 -> blur, custom_layers.py:204-206): one pass instead of a box-filter pass plus an
+// activation-backward pass.  Same sliding window as box3_act_kernel, over strips of BOXB_RH rows so that the per-channel
+// bias reduction ends in few global atomics (LDS float atomics inside the block).
+constexpr int BOXB_RH = 32;
+template <typename T>
+__global__ void box3_actbwd_reduce_kernel(const T* __restrict__ gy, const T* __restrict__ y, T* __restrict__ gz,
+                                          float* __restrict__ gbias, int B, int H, int W, int C, int Clog, int act, float gain) {
+  extern __shared__ float red[];                       // [C]
+  const int nvec = C >> 3;
+  const int strips = (H + BOXB_RH - 1) / BOXB_RH;
+  const long long total = (long long)B * strips * W * nvec;
+  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (gbias) {
+    for (int c = threadIdx.x; c < C; c += TPB) red[c] = 0.f;
+    __syncthreads();
+  }
+  float sb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sb[j] = 0.f;
+  int v = 0;
+  if (gid < total) {
+    v = (int)(gid % nvec);
+    long long t = gid / nvec;
+    const int w = (int)(t % W); t /= W;
+    const int strip = (int)(t % strips), b = (int)(t / strips);
+    const int h0 = strip * BOXB_RH, h1 = min(h0 + BOXB_RH, H);
+    const T* gb = gy + (size_t)b * H * W * C + v * 8;
+    auto rowsum = [&](int hh) {
+      F8 s = f8_zero();
+      if ((unsigned)hh >= (unsigned)H) return s;
+      const T* row = gb + (size_t)hh * W * C;
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int xx = w + dx;
+        if ((unsigned)xx >= (unsigned)W) continue;
+        const F8 q = Feat<T>::load(row + (size_t)xx * C);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s.v[j] += q.v[j];
+      }
+      return s;
+    };
+    F8 r0 = rowsum(h0 - 1), r1 = rowsum(h0);
+    for (int hh = h0; hh < h1; ++hh) {
+      const F8 r2 = rowsum(hh + 1);
+      const size_t off = (((size_t)b * H + hh) * W + w) * C + v * 8;
+      const F8 yo = Feat<T>::load(y + off);
+      F8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        o.v[j] = (r0.v[j] + r1.v[j] + r2.v[j]) * (1.f / 9.f) * act_grad_from_out(yo.v[j], act, gain);
+        sb[j] += o.v[j];
+      }
+      Feat<T>::store(gz + off, o);
+      r0 = r1; r1 = r2;
+    }
+  }
+  if (!gbias) return;
+  if (gid < total) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(&red[v * 8 + j], sb[j]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < Clog; c += TPB) atomicAdd(gbias + c, red[c]);
+}
+
 // gx = box3(gy * act'(y))   (box3 is self-adjoint)
 template <typename T>
 __global__ void box3_act_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ y, T* __restrict__ gx,
@@ -783,6 +849,19 @@ int lcgan_box3_act_bwd(const void* gy, const void* y, void* gx, int B, int H, in
   const long long n = (long long)B * H * W * (C / 8);
   ProfScope p(KID_STENCIL, 0, (double)n * 8 * 3 * (dtype == DT_BF16 ? 2 : 4), s);
   DISPATCH_T(dtype, hipLaunchKernelGGL(box3_act_bwd_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)gy, (const T*)y, (T*)gx, B, H, W, C, act, gain));
+  return launch_status();
+}
+
+// gz = box3(gy) * act'(y) ; gbias[c] += sum gz (gbias may be NULL; accumulated, must be zeroed by the caller)
+int lcgan_box3_actbwd_reduce(const void* gy, const void* y, void* gz, float* gbias, int B, int H, int W, int C, int Clog,
+                             int act, float gain, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if ((C & 7) || Clog > C) return LCGAN_EINVAL;
+  const long long n = (long long)B * H * W * (C / 8);
+  ProfScope p(KID_ACT_BWD, 0, (double)n * 8 * 3 * (dtype == DT_BF16 ? 2 : 4), s);
+  const long long nthr = (long long)B * ((H + BOXB_RH - 1) / BOXB_RH) * W * (C / 8);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(box3_actbwd_reduce_kernel<T>, grid1d(nthr), dim3(TPB), C * sizeof(float), s, (const T*)gy,
+                                       (const T*)y, (T*)gz, gbias, B, H, W, C, Clog, act, gain));
   return launch_status();
 }
 

@@ -74,11 +74,11 @@ class EqualizedConv2d(nn.Module):
         return ops.Conv2dFn.apply(x, self.weight.weight, bias, residual, self.kernel_size, self.stride, act, gain, wscale,
                                   self.lr_mul)
 
-    def forward_with_pool(self, x, act=ACT_NONE, gain=1.0):
-        """(self(x, act, gain), avg_pool2d(x, 2)) as ONE autograd node (see ops.ConvPoolFn)"""
+    def forward_with_pool(self, x, act=ACT_NONE, gain=1.0, box=False):
+        """(box3?(self(x, act, gain)), avg_pool2d(x, 2)) as ONE autograd node (see ops.ConvPoolFn)"""
         assert self.stride == 1 and act != ACT_NONE
         bias = None if self.no_bias else self.bias
-        return ops.ConvPoolFn.apply(x, self.weight.weight, bias, self.kernel_size, act, gain, self.weight.c, self.lr_mul)
+        return ops.ConvPoolFn.apply(x, self.weight.weight, bias, self.kernel_size, act, gain, self.weight.c, self.lr_mul, box)
 
     def forward_rgb(self, img, act=ACT_NONE, gain=1.0):
         w = self.weight.weight
@@ -211,10 +211,9 @@ class DiscriminatorBlock(nn.Module):
 
     def forward(self, x):
         if self.skip:
-            h, pooled = self.conv0.forward_with_pool(x, ACT_LRELU, SQRT2)      # :202, :204-205 (one node: see ops.ConvPoolFn)
+            h, pooled = self.conv0.forward_with_pool(x, ACT_LRELU, SQRT2, box=True)   # :202, :204-206 (one node: see ops.ConvPoolFn)
         else:
-            h = self.conv0(x, ACT_LRELU, 1.0)                                   # :212-213
-        h = ops.Box3Fn.apply(h)                                                 # :206
+            h = ops.Box3Fn.apply(self.conv0(x, ACT_LRELU, 1.0))                 # :212-214
         h = self.conv1(h, ACT_LRELU, 1.0)                                       # :207-208
         if not self.skip:
             return h

@@ -161,6 +161,16 @@ class HipKernels:
                    self._stream())
         return gx
 
+    def box3_actbwd(self, gy: Tensor, y: Tensor, act: int, gain: float, clog: int, want_gbias: bool):
+        """-> (gz = box3(gy) * act'(y), gbias [clog] | None)"""
+        self._chk(gy, y)
+        B, H, W, Cc = gy.shape
+        gz = torch.empty_like(gy)
+        gbias = self._zeros.take((clog,), gy.device) if want_gbias else None
+        self._call("lcgan_box3_actbwd_reduce", gy.data_ptr(), y.data_ptr(), gz.data_ptr(), _p(gbias), B, H, W, Cc, clog, act,
+                   float(gain), dt_code(gy.dtype), self._stream())
+        return gz, gbias
+
     def up2box(self, x: Tensor, residual: Optional[Tensor]) -> Tensor:
         self._chk(x, residual)
         B, H, W, Cc = x.shape

@@ -134,39 +134,68 @@ class ConvTransposeFn(Function):
 
 
 class ConvPoolFn(Function):
-    """(h, pooled) = (act(conv_k(x, w*wscale) + bias*bias_scale) * gain, avg_pool2d(x, 2)): the two consumers of a
-    DiscriminatorBlock's input (custom_layers.py:202,204).  Owning both lets the backward pass fold the pooled branch's
-    gradient into the epilogue of the conv's data-gradient kernel instead of up-sampling it and adding two
-    full-resolution tensors (3 ms per iteration at 256x256, batch 32)."""
+    """(h, pooled) = (box3?(act(conv_k(x, w*wscale) + bias*bias_scale) * gain), avg_pool2d(x, 2)): the two consumers of a
+    DiscriminatorBlock's input (custom_layers.py:202,204-206).  Owning both lets the backward pass fold the pooled branch's
+    gradient into the epilogue of the conv's data-gradient kernel instead of up-sampling it and adding two full-resolution
+    tensors (3 ms per iteration at 256x256, batch 32); with box=True the blur after the activation joins the node, so its
+    backward and the activation backward are one pass (BoxActBwdFn)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, k, act, gain, wscale, bias_scale):
+    def forward(ctx, x, w, bias, k, act, gain, wscale, bias_scale, box):
         K = _K()
         pw, _ = _prep(w, wscale, False, _need_lo(x))
         y = K.conv_fwd(x, pw, w.shape[0], k, 1, bias=bias, bias_scale=bias_scale, act=act, gain=gain)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
-        ctx.cfg = (k, act, gain, wscale, bias_scale, bias is not None)
-        return y, K.avgpool2(x)
+        ctx.cfg = (k, act, gain, wscale, bias_scale, bias is not None, box)
+        return (K.box3_act(y, ACT_NONE, 1.0) if box else y), K.avgpool2(x)
 
     @staticmethod
     def backward(ctx, gy, gpooled):
         x, w, y = ctx.saved_tensors
-        k, act, gain, wscale, bias_scale, has_bias = ctx.cfg
+        k, act, gain, wscale, bias_scale, has_bias, box = ctx.cfg
         A = w.shape[0]
         want_gb = has_bias and ctx.needs_input_grad[2]
         if gy is None:                                                   # only the pooled branch was used
             gx = AvgPool2TFn.apply(gpooled.contiguous()) if ctx.needs_input_grad[0] else None
-            return gx, None, None, None, None, None, None, None
+            return gx, None, None, None, None, None, None, None, None
         gy = gy.contiguous()
-        if act != ACT_NONE or want_gb:
-            gz, gb = ActBwdFn.apply(gy, y, act, gain, A, want_gb, bias_scale)
+        if box and act != ACT_NONE:
+            gz, gb = BoxActBwdFn.apply(gy, y, act, gain, A, want_gb, bias_scale)
         else:
-            gz, gb = gy, None
+            if box:
+                gy = Box3Fn.apply(gy)
+            if act != ACT_NONE or want_gb:
+                gz, gb = ActBwdFn.apply(gy, y, act, gain, A, want_gb, bias_scale)
+            else:
+                gz, gb = gy, None
         gx = None
         if ctx.needs_input_grad[0]:
             gx = ConvTransposeFn.apply(gz, w, k, 1, wscale, x.shape[-1], None if gpooled is None else gpooled.contiguous())
         gw = ConvWeightGradFn.apply(x, gz, k, 1, wscale, w.shape[0], w.shape[1]) if ctx.needs_input_grad[1] else None
-        return gx, gw, (gb if want_gb else None), None, None, None, None, None
+        return gx, gw, (gb if want_gb else None), None, None, None, None, None, None
+
+
+class BoxActBwdFn(Function):
+    """(gz, gbias) = (box3(gy) * act'(y), bias_scale * sum gz): backward of  act(.) -> box3  in one pass.  Linear in gy."""
+
+    @staticmethod
+    def forward(ctx, gy, y, act, gain, clog, want_gbias, bias_scale):
+        gz, gb = _K().box3_actbwd(gy, y, act, gain, clog, want_gbias)
+        if gb is None:
+            gb = gy.new_zeros((0,), dtype=torch.float32)
+        else:
+            gb = gb * bias_scale if bias_scale != 1.0 else gb
+        ctx.save_for_backward(y)
+        ctx.cfg = (act, gain)
+        ctx.mark_non_differentiable(gb)
+        return gz, gb
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ggz, _ggb):
+        (y,) = ctx.saved_tensors
+        act, gain = ctx.cfg
+        return _K().box3_act_bwd(ggz.contiguous(), y, act, gain), None, None, None, None, None, None
 
 
 class ConvWeightGradFn(Function):

@@ -138,6 +138,11 @@ class EmulatedKernels:
     def box3_act(self, x, act, gain):
         return nhwc(act_fwd(F.avg_pool2d(nchw(x), 3, 1, 1), act) * gain, x.dtype)
 
+    def box3_actbwd(self, gy, y, act, gain, clog, want_gbias):
+        gz = F.avg_pool2d(nchw(gy), 3, 1, 1) * act_grad_from_out(nchw(y), act, gain)
+        gb = gz[:, :clog].sum(dim=(0, 2, 3)) if want_gbias else None
+        return nhwc(gz, gy.dtype), gb
+
     def box3_act_bwd(self, gy, y, act, gain):
         gz = nchw(gy) * (act_grad_from_out(nchw(y), act, gain) if act != ACT_NONE else gain)
         return nhwc(F.avg_pool2d(gz, 3, 1, 1), gy.dtype)

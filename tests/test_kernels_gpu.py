@@ -286,6 +286,19 @@ def test_layout(H, dtype):
     check(H.nhwc_to_nchw(f.cuda(), 13, True), E.nhwc_to_nchw(f, 13, True), torch.float32, "reduce")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 40, 24, 16), (1, 7, 9, 72), (3, 64, 64, 128)])
+def test_box3_actbwd(H, dtype, shape):
+    """backward of act -> blur in one pass: gz = box3(gy) * act'(y), gbias = sum gz"""
+    B, Hh, W, C = shape
+    gy, y = feat((B, Hh, W, ceil8(C)), dtype, 61, C), feat((B, Hh, W, ceil8(C)), dtype, 62, C)
+    gz, gb = H.box3_actbwd(gy.cuda(), y.cuda(), 1, 1.4, C, True)
+    ez, eb = E.box3_actbwd(gy, y, 1, 1.4, C, True)
+    check(gz, ez, dtype, "gz")
+    check(gb, eb, torch.float32, "gbias")
+    assert H.box3_actbwd(gy.cuda(), y.cuda(), 1, 1.4, C, False)[1] is None
+
+
 # ------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,I,O", [(8, 64, 64), (32, 8192, 512), (5, 6, 8), (96, 512, 1), (32, 512, 2048)])
 def test_linear(H, M, I, O):
