@@ -918,7 +918,7 @@ __global__ void unprep_wgrad_kernel(const float* __restrict__ gwp, int A, int Bc
 
 // epilogue of a split-K convolution: y = act(post * ws + bias) * gain + residual   over [B*Hout*Wout][Cout]
 template <typename T>
-__global__ void conv_finalize_kernel(const float* __restrict__ ws, T* __restrict__ y, const float* __restrict__ post,
+__global__ void conv_finalize_kernel(float* __restrict__ ws, T* __restrict__ y, const float* __restrict__ post,
                                      const float* __restrict__ bias, const T* __restrict__ residual,
                                      long long npix, int pix_per_sample, int Cout, int N, float bias_scale, float gain, int act,
                                      int res_half, int Wout) {
@@ -930,6 +930,7 @@ __global__ void conv_finalize_kernel(const float* __restrict__ ws, T* __restrict
   const int b = (int)(pix / pix_per_sample);
   const size_t off = (size_t)pix * Cout + v * 8;
   F8 s = Feat<float>::load(ws + off);
+  Feat<float>::store(ws + off, f8_zero());                         // leave the scratch zeroed for the next split-K launch
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int n = v * 8 + j;
@@ -993,11 +994,9 @@ int dispatch_igemm(const ConvArgs& a_in, int nphase, int dtype, hipStream_t s) {
         if (g_splitk_ws) hipFree(g_splitk_ws);
         g_splitk_ws_bytes = std::max(bytes, (size_t)8 << 20);
         if (hipMalloc((void**)&g_splitk_ws, g_splitk_ws_bytes) != hipSuccess) { g_splitk_ws = nullptr; g_splitk_ws_bytes = 0; ns = 1; }
+        else hipMemsetAsync(g_splitk_ws, 0, g_splitk_ws_bytes, s);   // zeroed once: conv_finalize_kernel re-zeroes what it consumed
       }
-      if (ns > 1) {
-        hipMemsetAsync(g_splitk_ws, 0, bytes, s);
-        a.nsplit = ns; a.ws = g_splitk_ws;
-      }
+      if (ns > 1) { a.nsplit = ns; a.ws = g_splitk_ws; }
     }
   }
   if (dtype == DT_BF16) return launch_igemm<__bf16, 1>(a, nphase, s);

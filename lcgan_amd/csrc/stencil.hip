@@ -66,12 +66,13 @@ __global__ void box3_act_kernel(const T* __restrict__ x, T* __restrict__ y, int 
 
 // gz = box3(gy) * act'(y) ; gbias[c] += sum_{b,p} gz     -- the backward of  y = act(conv + bias) -> box3(y)  up to the conv's
 // pre-activation (DiscriminatorBlock conv0 -> blur, custom_layers.py:204-206): one pass instead of a box-filter pass plus an
-// activation-backward pass.  Same sliding window as box3_act_kernel, over strips of BOXB_RH rows so that the per-channel
+// activation-backward pass.  Same sliding window as box3_act_kernel, over taller strips (BOXB_RH rows) so that the per-channel
 // bias reduction ends in few global atomics (LDS float atomics inside the block).
-constexpr int BOXB_RH = 32;
+// Strip height: 32 rows when that still leaves >= 256K threads, else 8 (small local batches are latency-, not atomics-bound).
 template <typename T>
 __global__ void box3_actbwd_reduce_kernel(const T* __restrict__ gy, const T* __restrict__ y, T* __restrict__ gz,
-                                          float* __restrict__ gbias, int B, int H, int W, int C, int Clog, int act, float gain) {
+                                          float* __restrict__ gbias, int B, int H, int W, int C, int Clog, int act, float gain,
+                                          int BOXB_RH) {
   extern __shared__ float red[];                       // [C]
   const int nvec = C >> 3;
   const int strips = (H + BOXB_RH - 1) / BOXB_RH;
@@ -859,9 +860,10 @@ int lcgan_box3_actbwd_reduce(const void* gy, const void* y, void* gz, float* gbi
   if ((C & 7) || Clog > C) return LCGAN_EINVAL;
   const long long n = (long long)B * H * W * (C / 8);
   ProfScope p(KID_ACT_BWD, 0, (double)n * 8 * 3 * (dtype == DT_BF16 ? 2 : 4), s);
-  const long long nthr = (long long)B * ((H + BOXB_RH - 1) / BOXB_RH) * W * (C / 8);
+  const int rh = n / 32 >= (1 << 18) ? 32 : 8;
+  const long long nthr = (long long)B * ((H + rh - 1) / rh) * W * (C / 8);
   DISPATCH_T(dtype, hipLaunchKernelGGL(box3_actbwd_reduce_kernel<T>, grid1d(nthr), dim3(TPB), C * sizeof(float), s, (const T*)gy,
-                                       (const T*)y, (T*)gz, gbias, B, H, W, C, Clog, act, gain));
+                                       (const T*)y, (T*)gz, gbias, B, H, W, C, Clog, act, gain, rh));
   return launch_status();
 }
 
