@@ -31,6 +31,9 @@ int g_mfma16 = 0;                         // lcgan_set_option(4, ...): halo kern
 int g_wgrad3_small = 0;                   // lcgan_set_option(5, ...): row-segment wgrad kernel for 16/8-wide layers and 1x1 kernels: 0 = only without per-sample scales (multi-sample splits), 1 = always, 2 = never
                                           // (default off: measured 0.5 ms/iteration SLOWER than the generic kernel on those shapes)
 int g_wgrad3_wgs = 0;                     // lcgan_set_option(2, ...): 0 = cost-model split of the row-segment wgrad kernel, > 0 = explicit workgroup target
+int g_halo_min_wgs = 128;                 // lcgan_set_option(6, ...): halo launches with fewer workgroups go to the split-K implicit GEMM
+int g_halo_split_wgs = 0;                 // lcgan_set_option(7, ...): halo launches with fewer workgroups split their channel chunks over blockIdx.z
+                                          // (default off: with 384 the atomics epilogue + finalize pass cost more than the idle CUs, 31.5 vs 29.9 ms at local batch 4)
 int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): TIMING EXPERIMENTS ONLY: skip the wgrad epilogue atomics
 
 constexpr int BM = 128, BN = 128, BK = 32;
@@ -277,6 +280,7 @@ struct HaloArgs {
   TapTable taps[4];
   int hy0[4], hx0[4], hh[4], hw[4];          // per phase: halo origin (min dy, min dx) and extent in input pixels
   int halo_elems;                            // LDS elements reserved for the halo (max over phases)
+  int nsplit; float* ws;                     // split-K over channel chunks: blockIdx.z = phase * nsplit + split; raw fp32 partials -> ws
   int dbg;                                   // TIMING EXPERIMENTS ONLY (option 3): 1 = skip the global stores, 2 = skip the LDS emit too, 4 = skip the main loop
 };
 
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int phase = blockIdx.z, n0 = blockIdx.y * BN;
+  const int phase = blockIdx.z / a.nsplit, split = blockIdx.z - phase * a.nsplit, n0 = blockIdx.y * BN;
   const int tile = blockIdx.x;
   const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
   const TapTable& tt = a.taps[phase];
@@ -341,7 +345,11 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
 
   // ---- weight tile: 128 rows x 4 vectors = 512 items, one per thread; prefetched TWO taps ahead in two named registers ----
   const int brow = tid >> 2;
-  const int ntaps = tt.n, nchunks = a.kc_per_tap, total = ntaps * nchunks;
+  // split-K: this workgroup reduces the channel chunks [cb, nchunks) of its share
+  const int cper = (a.kc_per_tap + a.nsplit - 1) / a.nsplit;
+  const int cb = split * cper, nchunks = min(cb + cper, a.kc_per_tap);
+  if (cb >= nchunks) return;
+  const int ntaps = tt.n, total = ntaps * (nchunks - cb);
   const size_t wrow = (size_t)(n0 + brow) * a.Kpad + hvec * 8;
   const bool bvalid = n0 + brow < a.N;
   auto b_load = [&](int c, int t) -> bf16x8 {
@@ -380,19 +388,19 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
   }
 
   // (c, t) of the tile two steps ahead of the one being computed
-  int lc = 0, lt = 0;
+  int lc = cb, lt = 0;
   auto advance = [&]() { if (++lt == ntaps) { lt = 0; ++lc; } };
 
-  halo_load(0);
+  halo_load(cb * BK);
   halo_store();
-  b_store(0, b_load(0, 0));
+  b_store(0, b_load(cb, 0));
   advance();                                                   // -> tile 1
   bf16x8 r0 = (1 < total) ? b_load(lc, lt) : zero_bf16x8();    // tile 1 in flight
   advance();                                                   // -> tile 2
   bf16x8 r1 = zero_bf16x8();
   __syncthreads();
 
-  int c = 0, t = 0;
+  int c = cb, t = 0;
   // one step: compute tile q from buffer (q & 1); `rs` holds tile q+1 (loaded one step ago), `rl` receives tile q+2
   auto step = [&](int q, bf16x8& rs, bf16x8& rl) {
     if (t == 0 && c + 1 < nchunks) halo_load((c + 1) * BK);    // next chunk's halo: in flight during this chunk's taps
@@ -438,6 +446,43 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
   for (int q = 0; q < ((a.dbg & 4) ? 2 : total); q += 2) {
     step(q, r0, r1);
     if (q + 1 < total) step(q + 1, r1, r0);
+  }
+
+  if (a.nsplit > 1) {                       // split-K: raw partial sums; conv_finalize_kernel applies the epilogue
+    if (M16) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wn * 64 + ni * 16 + (lane & 15);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = wm * 64 + mi * 16 + (lane >> 4) * 4 + r;
+            const int py = ty * HT + (row >> 4), px = tx * HT + (row & 15);
+            if (py < a.Hm && px < a.Wm && n < a.Cout) {
+              const int oy = py * a.out_mul + (phase >> 1), ox = px * a.out_mul + (phase & 1);
+              atomicAdd(a.ws + ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n, acc16[mi][ni][r]);
+            }
+          }
+      }
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int py = ty * HT + (row >> 4), px = tx * HT + (row & 15);
+            if (py < a.Hm && px < a.Wm && n < a.Cout) {
+              const int oy = py * a.out_mul + (phase >> 1), ox = px * a.out_mul + (phase & 1);
+              atomicAdd(a.ws + ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n, acc[mi][ni][r]);
+            }
+          }
+      }
+    }
+    return;
   }
 
   // ---- epilogue: demod/bias/act in registers -> bf16 tile in LDS -> 16-byte coalesced stores (+ residual) ----------------
@@ -510,6 +555,31 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
   }
 }
 
+// fp32 scratch of the split-K paths ([output pixel][Cout] partial sums met by atomics).  Grow-only, owned by the library,
+// zeroed once when allocated: conv_finalize_kernel re-zeroes what it consumes, so launches need no memset.
+float* g_splitk_ws = nullptr;
+size_t g_splitk_ws_bytes = 0;
+float* splitk_scratch(size_t bytes, hipStream_t s) {
+  if (bytes > g_splitk_ws_bytes) {
+    if (g_splitk_ws) hipFree(g_splitk_ws);
+    g_splitk_ws_bytes = std::max(bytes, (size_t)8 << 20);
+    if (hipMalloc((void**)&g_splitk_ws, g_splitk_ws_bytes) != hipSuccess) { g_splitk_ws = nullptr; g_splitk_ws_bytes = 0; return nullptr; }
+    hipMemsetAsync(g_splitk_ws, 0, g_splitk_ws_bytes, s);
+  }
+  return g_splitk_ws;
+}
+template <typename T>
+__global__ void conv_finalize_kernel(float* __restrict__ ws, T* __restrict__ y, const float* __restrict__ post,
+                                     const float* __restrict__ bias, const T* __restrict__ residual,
+                                     long long npix, int pix_per_sample, int Cout, int N, float bias_scale, float gain, int act,
+                                     int res_half, int Wout);
+template <typename T>
+void launch_finalize(const ConvArgs& a, float* ws, hipStream_t s) {
+  const long long npix = (long long)a.B * a.Hout * a.Wout, nthr = npix * (a.Cout / 8);
+  hipLaunchKernelGGL((conv_finalize_kernel<T>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, ws, (T*)a.y, a.post, a.bias,
+                     (const T*)a.residual, npix, a.Hout * a.Wout, a.Cout, a.N, a.bias_scale, a.gain, a.act, a.res_half, a.Wout);
+}
+
 // host side: returns true when the halo kernel was launched for this geometry
 bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   if (c.Hm < HT || c.Wm < HT || c.act == ACT_TANH) return false;
@@ -536,10 +606,18 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   if (max_halo * 4 > (in_mul == 1 ? 3 : 9) * 512) return false;
   // a launch that cannot cover half the CUs (small local batch x low resolution: 16..64 tiles, each walking the full K =
   // 9*Cin reduction) goes to the split-K implicit GEMM instead, which spreads the reduction over ~256 workgroups
-  if (g_use_splitk && c.B * a.tiles_x * a.tiles_y * cdiv(c.Cout, BN) * nphase < 128 && c.taps[0].n * c.kc_per_tap >= 8) return false;
+  const int halo_wgs = c.B * a.tiles_x * a.tiles_y * cdiv(c.Cout, BN) * nphase;
+  if (g_use_splitk && halo_wgs < g_halo_min_wgs && c.taps[0].n * c.kc_per_tap >= 8) return false;
+  // fewer workgroups than ~3/4 of one resident wave (512): split the channel chunks over blockIdx.z (>= 2 chunks per split)
+  a.nsplit = 1; a.ws = nullptr;
+  if (g_use_splitk && halo_wgs < g_halo_split_wgs && c.kc_per_tap >= 4) {
+    const int ns = std::min(c.kc_per_tap / 2, (512 + halo_wgs - 1) / halo_wgs);
+    float* ws = ns > 1 ? splitk_scratch((size_t)c.B * c.Hout * c.Wout * c.Cout * sizeof(float), s) : nullptr;
+    if (ws) { a.nsplit = ns; a.ws = ws; }
+  }
   a.halo_elems = max_halo * HROW;
   const size_t smem = std::max(((size_t)a.halo_elems + 2 * TILE) * sizeof(__bf16), (size_t)256 * (BN + 8) * sizeof(__bf16));
-  dim3 grid(c.B * a.tiles_x * a.tiles_y, cdiv(c.Cout, BN), nphase);
+  dim3 grid(c.B * a.tiles_x * a.tiles_y, cdiv(c.Cout, BN), nphase * a.nsplit);
 #define LAUNCH_HALO(IM, MM)                                                                                             \
   {                                                                                                                     \
     static bool set = false;                                                                                            \
@@ -551,6 +629,7 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   else if (g_mfma16) LAUNCH_HALO(2, true)
   else LAUNCH_HALO(2, false)
 #undef LAUNCH_HALO
+  if (a.nsplit > 1) launch_finalize<__bf16>(c, a.ws, s);
   return true;
 }
 
@@ -965,19 +1044,12 @@ int launch_igemm(const ConvArgs& a, int nphase, hipStream_t s) {
   }
   dim3 grid(cdiv(a.M, BM), cdiv(a.Cout, BN), nphase * a.nsplit);
   hipLaunchKernelGGL((conv_igemm_kernel<T, NS>), grid, dim3(256), smem, s, a);
-  if (a.nsplit > 1) {
-    const long long npix = (long long)a.B * a.Hout * a.Wout, nthr = npix * (a.Cout / 8);
-    hipLaunchKernelGGL((conv_finalize_kernel<T>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a.ws, (T*)a.y, a.post, a.bias,
-                       (const T*)a.residual, npix, a.Hout * a.Wout, a.Cout, a.N, a.bias_scale, a.gain, a.act, a.res_half, a.Wout);
-  }
+  if (a.nsplit > 1) launch_finalize<T>(a, a.ws, s);
   return launch_status();
 }
 
 // Small-M layers (4x4 ... 16x16 grids) are weight-streaming bound and would occupy a handful of CUs: split the (tap, chunk)
 // loop over blockIdx.z so >= ~256 workgroups stream disjoint weight slices; partials meet in an fp32 workspace.
-float* g_splitk_ws = nullptr;
-size_t g_splitk_ws_bytes = 0;
-
 int dispatch_igemm(const ConvArgs& a_in, int nphase, int dtype, hipStream_t s) {
   ConvArgs a = a_in;
   a.nsplit = 1; a.ws = nullptr;
@@ -988,15 +1060,8 @@ int dispatch_igemm(const ConvArgs& a_in, int nphase, int dtype, hipStream_t s) {
   if (g_use_splitk && wgs <= 192 && nq_min >= 8) {
     int ns = std::min(nq_min / 4, (256 + wgs - 1) / wgs);
     if (ns > 1) {
-      const size_t bytes = (size_t)a.B * a.Hout * a.Wout * a.Cout * sizeof(float);
-      if (bytes > g_splitk_ws_bytes) {
-        // grow-only scratch owned by the library (small layers only: <= a few MB); allocation happens outside any capture
-        if (g_splitk_ws) hipFree(g_splitk_ws);
-        g_splitk_ws_bytes = std::max(bytes, (size_t)8 << 20);
-        if (hipMalloc((void**)&g_splitk_ws, g_splitk_ws_bytes) != hipSuccess) { g_splitk_ws = nullptr; g_splitk_ws_bytes = 0; ns = 1; }
-        else hipMemsetAsync(g_splitk_ws, 0, g_splitk_ws_bytes, s);   // zeroed once: conv_finalize_kernel re-zeroes what it consumed
-      }
-      if (ns > 1) { a.nsplit = ns; a.ws = g_splitk_ws; }
+      float* ws = splitk_scratch((size_t)a.B * a.Hout * a.Wout * a.Cout * sizeof(float), s);
+      if (ws) { a.nsplit = ns; a.ws = ws; }
     }
   }
   if (dtype == DT_BF16) return launch_igemm<__bf16, 1>(a, nphase, s);
@@ -1019,6 +1084,8 @@ int lcgan_set_option(int option, int value) {
   if (option == 3) { const int old = g_dbg_no_atomics; g_dbg_no_atomics = value; return old; }
   if (option == 4) { const int old = g_mfma16; g_mfma16 = value; return old; }
   if (option == 5) { const int old = g_wgrad3_small; g_wgrad3_small = value; return old; }
+  if (option == 6) { const int old = g_halo_min_wgs; g_halo_min_wgs = value; return old; }
+  if (option == 7) { const int old = g_halo_split_wgs; g_halo_split_wgs = value; return old; }
   return LCGAN_EINVAL;
 }
 

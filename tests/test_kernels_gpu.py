@@ -72,6 +72,9 @@ CONV_CASES = [
     (1, 20, 40, 40, 24, 3, 1),
     (2, 32, 32, 128, 256, 1, 1),
     (2, 64, 32, 72, 136, 3, 2),
+    # few tiles x deep reduction: the halo kernel splits its channel chunks over blockIdx.z (fp32 partials + finalize)
+    (1, 32, 32, 256, 128, 3, 1),
+    (2, 32, 32, 160, 64, 3, 2),
 ]
 
 
