@@ -22,6 +22,10 @@ for s in "$@"; do
     benchq)  step benchq 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline ;;
     prof)    export TMPDIR=/tmp
              step prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline ;;
+    pmc)     export TMPDIR=/tmp
+             step pmc_fetch 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline
+             step pmc_write 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline
+             python3 scripts/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_traffic.json | tee -a gpurun_out/summary.log ;;
     prof4)   export TMPDIR=/tmp
              step prof4 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof4 -- python3 bench.py --steps 2 --warmup 1 --batch 4 --no-cpu-baseline --no-roofline ;;
   esac
