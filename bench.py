@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="GLOBAL batch (worker.py:35 splits it over the ranks)")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--epoch-type", choices=["r1", "odd", "even", "cycle"], default="r1")
+    ap.add_argument("--freezeD-layer", type=int, default=-1,
+                    help="BASELINE config 4: freeze the first discriminator layers (main.py --freezeD_layer, with freezeD_start 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -106,7 +108,8 @@ def main():
     from tests.helpers import make_args
     config.set_feature_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
     assert kernels.backend_name() == "hip"
-    args = make_args(a.res, a.batch)
+    extra = dict(freezeD_start=0, freezeD_layer=a.freezeD_layer) if a.freezeD_layer >= 0 else {}
+    args = make_args(a.res, a.batch, **extra)
     torch.manual_seed(0)                                   # identical reference-style init on every rank
     w = worker.WORKER(args, local_rank, world, device=dev)
     torch.manual_seed(1 + rank)                            # different latents per rank
@@ -141,10 +144,12 @@ def main():
         "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": f"LC-GAN G+D iteration ({a.epoch_type}: train_generator + ema + train_discriminator"
-                               f"{' with R1' if a.epoch_type == 'r1' else ''}), {a.res}x{a.res}, global batch {a.batch}",
+                               f"{' with R1' if a.epoch_type == 'r1' else ''}), {a.res}x{a.res}, global batch {a.batch}"
+                               f"{f', freezeD_layer {a.freezeD_layer}' if a.freezeD_layer >= 0 else ''}",
                    "global_batch": a.batch, "resolution": a.res, "parallelism": f"dp{world}",
                    "algorithmic_tflop_per_step": fl_step / 1e12},
-        "step_mfma_frac": fl_step / (dt / a.steps) / (world * PEAK_BF16_DENSE),
+        # (with frozen discriminator layers part of the backward is skipped: the full-step FLOP formula does not apply)
+        "step_mfma_frac": fl_step / (dt / a.steps) / (world * PEAK_BF16_DENSE) if a.freezeD_layer < 0 else None,
     }
 
     if rank == 0 and not a.no_roofline:
