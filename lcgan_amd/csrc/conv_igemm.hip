@@ -34,7 +34,8 @@ int g_wgrad3_wgs = 0;                     // lcgan_set_option(2, ...): 0 = cost-
 int g_halo_min_wgs = 128;                 // lcgan_set_option(6, ...): halo launches with fewer workgroups go to the split-K implicit GEMM
 int g_halo_split_wgs = 0;                 // lcgan_set_option(7, ...): halo launches with fewer workgroups split their channel chunks over blockIdx.z
                                           // (default off: with 384 the atomics epilogue + finalize pass cost more than the idle CUs, 31.5 vs 29.9 ms at local batch 4)
-int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): TIMING EXPERIMENTS ONLY: skip the wgrad epilogue atomics
+int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): TIMING EXPERIMENTS ONLY, bit mask: 16 = skip the wgrad3 epilogue atomics;
+                                          // halo kernel: 1 = skip the output stores, 2 = skip the LDS emit, 4 = two main-loop steps only, 8 = linear tile order
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDS_ROW = 40;               // bf16 per staged row: 32 + 8 pad (80 B stride: conflict-free ds_read_b128)
@@ -294,7 +295,10 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int phase = blockIdx.z / a.nsplit, split = blockIdx.z - phase * a.nsplit, n0 = blockIdx.y * BN;
-  const int tile = blockIdx.x;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so every XCD gets a contiguous run of tiles
+  // (neighbouring tiles share halo columns and rows in that XCD's L2): -1.3 % on the conv launches of an iteration
+  int tile = blockIdx.x;
+  if (!(a.dbg & 8) && (gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
   const TapTable& tt = a.taps[phase];
   const int hy0 = a.hy0[phase], hx0 = a.hx0[phase], hh = a.hh[phase], hw = a.hw[phase];
@@ -1226,7 +1230,7 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
       (long long)B * Hx * Wx * Cx < (1ll << 31) && (long long)B * Hg * Wg * Cg < (1ll << 31)) {
     // row-segment kernel: chunk = (sample, row group, SEGW-column segment) of `seg` positions; grid.z = split x kernel row
     const int seg = segw == 64 ? 64 : 32, rows = seg / segw, nkx = k;
-    a.dbg_no_atomics = g_dbg_no_atomics;
+    a.dbg_no_atomics = g_dbg_no_atomics & 16;
     const int tiles3 = cdiv(A, 128) * cdiv(Bc, 128) * nkx;
     const bool scaled = pre_x || pre_g;
     const int groups = scaled ? B : 1;
