@@ -1248,7 +1248,7 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
       const int min_chunks = 2048 / seg;
       parts = max(1, min(parts, cps / min_chunks > 0 ? cps / min_chunks : 1));
     } else {
-      const int occ = smem3 * 2 <= 160 * 1024 ? 2 : 1;
+      const int occ = 1;                                          // 166-236 VGPRs: one 512-thread workgroup per CU whatever the LDS size
       const int max_parts = max(1, cps / (1024 / seg));
       double best = 1e30;
       for (int pt = 1; pt <= max_parts; ++pt) {

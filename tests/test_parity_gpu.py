@@ -183,7 +183,7 @@ def test_full_size_properties_256():
         with torch.no_grad():
             D.module.logit_mapper.mlp[0].weight.weight.mul_(2.0)
         b = r1_of()
-        assert abs(b / a - 4.0) <= 2e-2, (a, b)
+        assert abs(b / a - 4.0) <= 5e-2, (a, b)     # power-of-two scaling is exact; what remains is the run-to-run noise above (x4)
         with torch.no_grad():
             D.module.logit_mapper.mlp[0].weight.weight.mul_(0.5)
         before = {k: v.clone() for k, v in w.generator.module.state_dict().items()}
