@@ -131,27 +131,31 @@ __global__ void box3_actbwd_reduce_kernel(const T* __restrict__ gy, const T* __r
   for (int c = threadIdx.x; c < Clog; c += TPB) atomicAdd(gbias + c, red[c]);
 }
 
-// gx = box3(gy * act'(y))   (box3 is self-adjoint)
+// gx = box3(gy * act'(y))   (box3 is self-adjoint).  Same separable sliding window as box3_act_kernel: a thread owns one
+// (column, 8-channel vector), walks BOX_RH rows and keeps the last three horizontal 3-sums of gy*act'(y) in registers
+// (6 vector loads per output instead of 18: the 9-tap version ran 2.2x off the HBM roofline).
 template <typename T>
 __global__ void box3_act_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ y, T* __restrict__ gx,
                                     int B, int H, int W, int C, int act, float gain) {
   const int nvec = C >> 3;
-  const long long total = (long long)B * H * W * nvec;
+  const int strips = (H + BOX_RH - 1) / BOX_RH;
+  const long long total = (long long)B * strips * W * nvec;
   const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
   if (gid >= total) return;
   const int v = (int)(gid % nvec);
-  const long long pix = gid / nvec;
-  const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
-  F8 s = f8_zero();
-#pragma unroll
-  for (int dy = -1; dy <= 1; ++dy) {
-    const int yy = h + dy;
-    if ((unsigned)yy >= (unsigned)H) continue;
+  long long t = gid / nvec;
+  const int w = (int)(t % W); t /= W;
+  const int strip = (int)(t % strips), b = (int)(t / strips);
+  const int h0 = strip * BOX_RH, h1 = min(h0 + BOX_RH, H);
+  const size_t base = (size_t)b * H * W * C + v * 8;
+  auto rowsum = [&](int hh) {
+    F8 s = f8_zero();
+    if ((unsigned)hh >= (unsigned)H) return s;
 #pragma unroll
     for (int dx = -1; dx <= 1; ++dx) {
       const int xx = w + dx;
       if ((unsigned)xx >= (unsigned)W) continue;
-      const size_t off = (((size_t)b * H + yy) * W + xx) * C + v * 8;
+      const size_t off = base + ((size_t)hh * W + xx) * C;
       const F8 g = Feat<T>::load(gy + off);
       if (act == ACT_NONE) {
 #pragma unroll
@@ -162,10 +166,17 @@ __global__ void box3_act_bwd_kernel(const T* __restrict__ gy, const T* __restric
         for (int j = 0; j < 8; ++j) s.v[j] += g.v[j] * act_grad_from_out(yo.v[j], act, gain);
       }
     }
-  }
+    return s;
+  };
+  F8 r0 = rowsum(h0 - 1), r1 = rowsum(h0);
+  for (int hh = h0; hh < h1; ++hh) {
+    const F8 r2 = rowsum(hh + 1);
+    F8 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) s.v[j] *= (1.f / 9.f);
-  Feat<T>::store(gx + (size_t)pix * C + v * 8, s);
+    for (int j = 0; j < 8; ++j) o.v[j] = (r0.v[j] + r1.v[j] + r2.v[j]) * (1.f / 9.f);
+    Feat<T>::store(gx + base + ((size_t)hh * W + w) * C, o);
+    r0 = r1; r1 = r2;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -724,31 +735,31 @@ __global__ void rgb_expand_kernel(const float* __restrict__ img, const float* __
   }
 }
 
+// One block = PB consecutive pixels of ONE sample; a thread keeps its 3 x 8 weights in registers and walks the pixels (the first
+// version re-read the 24 weights from L1 for every 16-byte feature vector: 2.9 TB/s).
 template <typename T>
 __global__ void rgb_reduce_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                  float bias_scale, float* __restrict__ img, int B, int HW, int C, int per_sample) {
-  const int nvec = C >> 3;                                   // power of two <= 64
-  const long long total = (long long)B * HW * nvec;
-  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
-  const bool live = gid < total;
-  const long long gg = live ? gid : total - 1;
-  const int v = (int)(gg % nvec);
-  const long long pix = gg / nvec;
-  const int p = (int)(pix % HW), b = (int)(pix / HW);
+                                  float bias_scale, float* __restrict__ img, int HW, int C, int per_sample, int PB) {
+  const int nvec = C >> 3;                                   // power of two <= 64: a pixel's vectors sit in one wave
+  const int groups = TPB / nvec;
+  const int grp = threadIdx.x / nvec, v = threadIdx.x - grp * nvec;
+  const int b = blockIdx.y;
   const float* wb = w + (per_sample ? (size_t)b * 3 * C : 0);
-  const F8 t = Feat<T>::load(x + (size_t)pix * C + v * 8);
-  float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+  float w0[8], w1[8], w2[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int c = v * 8 + j;
-    o0 += t.v[j] * wb[c]; o1 += t.v[j] * wb[C + c]; o2 += t.v[j] * wb[2 * C + c];
-  }
-  for (int o = nvec >> 1; o > 0; o >>= 1) { o0 += __shfl_xor(o0, o, 64); o1 += __shfl_xor(o1, o, 64); o2 += __shfl_xor(o2, o, 64); }
-  if (live && v == 0) {
-    const float b0 = bias ? bias[0] * bias_scale : 0.f, b1 = bias ? bias[1] * bias_scale : 0.f, b2 = bias ? bias[2] * bias_scale : 0.f;
-    img[((size_t)b * 3 + 0) * HW + p] = o0 + b0;
-    img[((size_t)b * 3 + 1) * HW + p] = o1 + b1;
-    img[((size_t)b * 3 + 2) * HW + p] = o2 + b2;
+  for (int j = 0; j < 8; ++j) { const int c = v * 8 + j; w0[j] = wb[c]; w1[j] = wb[C + c]; w2[j] = wb[2 * C + c]; }
+  const float b0 = bias ? bias[0] * bias_scale : 0.f, b1 = bias ? bias[1] * bias_scale : 0.f, b2 = bias ? bias[2] * bias_scale : 0.f;
+  const int p0 = blockIdx.x * PB, p1 = min(p0 + PB, HW);
+  float* ib = img + (size_t)b * 3 * HW;
+  for (int pb = p0; pb < p1; pb += groups) {                 // every lane runs every trip (the shuffles need the whole wave)
+    const int p = pb + grp;
+    const bool live = p < p1;
+    const F8 t = live ? Feat<T>::load(x + ((size_t)b * HW + p) * C + v * 8) : f8_zero();
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { o0 += t.v[j] * w0[j]; o1 += t.v[j] * w1[j]; o2 += t.v[j] * w2[j]; }
+    for (int o = nvec >> 1; o > 0; o >>= 1) { o0 += __shfl_xor(o0, o, 64); o1 += __shfl_xor(o1, o, 64); o2 += __shfl_xor(o2, o, 64); }
+    if (live && v == 0) { ib[p] = o0 + b0; ib[HW + p] = o1 + b1; ib[2 * HW + p] = o2 + b2; }
   }
 }
 
@@ -849,7 +860,8 @@ int lcgan_box3_act_bwd(const void* gy, const void* y, void* gx, int B, int H, in
   if (C & 7) return LCGAN_EINVAL;
   const long long n = (long long)B * H * W * (C / 8);
   ProfScope p(KID_STENCIL, 0, (double)n * 8 * 3 * (dtype == DT_BF16 ? 2 : 4), s);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(box3_act_bwd_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)gy, (const T*)y, (T*)gx, B, H, W, C, act, gain));
+  const long long nthr = (long long)B * ((H + BOX_RH - 1) / BOX_RH) * W * (C / 8);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(box3_act_bwd_kernel<T>, grid1d(nthr), dim3(TPB), 0, s, (const T*)gy, (const T*)y, (T*)gx, B, H, W, C, act, gain));
   return launch_status();
 }
 
@@ -1014,8 +1026,9 @@ int lcgan_rgb_reduce(const void* x, const float* w, const float* bias, float bia
   if ((C & 7) || !pow2_le64(C / 8)) return LCGAN_EINVAL;
   const long long n = (long long)B * HW * (C / 8);
   ProfScope p(KID_RGB, 0, (double)n * 8 * (dtype == DT_BF16 ? 2 : 4), s);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(rgb_reduce_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)x, w, bias, bias_scale, img,
-                                       B, HW, C, per_sample));
+  const int PB = 256;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(rgb_reduce_kernel<T>, dim3(cdiv(HW, PB), B), dim3(TPB), 0, s, (const T*)x, w, bias, bias_scale, img,
+                                       HW, C, per_sample, PB));
   return launch_status();
 }
 // gw[bw][o][c] += sum_p img[b,o,p] feat[b,p,c]   (gw must be zeroed by the caller)
