@@ -30,6 +30,13 @@ extern "C" {
  * (parts = 1 for dtype bf16, 3 for dtype f32); wsq [A][Bc] (= sum_taps (scale*w)^2, the demodulation statistic) may be NULL. */
 int lcgan_conv_weight_prep(const float* w, int A, int Bc, int k, float scale, int transpose,
                            void* wp, int parts, float* wsq, void* stream);
+/* every weight preparation of a network in one launch (EqualizedWeight.forward custom_layers.py:14 for all its convs, both
+ * GEMM layouts, + the demodulation statistics).  descs: DEVICE array of 64-byte jobs {const float* w; int64 out_off (bf16
+ * elements into out_base); int64 wsq_off (floats into wsq_base); int A, Bc, kk, transpose, parts, N, Kc, Kpad; float scale;
+ * int pad}; chunk_entry / chunk_index: device int arrays, one entry per 16384-element chunk of a job (index >= 0: prepared
+ * elements, < 0: wsq chunk -index-1).  Output layout per job as lcgan_conv_weight_prep. */
+int lcgan_conv_weight_prep_group(const void* descs, const int* chunk_entry, const int* chunk_index, int n_chunks,
+                                 void* out_base, float* wsq_base, double total_elems, void* stream);
 /* gw[a][b][t] = scale*gwp[t][a][b] + 2 scale^2 w[a][b][t] gwsq[a][b]  (w, gwsq may be NULL);
  * transposed != 0 reads gwp as [t][Bc][A] (weight gradient of the transposed convolution) */
 int lcgan_conv_wgrad_unprep(const float* gwp, int A, int Bc, int k, float scale, int transposed, const float* w,

@@ -17,6 +17,7 @@ P, I, F, D, LL = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_longlong
 SIGNATURES = {
     "lcgan_conv_weight_prep": [P, I, I, I, F, I, P, I, P, P],
     "lcgan_conv_wgrad_unprep": [P, I, I, I, F, I, P, P, P, P],
+    "lcgan_conv_weight_prep_group": [P, P, P, I, P, P, D, P],
     "lcgan_conv_fwd": [P, P, P, I, I, I, I, I, I, I, I, P, P, P, F, I, F, P, I, I, P],
     "lcgan_conv_bwd_data": [P, P, P, I, I, I, I, I, I, I, I, P, P, P, F, I, F, P, I, I, P],
     "lcgan_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P, I, P],

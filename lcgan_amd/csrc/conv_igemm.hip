@@ -973,6 +973,48 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, int A, int Bc, i
   }
 }
 
+// All weight preparations of a network in ONE launch (after its Adam step every conv weight needs its forward layout, its
+// transposed layout and, for modulated convs, the demodulation statistic: ~120 launches per iteration otherwise).  A device
+// table describes the jobs; a block handles one 16384-element chunk of one job (chunk_index >= 0: prepared-weight elements,
+// < 0: chunk -index-1 of the wsq statistic).  Outputs live in two flat buffers at the offsets recorded in the table.
+struct PrepDesc { const float* w; long long out_off; long long wsq_off; int A, Bc, kk, transpose, parts, N, Kc, Kpad; float scale; int pad; };
+constexpr int PREP_CHUNK = 16384;
+__global__ __launch_bounds__(256) void prep_group_kernel(const PrepDesc* __restrict__ descs, const int* __restrict__ chunk_entry,
+                                                         const int* __restrict__ chunk_index, __bf16* __restrict__ out_base,
+                                                         float* __restrict__ wsq_base) {
+  const PrepDesc d = descs[chunk_entry[blockIdx.x]];
+  const int ci = chunk_index[blockIdx.x];
+  if (ci >= 0) {
+    const size_t total = (size_t)d.kk * d.N * d.Kpad;
+    const size_t beg = (size_t)ci * PREP_CHUNK, end = min(beg + PREP_CHUNK, total);
+    __bf16* out = out_base + d.out_off;
+    for (size_t idx = beg + threadIdx.x; idx < end; idx += 256) {
+      const int c = (int)(idx % d.Kpad);
+      const int n = (int)((idx / d.Kpad) % d.N);
+      const int t = (int)(idx / ((size_t)d.Kpad * d.N));
+      float v = 0.f;
+      if (c < d.Kc) {
+        const int aa = d.transpose ? c : n, bb = d.transpose ? n : c;
+        v = d.w[((size_t)aa * d.Bc + bb) * d.kk + t] * d.scale;
+      }
+      for (int pp = 0; pp < d.parts; ++pp) {
+        const __bf16 h = (__bf16)v;
+        out[(size_t)pp * total + idx] = h;
+        v -= (float)h;
+      }
+    }
+  } else {
+    const int AB = d.A * d.Bc;
+    const int beg = (-ci - 1) * PREP_CHUNK, end = min(beg + PREP_CHUNK, AB);
+    float* wsq = wsq_base + d.wsq_off;
+    for (int i = beg + threadIdx.x; i < end; i += 256) {
+      float acc = 0.f;
+      for (int t = 0; t < d.kk; ++t) { const float v = d.w[(size_t)i * d.kk + t] * d.scale; acc += v * v; }
+      wsq[i] = acc;
+    }
+  }
+}
+
 // wsq[a][b] = sum_t (scale * w[a][b][t])^2      (demodulation statistic, custom_layers.py:67)
 __global__ void wsq_kernel(const float* __restrict__ w, int AB, int kk, float scale, float* __restrict__ wsq) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1103,6 +1145,19 @@ int lcgan_conv_weight_prep(const float* w, int A, int Bc, int k, float scale, in
   hipLaunchKernelGGL(prep_weight_kernel, dim3((unsigned)min((size_t)4096, (total + 255) / 256)), dim3(256), 0, s,
                      w, A, Bc, kk, scale, transpose, (__bf16*)wp, parts, N, Kc, Kpad);
   if (wsq) hipLaunchKernelGGL(wsq_kernel, dim3(cdiv((long long)A * Bc, 256)), dim3(256), 0, s, w, A * Bc, kk, scale, wsq);
+  return launch_status();
+}
+
+// descs: device array of 64-byte job descriptors {w (8 B), out_off (8 B, bf16 elements), wsq_off (8 B, floats, unused when the
+// job has no wsq chunks), A, Bc, kk, transpose, parts, N, Kc, Kpad (8 ints), scale (float), pad}; chunk_entry / chunk_index:
+// device int arrays, one entry per 16384-element chunk (chunk_index >= 0: prepared elements, < 0: wsq chunk -index-1).
+int lcgan_conv_weight_prep_group(const void* descs, const int* chunk_entry, const int* chunk_index, int n_chunks,
+                                 void* out_base, float* wsq_base, double total_elems, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n_chunks <= 0) return LCGAN_OK;
+  ProfScope p(KID_WEIGHT_PREP, 0, total_elems * 6.0, s);
+  hipLaunchKernelGGL(prep_group_kernel, dim3(n_chunks), dim3(256), 0, s, (const PrepDesc*)descs, chunk_entry, chunk_index,
+                     (__bf16*)out_base, wsq_base);
   return launch_status();
 }
 

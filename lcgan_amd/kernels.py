@@ -103,6 +103,60 @@ class HipKernels:
                    self._stream())
         return PreparedWeight(buf, parts, N, Kpad, k), wsq
 
+    _PREP_DESC = None
+    PREP_CHUNK = 16384
+
+    def prep_weight_group(self, jobs):
+        """jobs: [(w, scale, transpose, need_lo, want_wsq)] -> [(PreparedWeight, wsq | None)] from ONE launch.  The device job
+        table only depends on the parameters' addresses / shapes and is cached."""
+        import numpy as np
+        if HipKernels._PREP_DESC is None:
+            HipKernels._PREP_DESC = np.dtype([("w", "<u8"), ("out_off", "<i8"), ("wsq_off", "<i8"), ("A", "<i4"), ("Bc", "<i4"),
+                                              ("kk", "<i4"), ("transpose", "<i4"), ("parts", "<i4"), ("N", "<i4"), ("Kc", "<i4"),
+                                              ("Kpad", "<i4"), ("scale", "<f4"), ("pad", "<i4")])
+            assert HipKernels._PREP_DESC.itemsize == 64
+            self._prep_tables = {}
+        dev = jobs[0][0].device
+        sig = tuple((w.data_ptr(), tuple(w.shape), float(sc), bool(tr), bool(lo), bool(ws)) for w, sc, tr, lo, ws in jobs)
+        tab = self._prep_tables.get(sig)
+        if tab is None:
+            if len(self._prep_tables) > 64:
+                self._prep_tables.clear()
+            arr = np.zeros(len(jobs), dtype=HipKernels._PREP_DESC)
+            ce, ci, meta = [], [], []
+            out_off = wsq_off = 0
+            for i, (w, sc, tr, lo, ws) in enumerate(jobs):
+                self._chk(w)
+                A, Bc, k, _ = w.shape
+                N, Kc = (Bc, A) if tr else (A, Bc)
+                Kpad = (Kc + 31) // 32 * 32
+                parts = 3 if lo else 1
+                total = k * k * N * Kpad
+                arr[i] = (w.data_ptr(), out_off, wsq_off, A, Bc, k * k, int(tr), parts, N, Kc, Kpad, sc, 0)
+                n = (total + self.PREP_CHUNK - 1) // self.PREP_CHUNK
+                ce += [i] * n
+                ci += list(range(n))
+                if ws:
+                    n = (A * Bc + self.PREP_CHUNK - 1) // self.PREP_CHUNK
+                    ce += [i] * n
+                    ci += [-(j + 1) for j in range(n)]
+                meta.append((out_off, parts, total, N, Kpad, k, wsq_off if ws else -1, A, Bc))
+                out_off += parts * total
+                wsq_off += A * Bc if ws else 0
+            tab = (torch.from_numpy(arr.view(np.uint8).copy()).to(dev), torch.tensor(ce, dtype=torch.int32).to(dev),
+                   torch.tensor(ci, dtype=torch.int32).to(dev), meta, out_off, wsq_off)
+            self._prep_tables[sig] = tab
+        descs, ce, ci, meta, n_out, n_wsq = tab
+        out = torch.empty((n_out,), dtype=torch.bfloat16, device=dev)
+        wsqs = torch.empty((max(n_wsq, 1),), dtype=torch.float32, device=dev)
+        self._call("lcgan_conv_weight_prep_group", descs.data_ptr(), ce.data_ptr(), ci.data_ptr(), ce.numel(), out.data_ptr(),
+                   wsqs.data_ptr(), float(n_out), self._stream())
+        res = []
+        for (o, parts, total, N, Kpad, k, wo, A, Bc) in meta:
+            buf = out[o:o + parts * total].view(parts, k * k, N, Kpad)
+            res.append((PreparedWeight(buf, parts, N, Kpad, k), wsqs[wo:wo + A * Bc].view(A, Bc) if wo >= 0 else None))
+        return res
+
     def unprep_wgrad(self, gwp: Tensor, A: int, Bc: int, k: int, scale: float, transposed: bool = False,
                      w: Optional[Tensor] = None, gwsq: Optional[Tensor] = None) -> Tensor:
         self._chk(gwp, w, gwsq)

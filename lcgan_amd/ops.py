@@ -47,11 +47,50 @@ def bump_weight_epoch() -> None:
     _weight_epoch += 1
 
 
+_recipes: dict = {}         # id(param) -> [weakref(param), {(scale, transpose, need_lo): want_wsq}]   (survives invalidation)
+_groups: dict = {}          # id(param) -> _Group of the invalidation that last hit it
+
+
+class _Group:
+    """The parameters rewritten by one optimiser / EMA step: their prepared copies are rebuilt together, in one launch, the
+    first time any of them is needed again (96 prep + 25 wsq launches per iteration otherwise)."""
+    __slots__ = ("refs", "done")
+
+    def __init__(self, params):
+        import weakref
+        self.refs = [weakref.ref(p) for p in params]
+        self.done = False
+
+
 def invalidate_weights(params) -> None:
     """Invalidate the prepared copies of exactly these parameters (called by the Adam / EMA kernels' wrappers, which rewrite
     parameters through raw pointers without touching torch's version counters)."""
+    params = list(params)
+    grp = _Group(params)
     for p in params:
         _prep_cache.pop(id(p), None)
+        _groups[id(p)] = grp
+
+
+def _prep_group(grp) -> None:
+    import weakref
+    jobs, owners = [], []
+    for r in grp.refs:
+        p = r()
+        rec = _recipes.get(id(p)) if p is not None else None
+        if rec is None or rec[0]() is not p:
+            continue
+        for (scale, transpose, need_lo), want_wsq in rec[1].items():
+            jobs.append((p, scale, transpose, need_lo, want_wsq))
+            owners.append(p)
+    if len(jobs) < 2:
+        return
+    for (p, scale, transpose, need_lo, _), hit in zip(jobs, _K().prep_weight_group(jobs)):
+        ent = _prep_cache.get(id(p))
+        if ent is None or ent[0]() is not p or ent[1] != p._version or ent[2] != _weight_epoch:
+            ent = [weakref.ref(p), p._version, _weight_epoch, {}]
+            _prep_cache[id(p)] = ent
+        ent[3][(scale, transpose, need_lo)] = hit
 
 
 def _prep(w: Tensor, scale: float, transpose: bool, need_lo: bool, want_wsq: bool = False):
@@ -59,17 +98,37 @@ def _prep(w: Tensor, scale: float, transpose: bool, need_lo: bool, want_wsq: boo
     K = _K()
     if not isinstance(w, torch.nn.Parameter):
         return K.prep_weight(w, scale, transpose, need_lo, want_wsq)
+    key = (float(scale), bool(transpose), bool(need_lo))
     ent = _prep_cache.get(id(w))
-    if ent is None or ent[0]() is not w or ent[1] != w._version or ent[2] != _weight_epoch:
+    valid = ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == _weight_epoch
+    hit = ent[3].get(key) if valid else None
+    if hit is not None and not (want_wsq and hit[1] is None):
+        return hit
+    # miss: remember the recipe, then rebuild -- the whole group this parameter was invalidated with, if that is still due
+    rec = _recipes.get(id(w))
+    if rec is None or rec[0]() is not w:
+        if len(_recipes) > 4096:
+            _recipes.clear()
+        rec = [weakref.ref(w), {}]
+        _recipes[id(w)] = rec
+    known = key in rec[1] and (rec[1][key] or not want_wsq)
+    rec[1][key] = rec[1].get(key, False) or want_wsq
+    grp = _groups.get(id(w))
+    if known and grp is not None and not grp.done:
+        grp.done = True
+        _prep_group(grp)
+        ent = _prep_cache.get(id(w))
+        valid = ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == _weight_epoch
+        hit = ent[3].get(key) if valid else None
+        if hit is not None and not (want_wsq and hit[1] is None):
+            return hit
+    if not valid:
         if len(_prep_cache) > 4096:                       # parameters of dead modules: drop everything, it refills in one step
             _prep_cache.clear()
         ent = [weakref.ref(w), w._version, _weight_epoch, {}]
         _prep_cache[id(w)] = ent
-    key = (float(scale), bool(transpose), bool(need_lo))
-    hit = ent[3].get(key)
-    if hit is None or (want_wsq and hit[1] is None):
-        hit = K.prep_weight(w, scale, transpose, need_lo, want_wsq or (hit is not None and hit[1] is not None))
-        ent[3][key] = hit
+    hit = K.prep_weight(w, scale, transpose, need_lo, want_wsq or (hit is not None and hit[1] is not None))
+    ent[3][key] = hit
     return hit
 
 

@@ -97,6 +97,9 @@ class EmulatedKernels:
             y = y + residual.float()
         return y.to(dtype)
 
+    def prep_weight_group(self, jobs):
+        return [self.prep_weight(w, sc, tr, lo, ws) for w, sc, tr, lo, ws in jobs]
+
     @staticmethod
     def _res(residual, half):
         if residual is None or not half:

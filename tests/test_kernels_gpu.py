@@ -78,6 +78,23 @@ CONV_CASES = [
 ]
 
 
+def test_prep_weight_group(H):
+    """all preparations of a network in one launch == the single-weight kernel, bit for bit (both layouts, parts, wsq)"""
+    g = torch.Generator().manual_seed(5)
+    ws = [torch.randn(s, generator=g).cuda() for s in [(64, 40, 3, 3), (8, 128, 3, 3), (136, 72, 1, 1), (256, 256, 3, 3)]]
+    jobs = [(ws[0], 0.1, False, False, True), (ws[0], 0.1, True, False, False), (ws[1], 0.2, False, True, False),
+            (ws[2], 0.3, True, True, True), (ws[3], 0.05, False, False, True), (ws[3], 0.05, True, False, False)]
+    for rep in range(2):                                   # second round takes the cached job table
+        got = H.prep_weight_group(jobs)
+        for (w, sc, tr, lo, wq), (pw, wsq) in zip(jobs, got):
+            ref_pw, ref_wsq = H.prep_weight(w, sc, tr, lo, wq)
+            assert (pw.parts, pw.N, pw.Kpad, pw.k) == (ref_pw.parts, ref_pw.N, ref_pw.Kpad, ref_pw.k)
+            assert torch.equal(pw.buf, ref_pw.buf)
+            assert (wsq is None) == (ref_wsq is None)
+            if wsq is not None:
+                assert torch.equal(wsq, ref_wsq)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd(H, dtype, case):
