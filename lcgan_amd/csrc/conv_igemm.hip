@@ -34,6 +34,7 @@ int g_wgrad3_wgs = 0;                     // lcgan_set_option(2, ...): 0 = cost-
 int g_halo_min_wgs = 128;                 // lcgan_set_option(6, ...): halo launches with fewer workgroups go to the split-K implicit GEMM
 int g_halo_split_wgs = 0;                 // lcgan_set_option(7, ...): halo launches with fewer workgroups split their channel chunks over blockIdx.z
                                           // (default off: with 384 the atomics epilogue + finalize pass cost more than the idle CUs, 31.5 vs 29.9 ms at local batch 4)
+int g_wgrad_slab_min = 4;                 // lcgan_set_option(8, ...): row-segment wgrad launches with at least this many splits reduce through a slab instead of atomics (0 = never)
 int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): TIMING EXPERIMENTS ONLY, bit mask: 16 = skip the wgrad3 epilogue atomics;
                                           // halo kernel: 1 = skip the output stores, 2 = skip the LDS emit, 4 = two main-loop steps only, 8 = linear tile order
 
@@ -651,6 +652,7 @@ struct WgradArgs {
   int chunks_per_split, nsplit, nchunks;
   int parts;                                 // wgrad3: split = group * parts + part
   int cps_group;                             // wgrad3: chunks per group (group = one sample when per-sample scales exist, else the whole batch)
+  float* slab;                               // wgrad3: non-null = every split stores its partial tile to slab[split][tap][A][Bc] (plain stores) instead of atomics
   int dbg_no_atomics;
 };
 
@@ -941,10 +943,34 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
         const int aa = a0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (aa < a.A && cc < a.Bc && !a.dbg_no_atomics) {
           const float sgv = a.pre_g ? a.pre_g[(size_t)bsmp * a.Cg + aa] : 1.f;
-          atomicAdd(a.gwp + ((size_t)(ky * NKX + kx) * a.A + aa) * a.Bc + cc, acc[kx][mi][r] * sxv * sgv);
+          const size_t off = ((size_t)(ky * NKX + kx) * a.A + aa) * a.Bc + cc;
+          if (a.slab) a.slab[(size_t)split * (NKX * NKX) * a.A * a.Bc + off] = acc[kx][mi][r] * sxv * sgv;
+          else atomicAdd(a.gwp + off, acc[kx][mi][r] * sxv * sgv);
         }
       }
     }
+}
+
+// gwp[i] = sum_s slab[s][i]: the partial weight-gradient tiles of the row-segment kernel meet here instead of through fp32
+// atomics (12.5 M atomic adds onto 147 K addresses for the 128x128 top layer: ~20 % of that kernel)
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ gwp, int total, int nsplit) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  float acc = 0.f;
+#pragma unroll 4
+  for (int sI = 0; sI < nsplit; ++sI) acc += slab[(size_t)sI * total + i];
+  gwp[i] = acc;
+}
+
+float* g_slab = nullptr;
+size_t g_slab_bytes = 0;
+float* wgrad_slab_scratch(size_t bytes) {          // grow-only, owned by the library; every element is written before it is read
+  if (bytes > g_slab_bytes) {
+    if (g_slab) hipFree(g_slab);
+    g_slab_bytes = std::max(bytes, (size_t)64 << 20);
+    if (hipMalloc((void**)&g_slab, g_slab_bytes) != hipSuccess) { g_slab = nullptr; g_slab_bytes = 0; return nullptr; }
+  }
+  return g_slab;
 }
 
 // =========================================================================================================
@@ -1132,6 +1158,7 @@ int lcgan_set_option(int option, int value) {
   if (option == 5) { const int old = g_wgrad3_small; g_wgrad3_small = value; return old; }
   if (option == 6) { const int old = g_halo_min_wgs; g_halo_min_wgs = value; return old; }
   if (option == 7) { const int old = g_halo_split_wgs; g_halo_split_wgs = value; return old; }
+  if (option == 8) { const int old = g_wgrad_slab_min; g_wgrad_slab_min = value; return old; }
   return LCGAN_EINVAL;
 }
 
@@ -1316,6 +1343,13 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
     a.chunks_per_split = cdiv(cps, parts);
     a.parts = cdiv(cps, a.chunks_per_split);
     a.nsplit = groups * a.parts;
+    // partial tiles meet in a slab + one reduction pass instead of atomics when there are enough splits to make atomics hurt
+    a.slab = nullptr;
+    const size_t slab_bytes = (size_t)a.nsplit * k * k * A * Bc * sizeof(float);
+    // (measured per layer shape with scripts/ab_conv.py: -17 % at 16x16, -6 % at 32x32, -3..-7 % on the stride-2 layers, neutral at
+    // 64x64 and 256x256, +3 % at 128x128 stride 1: the atomics of the big stride-1 layers hide under other workgroups' compute)
+    if (g_wgrad_slab_min > 0 && a.nsplit >= g_wgrad_slab_min && slab_bytes <= ((size_t)1 << 30) && (Hg * Wg <= 4096 || stride == 2 || g_wgrad_slab_min == 1))
+      a.slab = wgrad_slab_scratch(slab_bytes);
     dim3 grid3(cdiv(A, 128), cdiv(Bc, 128), nkx * a.nsplit);
 #define LAUNCH_WG3(ST, SG, SW, NK)                                                                                      \
     {                                                                                                                   \
@@ -1333,6 +1367,10 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
     }
 #undef LAUNCH_WG3_K
 #undef LAUNCH_WG3
+    if (a.slab) {
+      const int total = k * k * A * Bc;
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, a.slab, gwp, total, a.nsplit);
+    }
   } else if (dtype == DT_BF16) {
     const size_t smem = 2 * 2 * WG_TILE * sizeof(__bf16);
     hipLaunchKernelGGL((conv_wgrad_kernel<__bf16, 1>), grid, dim3(256), smem, s, a);

@@ -12,7 +12,10 @@ def kernels_for(path):
     k = HipKernels.__new__(HipKernels)
     lib = C.CDLL(path)
     for name, argtypes in _lib.SIGNATURES.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:                       # an older build without this entry point
+            continue
         fn.argtypes = argtypes
         fn.restype = C.c_int
     k.lib = lib
@@ -22,6 +25,10 @@ def kernels_for(path):
 
 
 A, Bk = kernels_for(sys.argv[1]), kernels_for(sys.argv[2])
+for K_, env in ((A, "OPT_A"), (Bk, "OPT_B")):          # e.g. OPT_B="8=0,2=1536": lcgan_set_option switches per build
+    for kv in filter(None, os.environ.get(env, "").split(",")):
+        o, v = kv.split("=")
+        K_.lib.lcgan_set_option(int(o), int(v))
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 # (H, Cin, Cout, stride, count per iteration as fwd-like, as dgrad-like, as wgrad)   -- 256x256 generator + discriminator layers
 shapes = [(256, 128, 128, 1, 8, 6, 6), (128, 256, 256, 1, 9, 7, 5), (64, 512, 512, 1, 9, 7, 5), (32, 512, 512, 1, 12, 10, 5),
