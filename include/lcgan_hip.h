@@ -44,17 +44,20 @@ int lcgan_conv_wgrad_unprep(const float* gwp, int A, int Bc, int k, float scale,
 /* y = act(post[b,n] * conv_{k,stride,pad=k/2}(pre[b,c] * x, wp) + bias[n]*bias_scale) * gain + residual
    residual_half = 1: residual is [B,Hout/2,Wout/2,Cout] and enters as 0.25 * residual[ho/2][wo/2], the adjoint of
    F.avg_pool2d(x, 2) (custom_layers.py:202) -- the gradient of a DiscriminatorBlock's pooled skip branch lands in the
-   epilogue of conv0's data gradient instead of a separate up-sample + add. */
+   epilogue of conv0's data gradient instead of a separate up-sample + add.
+   xs / gs (both or neither; need post, no bias / act / residual): the style-gradient reduction of a modulated conv's backward
+   (autograd of custom_layers.py:62-64) fused into its data-gradient launch: with u = the unscaled result, y = post[b,n] * u and
+   gs[b,n] += sum_pixels xs[b,p,n] * u[b,p,n]   (xs: [B,Hout,Wout,Cout] = the conv's forward input; gs: [B][Cout] f32, accumulated). */
 int lcgan_conv_fwd(const void* x, const void* wp, void* y,
                    int B, int Hin, int Win, int Cin, int Cout, int N, int k, int stride,
                    const float* pre, const float* post, const float* bias, float bias_scale,
-                   int act, float gain, const void* residual, int residual_half, int dtype, void* stream);
+                   int act, float gain, const void* residual, int residual_half, const void* xs, float* gs, int dtype, void* stream);
 /* adjoint of lcgan_conv_fwd w.r.t. x (weights from weight_prep(transpose=1)); stride 2 == the x2 transposed
  * convolution of ModulatedConv2d(up=2): output [B][Hg*stride][Wg*stride][Cout]. */
 int lcgan_conv_bwd_data(const void* g, const void* wpT, void* gx,
                         int B, int Hg, int Wg, int Cg, int Cout, int N, int k, int stride,
                         const float* pre, const float* post, const float* bias, float bias_scale,
-                        int act, float gain, const void* residual, int residual_half, int dtype, void* stream);
+                        int act, float gain, const void* residual, int residual_half, const void* xs, float* gs, int dtype, void* stream);
 /* gwp[t][a][c] += sum_{b,i,j} (pre_g g)[b,i,j,a] (pre_x x)[b,i*stride+ky-pad,j*stride+kx-pad,c]; gwp f32, zeroed by caller */
 int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
                      int B, int Hx, int Wx, int Cx, int Hg, int Wg, int Cg, int A, int Bc, int k, int stride,

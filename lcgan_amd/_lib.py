@@ -18,8 +18,8 @@ SIGNATURES = {
     "lcgan_conv_weight_prep": [P, I, I, I, F, I, P, I, P, P],
     "lcgan_conv_wgrad_unprep": [P, I, I, I, F, I, P, P, P, P],
     "lcgan_conv_weight_prep_group": [P, P, P, I, P, P, D, P],
-    "lcgan_conv_fwd": [P, P, P, I, I, I, I, I, I, I, I, P, P, P, F, I, F, P, I, I, P],
-    "lcgan_conv_bwd_data": [P, P, P, I, I, I, I, I, I, I, I, P, P, P, F, I, F, P, I, I, P],
+    "lcgan_conv_fwd": [P, P, P, I, I, I, I, I, I, I, I, P, P, P, F, I, F, P, I, P, P, I, P],
+    "lcgan_conv_bwd_data": [P, P, P, I, I, I, I, I, I, I, I, P, P, P, F, I, F, P, I, P, P, I, P],
     "lcgan_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P, I, P],
     "lcgan_box3_act": [P, P, I, I, I, I, I, F, I, P],
     "lcgan_box3_act_bwd": [P, P, P, I, I, I, I, I, F, I, P],

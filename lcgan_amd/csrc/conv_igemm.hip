@@ -22,6 +22,8 @@
 
 #include <algorithm>
 
+extern "C" int lcgan_scale_reduce(void* u, const void* x, const float* sc, float* gs, int B, int HW, int C, int dtype, void* stream);
+
 namespace {
 
 int g_use_halo = 1;                       // lcgan_set_option(0, ...): bf16 halo-tile fast path on/off (A/B testing)
@@ -54,6 +56,7 @@ struct ConvArgs {
   int in_mul, out_mul;
   int pre_stride, post_stride;
   float bias_scale, gain; int act;
+  const void* xs; float* gs;                 // fused style-gradient reduction: gs[b,n] += sum_pixels xs[b,p,n] * acc  (xs: [B,Hout,Wout,Cout]; y = post * acc)
   int res_half;                              // residual is [B,Hout/2,Wout/2,Cout]: add 0.25 * residual[oy/2][ox/2] (avg_pool2d adjoint)
   int nsplit; float* ws;                     // split-K: blockIdx.z = phase * nsplit + split; raw fp32 partials are atomically added to ws [M_out pixels][Cout]
   TapTable taps[4];
@@ -276,6 +279,7 @@ constexpr int HROW = 40;                      // bf16 per staged pixel row (32 c
 struct HaloArgs {
   const __bf16* x; const __bf16* w; __bf16* y;
   const float* pre; const float* post; const float* bias; const __bf16* residual; int res_half;
+  const __bf16* xs; float* gs;               // see ConvArgs
   int B, Hin, Win, Cin, Hout, Wout, Cout, Hm, Wm, N, Kpad, kc_per_tap;
   int out_mul, tiles_x, tiles_y;
   float bias_scale, gain; int act;
@@ -494,7 +498,10 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
   // (the main loop ended with a barrier, so the staging buffers are free)
   constexpr int OROW = BN + 8;                                     // bf16 per output row in LDS (272 B: conflict-light)
   __bf16* ot = (__bf16*)smem;                                      // [256][OROW]
-  if (a.residual) {                                                // stage the residual tile with coalesced 16-byte loads
+  float* colbuf = (float*)(smem + 256 * OROW * sizeof(__bf16));    // [128] column sums of xs * acc (fused style-gradient reduction)
+  const __bf16* side = a.xs ? a.xs : a.residual;                   // the tile that meets the accumulators: residual, or xs
+  if (a.xs && tid < BN) colbuf[tid] = 0.f;
+  if (side) {                                                      // stage it with coalesced 16-byte loads
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int idx = tid + k * 512;
@@ -504,8 +511,8 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
       bf16x8 rr = zero_bf16x8();
       if (py < a.Hm && px < a.Wm && n < a.Cout) {
         const int oy = py * a.out_mul + (phase >> 1), ox = px * a.out_mul + (phase & 1);
-        rr = a.res_half ? *(const bf16x8*)(a.residual + ((size_t)(b * (a.Hout >> 1) + (oy >> 1)) * (a.Wout >> 1) + (ox >> 1)) * a.Cout + n)
-                        : *(const bf16x8*)(a.residual + ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n);
+        rr = (a.res_half && !a.xs) ? *(const bf16x8*)(side + ((size_t)(b * (a.Hout >> 1) + (oy >> 1)) * (a.Wout >> 1) + (ox >> 1)) * a.Cout + n)
+                                   : *(const bf16x8*)(side + ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n);
       }
       *(bf16x8*)(ot + row * OROW + vv * 8) = rr;
     }
@@ -517,37 +524,46 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
     pv = (a.post && n < a.Cout) ? a.post[(size_t)b * a.Cout + n] : 1.f;
   };
   const float res_scale = a.res_half ? 0.25f : 1.f;
-  auto emit = [&](int row, int nl, float accv, float bv, float pv) {
+  auto emit = [&](int row, int nl, float accv, float bv, float pv, float& cs) {
     float v = accv * pv + bv;
     v = (a.act == ACT_LRELU ? (v > 0.f ? v : v * LRELU_SLOPE) : v) * a.gain;
     if ((a.dbg & 2) && v != 12345.678f) return;
-    if (a.residual) v += res_scale * (float)ot[row * OROW + nl];   // same thread reads and rewrites this element: one rounding
+    if (a.xs) cs += accv * (float)ot[row * OROW + nl];             // style-gradient partial: x * (unscaled data gradient)
+    else if (a.residual) v += res_scale * (float)ot[row * OROW + nl];   // same thread reads and rewrites this element: one rounding
     ot[row * OROW + nl] = (__bf16)v;
+  };
+  auto colflush = [&](int nl, float cs, int width) {               // lanes sharing a column -> one LDS add per wave and column
+    if (!a.xs) return;
+    for (int o = width; o < 64; o <<= 1) cs += __shfl_xor(cs, o, 64);
+    if (lane < width) atomicAdd(&colbuf[nl], cs);
   };
   if (M16) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
       const int nl = wn * 64 + ni * 16 + (lane & 15);
-      float bv, pv;
+      float bv, pv, cs = 0.f;
       colconst(nl, bv, pv);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) emit(wm * 64 + mi * 16 + (lane >> 4) * 4 + r, nl, acc16[mi][ni][r], bv, pv);
+        for (int r = 0; r < 4; ++r) emit(wm * 64 + mi * 16 + (lane >> 4) * 4 + r, nl, acc16[mi][ni][r], bv, pv, cs);
+      colflush(nl, cs, 16);
     }
   } else {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int nl = wn * 64 + ni * 32 + (lane & 31);
-      float bv, pv;
+      float bv, pv, cs = 0.f;
       colconst(nl, bv, pv);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) emit(wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), nl, acc[mi][ni][r], bv, pv);
+        for (int r = 0; r < 16; ++r) emit(wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), nl, acc[mi][ni][r], bv, pv, cs);
+      colflush(nl, cs, 32);
     }
   }
   __syncthreads();
+  if (a.xs && tid < BN && n0 + tid < a.Cout) atomicAdd(a.gs + (size_t)b * a.Cout + n0 + tid, colbuf[tid]);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int idx = tid + k * 512;                                 // 256 rows x 16 vectors
@@ -592,6 +608,7 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   HaloArgs a = {};
   a.x = (const __bf16*)c.x; a.w = c.w; a.y = (__bf16*)c.y; a.pre = c.pre; a.post = c.post; a.bias = c.bias;
   a.residual = (const __bf16*)c.residual; a.res_half = c.res_half; a.dbg = g_dbg_no_atomics;
+  a.xs = (const __bf16*)c.xs; a.gs = c.gs;
   a.B = c.B; a.Hin = c.Hin; a.Win = c.Win; a.Cin = c.Cin; a.Hout = c.Hout; a.Wout = c.Wout; a.Cout = c.Cout;
   a.Hm = c.Hm; a.Wm = c.Wm; a.N = c.N; a.Kpad = c.Kpad; a.kc_per_tap = c.kc_per_tap; a.out_mul = c.out_mul;
   a.tiles_x = cdiv(c.Wm, HT); a.tiles_y = cdiv(c.Hm, HT);
@@ -615,13 +632,13 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   if (g_use_splitk && halo_wgs < g_halo_min_wgs && c.taps[0].n * c.kc_per_tap >= 8) return false;
   // fewer workgroups than ~3/4 of one resident wave (512): split the channel chunks over blockIdx.z (>= 2 chunks per split)
   a.nsplit = 1; a.ws = nullptr;
-  if (g_use_splitk && halo_wgs < g_halo_split_wgs && c.kc_per_tap >= 4) {
+  if (g_use_splitk && halo_wgs < g_halo_split_wgs && c.kc_per_tap >= 4 && !c.xs) {
     const int ns = std::min(c.kc_per_tap / 2, (512 + halo_wgs - 1) / halo_wgs);
     float* ws = ns > 1 ? splitk_scratch((size_t)c.B * c.Hout * c.Wout * c.Cout * sizeof(float), s) : nullptr;
     if (ws) { a.nsplit = ns; a.ws = ws; }
   }
   a.halo_elems = max_halo * HROW;
-  const size_t smem = std::max(((size_t)a.halo_elems + 2 * TILE) * sizeof(__bf16), (size_t)256 * (BN + 8) * sizeof(__bf16));
+  const size_t smem = std::max(((size_t)a.halo_elems + 2 * TILE) * sizeof(__bf16), (size_t)256 * (BN + 8) * sizeof(__bf16) + BN * sizeof(float));
   dim3 grid(c.B * a.tiles_x * a.tiles_y, cdiv(c.Cout, BN), nphase * a.nsplit);
 #define LAUNCH_HALO(IM, MM)                                                                                             \
   {                                                                                                                     \
@@ -1136,9 +1153,14 @@ int dispatch_igemm(const ConvArgs& a_in, int nphase, int dtype, hipStream_t s) {
       if (ws) { a.nsplit = ns; a.ws = ws; }
     }
   }
-  if (dtype == DT_BF16) return launch_igemm<__bf16, 1>(a, nphase, s);
-  if (dtype == DT_F32) return launch_igemm<float, 3>(a, nphase, s);
-  return LCGAN_EINVAL;
+  // generic path: the fused style-gradient reduction (xs, gs) runs as its own pass over the unscaled output
+  const void* xs = a.xs; float* gs = a.gs; const float* sr_scale = a.post;
+  if (xs) { a.post = nullptr; a.xs = nullptr; a.gs = nullptr; }
+  int rc = LCGAN_EINVAL;
+  if (dtype == DT_BF16) rc = launch_igemm<__bf16, 1>(a, nphase, s);
+  else if (dtype == DT_F32) rc = launch_igemm<float, 3>(a, nphase, s);
+  if (xs && rc == LCGAN_OK) rc = lcgan_scale_reduce(a.y, xs, sr_scale, gs, a.B, a.Hout * a.Wout, a.Cout, dtype, s);
+  return rc;
 }
 
 }  // namespace
@@ -1208,10 +1230,12 @@ int lcgan_conv_wgrad_unprep(const float* gwp, int A, int Bc, int k, float scale,
 int lcgan_conv_fwd(const void* x, const void* wp, void* y,
                    int B, int Hin, int Win, int Cin, int Cout, int N, int k, int stride,
                    const float* pre, const float* post, const float* bias, float bias_scale,
-                   int act, float gain, const void* residual, int residual_half, int dtype, void* stream) {
+                   int act, float gain, const void* residual, int residual_half, const void* xs, float* gs, int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || (Cin & 7) || (Cout & 7) || N > Cout) return LCGAN_EINVAL;
+  if (xs && (!gs || !post || residual || bias || act != ACT_NONE || gain != 1.f)) return LCGAN_EINVAL;
   ConvArgs a = {};
+  a.xs = xs; a.gs = xs ? gs : nullptr;
   a.x = x; a.w = (const __bf16*)wp; a.y = y;
   a.pre = pre; a.post = post; a.bias = bias; a.residual = residual; a.res_half = residual ? residual_half : 0;
   a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin;
@@ -1240,11 +1264,13 @@ int lcgan_conv_fwd(const void* x, const void* wp, void* y,
 int lcgan_conv_bwd_data(const void* g, const void* wpT, void* gx,
                         int B, int Hg, int Wg, int Cg, int Cout, int N, int k, int stride,
                         const float* pre, const float* post, const float* bias, float bias_scale,
-                        int act, float gain, const void* residual, int residual_half, int dtype, void* stream) {
+                        int act, float gain, const void* residual, int residual_half, const void* xs, float* gs, int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || (Cg & 7) || (Cout & 7) || N > Cout) return LCGAN_EINVAL;
   if (stride == 2 && k != 3) return LCGAN_EINVAL;
+  if (xs && (!gs || !post || residual || bias || act != ACT_NONE || gain != 1.f)) return LCGAN_EINVAL;
   ConvArgs a = {};
+  a.xs = xs; a.gs = xs ? gs : nullptr;
   a.x = g; a.w = (const __bf16*)wpT; a.y = gx;
   a.pre = pre; a.post = post; a.bias = bias; a.residual = residual; a.res_half = residual ? residual_half : 0;
   a.B = B; a.Hin = Hg; a.Win = Wg; a.Cin = Cg;

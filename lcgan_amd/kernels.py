@@ -166,29 +166,35 @@ class HipKernels:
         return gw
 
     def conv_fwd(self, x: Tensor, pw: PreparedWeight, N: int, k: int, stride: int, pre=None, post=None, bias=None,
-                 bias_scale: float = 1.0, act: int = ACT_NONE, gain: float = 1.0, residual=None, residual_half: bool = False) -> Tensor:
-        self._chk(x, pre, post, bias, residual)
+                 bias_scale: float = 1.0, act: int = ACT_NONE, gain: float = 1.0, residual=None, residual_half: bool = False,
+                 xs: Optional[Tensor] = None):
+        """xs given (needs post, no bias/act/residual): returns (y = post * u, gs[b,n] = sum_pixels xs * u), u = the unscaled result"""
+        self._chk(x, pre, post, bias, residual, xs)
         B, H, W, Cin = x.shape
         Cout = ceil8(N)
         y = torch.empty((B, (H + stride - 1) // stride, (W + stride - 1) // stride, Cout), dtype=x.dtype, device=x.device)
+        gs = self._zeros.take((B, Cout), x.device) if xs is not None else None
         assert pw.parts == (3 if x.dtype == torch.float32 else 1)
         self._call("lcgan_conv_fwd", x.data_ptr(), pw.buf.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, N, k, stride,
-                   _p(pre), _p(post), _p(bias), float(bias_scale), act, float(gain), _p(residual), int(residual_half), dt_code(x.dtype),
-                   self._stream())
-        return y
+                   _p(pre), _p(post), _p(bias), float(bias_scale), act, float(gain), _p(residual), int(residual_half), _p(xs), _p(gs),
+                   dt_code(x.dtype), self._stream())
+        return y if xs is None else (y, gs)
 
     def conv_bwd_data(self, g: Tensor, pw: PreparedWeight, N: int, k: int, stride: int, pre=None, post=None, bias=None,
-                      bias_scale: float = 1.0, act: int = ACT_NONE, gain: float = 1.0, residual=None, residual_half: bool = False) -> Tensor:
-        """residual_half: residual is [B,H/2,W/2,C] of gx's grid and enters as 0.25 * nearest-x2 (avg_pool2d adjoint)"""
-        self._chk(g, pre, post, bias, residual)
+                      bias_scale: float = 1.0, act: int = ACT_NONE, gain: float = 1.0, residual=None, residual_half: bool = False,
+                      xs: Optional[Tensor] = None):
+        """residual_half: residual is [B,H/2,W/2,C] of gx's grid and enters as 0.25 * nearest-x2 (avg_pool2d adjoint);
+        xs: as conv_fwd -> (gx, gs)"""
+        self._chk(g, pre, post, bias, residual, xs)
         B, H, W, Cg = g.shape
         Cout = ceil8(N)
         gx = torch.empty((B, H * stride, W * stride, Cout), dtype=g.dtype, device=g.device)
+        gs = self._zeros.take((B, Cout), g.device) if xs is not None else None
         assert pw.parts == (3 if g.dtype == torch.float32 else 1)
         self._call("lcgan_conv_bwd_data", g.data_ptr(), pw.buf.data_ptr(), gx.data_ptr(), B, H, W, Cg, Cout, N, k, stride,
-                   _p(pre), _p(post), _p(bias), float(bias_scale), act, float(gain), _p(residual), int(residual_half), dt_code(g.dtype),
-                   self._stream())
-        return gx
+                   _p(pre), _p(post), _p(bias), float(bias_scale), act, float(gain), _p(residual), int(residual_half), _p(xs), _p(gs),
+                   dt_code(g.dtype), self._stream())
+        return gx if xs is None else (gx, gs)
 
     def conv_wgrad(self, x: Tensor, g: Tensor, A: int, Bc: int, k: int, stride: int, pre_x=None, pre_g=None) -> Tensor:
         self._chk(x, g, pre_x, pre_g)

@@ -626,11 +626,11 @@ class ModConvFn(Function):
         if gz is None:
             gz = gy
         pwT, _ = _prep(w, c_eq, True, _need_lo(x))                               # [t][Cin][O]
+        # data gradient u = conv^T(d * gz); gx = s * u and gs = sum_p x * u leave the same launch (epilogue of the conv kernel)
         if up == 2:
-            u = K.conv_fwd(gz, pwT, Cin, k, 2, pre=d)                            # adjoint of the transposed conv
+            gx, gs = K.conv_fwd(gz, pwT, Cin, k, 2, pre=d, post=s, xs=x)         # adjoint of the transposed conv
         else:
-            u = K.conv_bwd_data(gz, pwT, Cin, k, 1, pre=d)
-        gx, gs = K.scale_reduce(u, x, s)                                         # gx = s*u (in place), gs = sum_p x*u
+            gx, gs = K.conv_bwd_data(gz, pwT, Cin, k, 1, pre=d, post=s, xs=x)
         gwsq = K.demod_bwd(gdq, d, s, wsq, gs)                                   # gs += demod path
         if up == 2:
             gwp = K.conv_wgrad(gz, x, Cin, O, k, 2, pre_x=d, pre_g=s)            # [t][Cin][O]

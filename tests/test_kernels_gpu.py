@@ -34,10 +34,11 @@ def tol(dtype):
     return (2e-4, 1e-4) if dtype == torch.float32 else (1.2e-2, 2e-3)
 
 
-def check(got, ref, dtype, what=""):
+def check(got, ref, dtype, what="", l2_scale=1.0):
     got, ref = got.detach().float().cpu(), ref.detach().float()
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     mx, l2 = tol(dtype)
+    l2 *= l2_scale
     scale = ref.abs().max().clamp_min(1e-20)
     e_max = float((got - ref).abs().max() / scale)
     e_l2 = float((got - ref).norm() / ref.norm().clamp_min(1e-20))
@@ -117,6 +118,10 @@ def test_conv_fwd(H, dtype, case):
     res = feat(tuple(ref0.shape), dtype, 6, Co)
     check(H.conv_fwd(x.cuda(), pw_h, Co, k, stride, pre=pre.cuda(), post=post.cuda(), bias=bias.cuda(), residual=res.cuda()),
           E.conv_fwd(x, pw_e, Co, k, stride, pre=pre, post=post, bias=bias, residual=res), dtype, "mod+residual")
+    y_h, gs_h = H.conv_fwd(x.cuda(), pw_h, Co, k, stride, pre=pre.cuda(), post=post.cuda(), xs=res.cuda())
+    y_e, gs_e = E.conv_fwd(x, pw_e, Co, k, stride, pre=pre, post=post, xs=res)
+    check(y_h, y_e, dtype, "fused y", l2_scale=2.0)        # generic path: u is rounded to bf16 BEFORE the style scale (two roundings)
+    check(gs_h, gs_e, dtype, "fused gs", l2_scale=3.0)     # generic path reduces the bf16-rounded u; few values, cancelling sums
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -138,6 +143,12 @@ def test_conv_bwd_data(H, dtype, case):
     bias = torch.randn(Ci, generator=torch.Generator().manual_seed(15))
     check(H.conv_bwd_data(g.cuda(), pw_h, Ci, k, stride, pre=pre.cuda(), post=post.cuda(), bias=bias.cuda(), act=1, gain=1.2),
           E.conv_bwd_data(g, pw_e, Ci, k, stride, pre=pre, post=post, bias=bias, act=1, gain=1.2), dtype, "mod+bias+act")
+    # style-gradient reduction fused into the launch: gx = post * u, gs = sum_pixels xs * u
+    xs = feat((B, Hh, W, ceil8(Ci)), dtype, 17, Ci)
+    gx_h, gs_h = H.conv_bwd_data(g.cuda(), pw_h, Ci, k, stride, pre=pre.cuda(), post=post.cuda(), xs=xs.cuda())
+    gx_e, gs_e = E.conv_bwd_data(g, pw_e, Ci, k, stride, pre=pre, post=post, xs=xs)
+    check(gx_h, gx_e, dtype, "fused gx", l2_scale=2.0)     # generic path: u is rounded to bf16 BEFORE the style scale (two roundings)
+    check(gs_h, gs_e, dtype, "fused gs", l2_scale=3.0)     # generic path reduces the bf16-rounded u; few values, cancelling sums
     if Hh % 2 == 0 and W % 2 == 0:         # pooled-branch gradient folded into the epilogue (0.25 * nearest-x2 of a half-res tensor)
         rh = feat((B, Hh // 2, W // 2, ceil8(Ci)), dtype, 16, Ci)
         check(H.conv_bwd_data(g.cuda(), pw_h, Ci, k, stride, residual=rh.cuda(), residual_half=True),
