@@ -34,8 +34,6 @@ int g_wgrad3_small = 0;                   // lcgan_set_option(5, ...): row-segme
                                           // (default off: measured 0.5 ms/iteration SLOWER than the generic kernel on those shapes)
 int g_wgrad3_wgs = 0;                     // lcgan_set_option(2, ...): 0 = cost-model split of the row-segment wgrad kernel, > 0 = explicit workgroup target
 int g_halo_min_wgs = 128;                 // lcgan_set_option(6, ...): halo launches with fewer workgroups go to the split-K implicit GEMM
-int g_halo_split_wgs = 0;                 // lcgan_set_option(7, ...): halo launches with fewer workgroups split their channel chunks over blockIdx.z
-                                          // (default off: with 384 the atomics epilogue + finalize pass cost more than the idle CUs, 31.5 vs 29.9 ms at local batch 4)
 int g_wgrad_slab_min = 4;                 // lcgan_set_option(8, ...): row-segment wgrad launches with at least this many splits reduce through a slab instead of atomics (0 = never)
 int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): TIMING EXPERIMENTS ONLY, bit mask: 16 = skip the wgrad3 epilogue atomics;
                                           // halo kernel: 1 = skip the output stores, 2 = skip the LDS emit, 4 = two main-loop steps only, 8 = linear tile order
@@ -286,12 +284,15 @@ struct HaloArgs {
   TapTable taps[4];
   int hy0[4], hx0[4], hh[4], hw[4];          // per phase: halo origin (min dy, min dx) and extent in input pixels
   int halo_elems;                            // LDS elements reserved for the halo (max over phases)
-  int nsplit; float* ws;                     // split-K over channel chunks: blockIdx.z = phase * nsplit + split; raw fp32 partials -> ws
   int dbg;                                   // TIMING EXPERIMENTS ONLY (option 3): 1 = skip the global stores, 2 = skip the LDS emit too, 4 = skip the main loop
 };
 
-template <int IN_MUL, bool M16>
+// EPI selects the epilogue at compile time: 0 = plain, 1 = + residual, 2 = + 0.25 * half-resolution residual, 3 = style-gradient
+// reduction (gs += sum xs * acc).  As run-time branches the last two cost every launch 5-7 % on the short-K top layer (measured
+// with scripts/ab_raw.py against the builds that preceded them).
+template <int IN_MUL, bool M16, int EPI>
 __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_kernel(HaloArgs a) {
+  constexpr bool SR = EPI == 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NI = IN_MUL == 1 ? 3 : 9;     // halo (pixel, 8-channel vector) items per thread: ceil(hh*hw*4 / 512)
   __bf16* halo = (__bf16*)smem;
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int phase = blockIdx.z / a.nsplit, split = blockIdx.z - phase * a.nsplit, n0 = blockIdx.y * BN;
+  const int phase = blockIdx.z, n0 = blockIdx.y * BN;
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so every XCD gets a contiguous run of tiles
   // (neighbouring tiles share halo columns and rows in that XCD's L2): -1.3 % on the conv launches of an iteration
   int tile = blockIdx.x;
@@ -354,11 +355,7 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
 
   // ---- weight tile: 128 rows x 4 vectors = 512 items, one per thread; prefetched TWO taps ahead in two named registers ----
   const int brow = tid >> 2;
-  // split-K: this workgroup reduces the channel chunks [cb, nchunks) of its share
-  const int cper = (a.kc_per_tap + a.nsplit - 1) / a.nsplit;
-  const int cb = split * cper, nchunks = min(cb + cper, a.kc_per_tap);
-  if (cb >= nchunks) return;
-  const int ntaps = tt.n, total = ntaps * (nchunks - cb);
+  const int ntaps = tt.n, nchunks = a.kc_per_tap, total = ntaps * nchunks;
   const size_t wrow = (size_t)(n0 + brow) * a.Kpad + hvec * 8;
   const bool bvalid = n0 + brow < a.N;
   auto b_load = [&](int c, int t) -> bf16x8 {
@@ -397,19 +394,19 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
   }
 
   // (c, t) of the tile two steps ahead of the one being computed
-  int lc = cb, lt = 0;
+  int lc = 0, lt = 0;
   auto advance = [&]() { if (++lt == ntaps) { lt = 0; ++lc; } };
 
-  halo_load(cb * BK);
+  halo_load(0);
   halo_store();
-  b_store(0, b_load(cb, 0));
+  b_store(0, b_load(0, 0));
   advance();                                                   // -> tile 1
   bf16x8 r0 = (1 < total) ? b_load(lc, lt) : zero_bf16x8();    // tile 1 in flight
   advance();                                                   // -> tile 2
   bf16x8 r1 = zero_bf16x8();
   __syncthreads();
 
-  int c = cb, t = 0;
+  int c = 0, t = 0;
   // one step: compute tile q from buffer (q & 1); `rs` holds tile q+1 (loaded one step ago), `rl` receives tile q+2
   auto step = [&](int q, bf16x8& rs, bf16x8& rl) {
     if (t == 0 && c + 1 < nchunks) halo_load((c + 1) * BK);    // next chunk's halo: in flight during this chunk's taps
@@ -457,51 +454,14 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
     if (q + 1 < total) step(q + 1, r1, r0);
   }
 
-  if (a.nsplit > 1) {                       // split-K: raw partial sums; conv_finalize_kernel applies the epilogue
-    if (M16) {
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wn * 64 + ni * 16 + (lane & 15);
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = wm * 64 + mi * 16 + (lane >> 4) * 4 + r;
-            const int py = ty * HT + (row >> 4), px = tx * HT + (row & 15);
-            if (py < a.Hm && px < a.Wm && n < a.Cout) {
-              const int oy = py * a.out_mul + (phase >> 1), ox = px * a.out_mul + (phase & 1);
-              atomicAdd(a.ws + ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n, acc16[mi][ni][r]);
-            }
-          }
-      }
-    } else {
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int py = ty * HT + (row >> 4), px = tx * HT + (row & 15);
-            if (py < a.Hm && px < a.Wm && n < a.Cout) {
-              const int oy = py * a.out_mul + (phase >> 1), ox = px * a.out_mul + (phase & 1);
-              atomicAdd(a.ws + ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n, acc[mi][ni][r]);
-            }
-          }
-      }
-    }
-    return;
-  }
-
   // ---- epilogue: demod/bias/act in registers -> bf16 tile in LDS -> 16-byte coalesced stores (+ residual) ----------------
   // (the main loop ended with a barrier, so the staging buffers are free)
   constexpr int OROW = BN + 8;                                     // bf16 per output row in LDS (272 B: conflict-light)
   __bf16* ot = (__bf16*)smem;                                      // [256][OROW]
   float* colbuf = (float*)(smem + 256 * OROW * sizeof(__bf16));    // [128] column sums of xs * acc (fused style-gradient reduction)
-  const __bf16* side = a.xs ? a.xs : a.residual;                   // the tile that meets the accumulators: residual, or xs
-  if (a.xs && tid < BN) colbuf[tid] = 0.f;
-  if (side) {                                                      // stage it with coalesced 16-byte loads
+  const __bf16* side = SR ? a.xs : a.residual;                     // the tile that meets the accumulators: residual, or xs
+  if (SR && tid < BN) colbuf[tid] = 0.f;
+  if (EPI != 0) {                                                  // stage it with coalesced 16-byte loads
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int idx = tid + k * 512;
@@ -511,7 +471,7 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
       bf16x8 rr = zero_bf16x8();
       if (py < a.Hm && px < a.Wm && n < a.Cout) {
         const int oy = py * a.out_mul + (phase >> 1), ox = px * a.out_mul + (phase & 1);
-        rr = (a.res_half && !a.xs) ? *(const bf16x8*)(side + ((size_t)(b * (a.Hout >> 1) + (oy >> 1)) * (a.Wout >> 1) + (ox >> 1)) * a.Cout + n)
+        rr = (EPI == 2) ? *(const bf16x8*)(side + ((size_t)(b * (a.Hout >> 1) + (oy >> 1)) * (a.Wout >> 1) + (ox >> 1)) * a.Cout + n)
                                    : *(const bf16x8*)(side + ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n);
       }
       *(bf16x8*)(ot + row * OROW + vv * 8) = rr;
@@ -523,17 +483,17 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
     bv = (a.bias && n < a.N) ? a.bias[n] * a.bias_scale : 0.f;
     pv = (a.post && n < a.Cout) ? a.post[(size_t)b * a.Cout + n] : 1.f;
   };
-  const float res_scale = a.res_half ? 0.25f : 1.f;
+  constexpr float res_scale = EPI == 2 ? 0.25f : 1.f;
   auto emit = [&](int row, int nl, float accv, float bv, float pv, float& cs) {
     float v = accv * pv + bv;
     v = (a.act == ACT_LRELU ? (v > 0.f ? v : v * LRELU_SLOPE) : v) * a.gain;
     if ((a.dbg & 2) && v != 12345.678f) return;
-    if (a.xs) cs += accv * (float)ot[row * OROW + nl];             // style-gradient partial: x * (unscaled data gradient)
-    else if (a.residual) v += res_scale * (float)ot[row * OROW + nl];   // same thread reads and rewrites this element: one rounding
+    if (SR) cs += accv * (float)ot[row * OROW + nl];               // style-gradient partial: x * (unscaled data gradient)
+    else if (EPI != 0) v += res_scale * (float)ot[row * OROW + nl];     // same thread reads and rewrites this element: one rounding
     ot[row * OROW + nl] = (__bf16)v;
   };
   auto colflush = [&](int nl, float cs, int width) {               // lanes sharing a column -> one LDS add per wave and column
-    if (!a.xs) return;
+    if (!SR) return;
     for (int o = width; o < 64; o <<= 1) cs += __shfl_xor(cs, o, 64);
     if (lane < width) atomicAdd(&colbuf[nl], cs);
   };
@@ -563,7 +523,7 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
     }
   }
   __syncthreads();
-  if (a.xs && tid < BN && n0 + tid < a.Cout) atomicAdd(a.gs + (size_t)b * a.Cout + n0 + tid, colbuf[tid]);
+  if (SR && tid < BN && n0 + tid < a.Cout) atomicAdd(a.gs + (size_t)b * a.Cout + n0 + tid, colbuf[tid]);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int idx = tid + k * 512;                                 // 256 rows x 16 vectors
@@ -630,28 +590,26 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   // 9*Cin reduction) goes to the split-K implicit GEMM instead, which spreads the reduction over ~256 workgroups
   const int halo_wgs = c.B * a.tiles_x * a.tiles_y * cdiv(c.Cout, BN) * nphase;
   if (g_use_splitk && halo_wgs < g_halo_min_wgs && c.taps[0].n * c.kc_per_tap >= 8) return false;
-  // fewer workgroups than ~3/4 of one resident wave (512): split the channel chunks over blockIdx.z (>= 2 chunks per split)
-  a.nsplit = 1; a.ws = nullptr;
-  if (g_use_splitk && halo_wgs < g_halo_split_wgs && c.kc_per_tap >= 4 && !c.xs) {
-    const int ns = std::min(c.kc_per_tap / 2, (512 + halo_wgs - 1) / halo_wgs);
-    float* ws = ns > 1 ? splitk_scratch((size_t)c.B * c.Hout * c.Wout * c.Cout * sizeof(float), s) : nullptr;
-    if (ws) { a.nsplit = ns; a.ws = ws; }
-  }
   a.halo_elems = max_halo * HROW;
   const size_t smem = std::max(((size_t)a.halo_elems + 2 * TILE) * sizeof(__bf16), (size_t)256 * (BN + 8) * sizeof(__bf16) + BN * sizeof(float));
-  dim3 grid(c.B * a.tiles_x * a.tiles_y, cdiv(c.Cout, BN), nphase * a.nsplit);
-#define LAUNCH_HALO(IM, MM)                                                                                             \
+  dim3 grid(c.B * a.tiles_x * a.tiles_y, cdiv(c.Cout, BN), nphase);
+#define LAUNCH_HALO(IM, MM, EP)                                                                                         \
   {                                                                                                                     \
     static bool set = false;                                                                                            \
-    if (!set) { hipFuncSetAttribute((const void*)conv_halo_kernel<IM, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
-    hipLaunchKernelGGL((conv_halo_kernel<IM, MM>), grid, dim3(512), smem, s, a);                                        \
+    if (!set) { hipFuncSetAttribute((const void*)conv_halo_kernel<IM, MM, EP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
+    hipLaunchKernelGGL((conv_halo_kernel<IM, MM, EP>), grid, dim3(512), smem, s, a);                                    \
   }
-  if (in_mul == 1 && g_mfma16) LAUNCH_HALO(1, true)
-  else if (in_mul == 1) LAUNCH_HALO(1, false)
-  else if (g_mfma16) LAUNCH_HALO(2, true)
-  else LAUNCH_HALO(2, false)
+#define LAUNCH_HALO_EPI(IM, MM)                                                                                         \
+  {                                                                                                                     \
+    if (a.xs) LAUNCH_HALO(IM, MM, 3) else if (a.residual && a.res_half) LAUNCH_HALO(IM, MM, 2)                          \
+    else if (a.residual) LAUNCH_HALO(IM, MM, 1) else LAUNCH_HALO(IM, MM, 0)                                             \
+  }
+  if (in_mul == 1 && g_mfma16 && !a.xs && !a.residual) LAUNCH_HALO(1, true, 0)
+  else if (in_mul == 1) LAUNCH_HALO_EPI(1, false)
+  else if (g_mfma16 && !a.xs && !a.residual) LAUNCH_HALO(2, true, 0)
+  else LAUNCH_HALO_EPI(2, false)
+#undef LAUNCH_HALO_EPI
 #undef LAUNCH_HALO
-  if (a.nsplit > 1) launch_finalize<__bf16>(c, a.ws, s);
   return true;
 }
 
@@ -1179,7 +1137,6 @@ int lcgan_set_option(int option, int value) {
   if (option == 4) { const int old = g_mfma16; g_mfma16 = value; return old; }
   if (option == 5) { const int old = g_wgrad3_small; g_wgrad3_small = value; return old; }
   if (option == 6) { const int old = g_halo_min_wgs; g_halo_min_wgs = value; return old; }
-  if (option == 7) { const int old = g_halo_split_wgs; g_halo_split_wgs = value; return old; }
   if (option == 8) { const int old = g_wgrad_slab_min; g_wgrad_slab_min = value; return old; }
   return LCGAN_EINVAL;
 }
