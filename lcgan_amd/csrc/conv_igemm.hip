@@ -35,7 +35,7 @@ int g_wgrad3_small = 0;                   // lcgan_set_option(5, ...): row-segme
 int g_wgrad3_wgs = 0;                     // lcgan_set_option(2, ...): 0 = cost-model split of the row-segment wgrad kernel, > 0 = explicit workgroup target
 int g_halo_min_wgs = 128;                 // lcgan_set_option(6, ...): halo launches with fewer workgroups go to the split-K implicit GEMM
 int g_wgrad_slab_min = 4;                 // lcgan_set_option(8, ...): row-segment wgrad launches with at least this many splits reduce through a slab instead of atomics (0 = never)
-int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): TIMING EXPERIMENTS ONLY, bit mask: 16 = skip the wgrad3 epilogue atomics;
+int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): experiments, bit mask (the wgrad3 no-atomics switch is gone: it sat in the epilogue);
                                           // halo kernel: 8 = linear tile order (the store / emit / main-loop skipping switches used for the
                                           // fixed-cost analysis in DESIGN.md were removed again: they sat in the hot epilogue)
 
@@ -628,7 +628,6 @@ struct WgradArgs {
   int parts;                                 // wgrad3: split = group * parts + part
   int cps_group;                             // wgrad3: chunks per group (group = one sample when per-sample scales exist, else the whole batch)
   float* slab;                               // wgrad3: non-null = every split stores its partial tile to slab[split][tap][A][Bc] (plain stores) instead of atomics
-  int dbg_no_atomics;
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -916,7 +915,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int aa = a0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (aa < a.A && cc < a.Bc && !a.dbg_no_atomics) {
+        if (aa < a.A && cc < a.Bc) {
           const float sgv = a.pre_g ? a.pre_g[(size_t)bsmp * a.Cg + aa] : 1.f;
           const size_t off = ((size_t)(ky * NKX + kx) * a.A + aa) * a.Bc + cc;
           if (a.slab) a.slab[(size_t)split * (NKX * NKX) * a.A * a.Bc + off] = acc[kx][mi][r] * sxv * sgv;
@@ -1295,7 +1294,6 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
       (long long)B * Hx * Wx * Cx < (1ll << 31) && (long long)B * Hg * Wg * Cg < (1ll << 31)) {
     // row-segment kernel: chunk = (sample, row group, SEGW-column segment) of `seg` positions; grid.z = split x kernel row
     const int seg = segw == 64 ? 64 : 32, rows = seg / segw, nkx = k;
-    a.dbg_no_atomics = g_dbg_no_atomics & 16;
     const int tiles3 = cdiv(A, 128) * cdiv(Bc, 128) * nkx;
     const bool scaled = pre_x || pre_g;
     const int groups = scaled ? B : 1;

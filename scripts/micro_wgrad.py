@@ -18,8 +18,7 @@ for (B, Hh, W, Ci, Co, st) in shapes:
     line = f"{(B,Hh,W,Ci,Co,st)}: "
     for wgs in (512, 1024, 1536, 3072, 6144):
         H.lib.lcgan_set_option(2, wgs)
-        for na in (0, 1):
-            H.lib.lcgan_set_option(3, 16 * na)
+        for na in (0,):
             dt = bench(lambda: H.conv_wgrad(x, g, Co, Ci, 3, st))
             line += f" wgs{wgs}{'-noatom' if na else ''}={fl/dt/1e12:.0f}TF"
     H.lib.lcgan_set_option(3, 0); H.lib.lcgan_set_option(2, 0)
