@@ -301,7 +301,8 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int phase = blockIdx.z, n0 = blockIdx.y * BN;
+  // the 4 sub-pixel phases of a transposed conv have 1/2/2/4 taps: dispatch the long ones first (shorter tail)
+  const int phase = gridDim.z - 1 - blockIdx.z, n0 = blockIdx.y * BN;
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so every XCD gets a contiguous run of tiles
   // (neighbouring tiles share halo columns and rows in that XCD's L2): -1.3 % on the conv launches of an iteration
   int tile = blockIdx.x;
