@@ -83,11 +83,12 @@ int lcgan_act_bwd_reduce(const void* gy, const void* y, void* gz, const float* b
 /* style gradient: gs[b,c] += sum_p x*u ; u <- s[b,c]*u in place   (autograd of custom_layers.py:62-64) */
 int lcgan_scale_reduce(void* u, const void* x, const float* s, float* gs, int B, int HW, int C, int dtype, void* stream);
 /* bicubic feature warp: get_coordinates + grid_sample(bicubic, zeros, align_corners=False), custom_layers.py:127-134,162-165
- * flow [B,H,W,8] (ch 0 = x, ch 1 = y).  Backward = pixel-level transposed index + gather (no float atomics); workspaces:
- * ws_cnt int[B*H*W+4], ws_ent 8 B x [B*H*W*32], ws_ovf 12 B x [ovf_cap] (contents irrelevant on entry). */
+ * flow [B,H,W,8] (ch 0 = x, ch 1 = y).  Backward = exact pixel-level CSR transpose (count, scan, fill) + gather, no float
+ * atomics, any flow field; workspaces (contents irrelevant on entry), npix = B*H*W (16*npix < 2^31):
+ * ws_cnt int[npix+1], ws_off int[npix+1], ws_tiles int[ceil((npix+1)/1024)], ws_ent 8 B x [16*npix]. */
 int lcgan_warp_fwd(const void* x, const void* flow, void* y, int B, int H, int W, int C, float scale, int dtype, void* stream);
 int lcgan_warp_bwd(const void* gy, const void* x, const void* flow, void* gx, void* gflow,
-                   int* ws_cnt, void* ws_ent, void* ws_ovf, int ovf_cap,
+                   int* ws_cnt, int* ws_off, int* ws_tiles, void* ws_ent,
                    int B, int H, int W, int C, float scale, int dtype, void* stream);
 int lcgan_cast_from_f32(const float* src, void* dst, long long n, int dtype, void* stream);
 /* MinibatchStdLayer custom_layers.py:243-256 (G = min(8,N), strided groups); x [N][HW][C] -> y [N][HW][Cy], Cy > C */

@@ -412,6 +412,8 @@ __device__ __forceinline__ void warp_coords(const T* flow, size_t pix, int h, in
   iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
 }
 
+// Branch-free taps: out-of-range taps are clamped to a valid address and given weight 0, so the 16 loads issue back to back
+// (the version with a bounds branch per tap spent ~70 % of its 1300 instructions on address arithmetic and exec-mask branches).
 template <typename T>
 __global__ void warp_fwd_kernel(const T* __restrict__ x, const T* __restrict__ flow, T* __restrict__ y,
                                 int B, int H, int W, int C, float scale) {
@@ -429,17 +431,24 @@ __global__ void warp_fwd_kernel(const T* __restrict__ x, const T* __restrict__ f
   cubic_coeffs(ix - fx0, cx);
   cubic_coeffs(iy - fy0, cy);
   const int x0 = (int)fx0 - 1, y0 = (int)fy0 - 1;
+  int xo[4];                                                  // element offsets of the 4 tap columns (clamped), weights zeroed outside
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int xx = x0 + j;
+    if ((unsigned)xx >= (unsigned)W) cx[j] = 0.f;
+    xo[j] = min(max(xx, 0), W - 1) * C;
+  }
+  const T* xb = x + (size_t)b * H * W * C + v * 8;
   F8 s = f8_zero();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int yy = y0 + i;
-    if ((unsigned)yy >= (unsigned)H) continue;
+    const float wy = ((unsigned)yy < (unsigned)H) ? cy[i] : 0.f;
+    const T* row = xb + (size_t)(min(max(yy, 0), H - 1) * W) * C;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int xx = x0 + j;
-      if ((unsigned)xx >= (unsigned)W) continue;
-      const float wgt = cy[i] * cx[j];
-      const F8 t = Feat<T>::load(x + (((size_t)b * H + yy) * W + xx) * C + v * 8);
+      const float wgt = wy * cx[j];
+      const F8 t = Feat<T>::load(row + xo[j]);
 #pragma unroll
       for (int q = 0; q < 8; ++q) s.v[q] += t.v[q] * wgt;
     }
@@ -449,20 +458,22 @@ __global__ void warp_fwd_kernel(const T* __restrict__ x, const T* __restrict__ f
 
 // ---- backward of the warp ------------------------------------------------------------------------------------
 // The scatter  gx[q] += wgt * gy[p]  (16 taps per output pixel p) has the same (p -> q, wgt) pattern for all C channels,
-// so it is transposed ONCE per launch at pixel level into per-input-pixel lists and then executed as a gather:
-//   warp_bwd_grid_kernel   gflow[p] = d/d(grid) : forward-like gather of x around the sample point (no atomics)
-//   warp_index_kernel      one thread per output pixel: slot = atomicAdd(cnt[q], 1) (integer), entries[q][slot] = (p, wgt);
-//                          lists longer than WARP_K spill into a global overflow list (exact, merely slower)
-//   warp_gather_kernel     one thread per (input pixel q, 8-channel vector): gx[q] = sum_entries wgt * gy[p]
-// This replaces 16 float atomics per element (bounded by the ~1.3 TB/s chip-wide float-atomic rate) by 16 integer
-// atomics per PIXEL plus coalesced 16-byte gathers.
-constexpr int WARP_K = 32;                                   // list capacity per input pixel (mean occupancy is <= 16)
+// so it is transposed ONCE per launch at pixel level into an exact CSR structure and then executed as a gather:
+//   warp_bwd_grid_kernel   gflow[p] = d/d(grid): forward-like gather of x around the sample point; its v == 0 lanes also
+//                          COUNT the taps that land on every input pixel (integer atomics)
+//   warp_scan_*            exclusive prefix sum of the counts -> list offsets (three small kernels)
+//   warp_fill_kernel       one thread per output pixel: entries[offs[q] + slot] = (p, wgt), slot from counting cnt[q] down
+//   warp_gather_kernel     one thread per (input pixel q, 8-channel vector): gx[q] = sum over its list of wgt * gy[p]
+// This replaces 16 float atomics per element (bounded by the ~1.3 TB/s chip-wide float-atomic rate) by 32 integer
+// atomics per PIXEL plus coalesced 16-byte gathers, and it is exact for ANY flow field: the first version used fixed
+// 32-entry lists with a global overflow list, which silently dropped entries beyond its capacity and went quadratic
+// (0.85 s per launch) on flows that compress an area by more than 2x.
 struct WarpEntry { int p; float w; };
-struct WarpOverflow { int q; int p; float w; };
+constexpr int SCAN_TILE = 1024;                              // elements per scan block (256 threads x 4)
 
 template <typename T>
 __global__ void warp_bwd_grid_kernel(const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ flow,
-                                     T* __restrict__ gflow, int B, int H, int W, int C, float scale) {
+                                     T* __restrict__ gflow, int* __restrict__ cnt, int B, int H, int W, int C, float scale) {
   const int nvec = C >> 3;                                   // power of two, <= 64 (checked by the launcher)
   const long long total = (long long)B * H * W * nvec;
   const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
@@ -488,6 +499,7 @@ __global__ void warp_bwd_grid_kernel(const T* __restrict__ gy, const T* __restri
     for (int j = 0; j < 4; ++j) {
       const int xx = x0 + j;
       if ((unsigned)xx >= (unsigned)W) continue;
+      if (live && v == 0) atomicAdd(cnt + (b * H + yy) * W + xx, 1);
       const F8 t = Feat<T>::load(x + (((size_t)b * H + yy) * W + xx) * C + v * 8);
       float dot = 0.f;
 #pragma unroll
@@ -506,11 +518,56 @@ __global__ void warp_bwd_grid_kernel(const T* __restrict__ gy, const T* __restri
   }
 }
 
-// cnt: int [B*H*W] zeroed; entries: [B*H*W][WARP_K]; ovf_cnt: int [1] zeroed; ovf: [ovf_cap]
+// exclusive prefix sum of cnt[0..n) -> offs[0..n): per-tile scan, scan of the tile sums (one block), add-back
+__global__ __launch_bounds__(256) void warp_scan_tiles_kernel(const int* __restrict__ cnt, int* __restrict__ offs,
+                                                              int* __restrict__ tile_sums, long long n) {
+  __shared__ int sh[256];
+  const long long base = (long long)blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+  int v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = (base + k < n) ? cnt[base + k] : 0;
+  const int mine = v[0] + v[1] + v[2] + v[3];
+  sh[threadIdx.x] = mine;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {                          // Hillis-Steele inclusive scan of the 256 thread sums
+    const int t = (threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  int run = sh[threadIdx.x] - mine;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { if (base + k < n) offs[base + k] = run; run += v[k]; }
+  if (threadIdx.x == 255) tile_sums[blockIdx.x] = sh[255];
+}
+__global__ __launch_bounds__(1024) void warp_scan_sums_kernel(int* __restrict__ tile_sums, int ntiles) {
+  __shared__ int sh[1024];
+  int carry = 0;
+  for (int base = 0; base < ntiles; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int mine = i < ntiles ? tile_sums[i] : 0;
+    sh[threadIdx.x] = mine;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int t = (threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < ntiles) tile_sums[i] = carry + sh[threadIdx.x] - mine;
+    carry += sh[1023];
+    __syncthreads();
+  }
+}
+__global__ void warp_scan_add_kernel(int* __restrict__ offs, const int* __restrict__ tile_sums, long long n) {
+  const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i < n) offs[i] += tile_sums[i / SCAN_TILE];
+}
+
+// entries[offs[q] + slot] = (p, wgt); slot counts cnt[q] down to 0, so no second counter array is needed
 template <typename T>
-__global__ void warp_index_kernel(const T* __restrict__ flow, int* __restrict__ cnt, WarpEntry* __restrict__ entries,
-                                  int* __restrict__ ovf_cnt, WarpOverflow* __restrict__ ovf, int ovf_cap,
-                                  int B, int H, int W, float scale) {
+__global__ void warp_fill_kernel(const T* __restrict__ flow, int* __restrict__ cnt, const int* __restrict__ offs,
+                                 WarpEntry* __restrict__ entries, int B, int H, int W, float scale) {
   const long long total = (long long)B * H * W;
   const long long pix = (long long)blockIdx.x * TPB + threadIdx.x;
   if (pix >= total) return;
@@ -530,22 +587,15 @@ __global__ void warp_index_kernel(const T* __restrict__ flow, int* __restrict__ 
       const int xx = x0 + j;
       if ((unsigned)xx >= (unsigned)W) continue;
       const int q = (b * H + yy) * W + xx;
-      const float wgt = cy[i] * cx[j];
-      const int slot = atomicAdd(cnt + q, 1);
-      if (slot < WARP_K) {
-        WarpEntry e; e.p = (int)pix; e.w = wgt;
-        entries[(size_t)q * WARP_K + slot] = e;
-      } else {
-        const int o = atomicAdd(ovf_cnt, 1);
-        if (o < ovf_cap) { WarpOverflow e; e.q = q; e.p = (int)pix; e.w = wgt; ovf[o] = e; }
-      }
+      const int slot = atomicSub(cnt + q, 1) - 1;
+      WarpEntry e; e.p = (int)pix; e.w = cy[i] * cx[j];
+      entries[(size_t)offs[q] + slot] = e;
     }
   }
 }
 
 template <typename T>
-__global__ void warp_gather_kernel(const T* __restrict__ gy, const int* __restrict__ cnt, const WarpEntry* __restrict__ entries,
-                                   const int* __restrict__ ovf_cnt, const WarpOverflow* __restrict__ ovf, int ovf_cap,
+__global__ void warp_gather_kernel(const T* __restrict__ gy, const int* __restrict__ offs, const WarpEntry* __restrict__ entries,
                                    T* __restrict__ gx, long long npix, int C) {
   const int nvec = C >> 3;
   const long long total = npix * nvec;
@@ -553,24 +603,13 @@ __global__ void warp_gather_kernel(const T* __restrict__ gy, const int* __restri
   if (gid >= total) return;
   const int v = (int)(gid % nvec);
   const long long q = gid / nvec;
-  const int n = cnt[q];
-  const int m = min(n, WARP_K);
-  const WarpEntry* e = entries + (size_t)q * WARP_K;
+  const int beg = offs[q], end = offs[q + 1];                  // offs has npix + 1 entries
   F8 s = f8_zero();
-  for (int k = 0; k < m; ++k) {
-    const WarpEntry en = e[k];
+  for (int k = beg; k < end; ++k) {
+    const WarpEntry en = entries[k];
     const F8 t = Feat<T>::load(gy + (size_t)en.p * C + v * 8);
 #pragma unroll
     for (int j = 0; j < 8; ++j) s.v[j] += en.w * t.v[j];
-  }
-  if (n > WARP_K) {                                            // rare: walk the global overflow list for this pixel
-    const int no = min(ovf_cnt[0], ovf_cap);
-    for (int k = 0; k < no; ++k) {
-      if (ovf[k].q != (int)q) continue;
-      const F8 t = Feat<T>::load(gy + (size_t)ovf[k].p * C + v * 8);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s.v[j] += ovf[k].w * t.v[j];
-    }
   }
   Feat<T>::store(gx + (size_t)q * C + v * 8, s);
 }
@@ -949,28 +988,29 @@ int lcgan_warp_fwd(const void* x, const void* flow, void* y, int B, int H, int W
   return launch_status();
 }
 
-// Backward of lcgan_warp_fwd.  gx: [B,H,W,C], gflow: [B,H,W,8].  Workspace (caller-allocated, any contents):
-//   ws_cnt   int   [B*H*W + 4]   (the last 4 ints hold the overflow counter; zeroed here with hipMemsetAsync)
-//   ws_ent   8 B x [B*H*W * 32]  per-input-pixel lists (p, weight)
-//   ws_ovf   12 B x [ovf_cap]    overflow list for pixels hit by more than 32 taps
-// Returns the data gradient through a gather (no float atomics).  If the overflow list itself overflows (ovf_cap too
-// small for a pathological flow) the excess taps are dropped and ws_cnt[B*H*W] > ovf_cap tells the caller.
+// Backward of lcgan_warp_fwd.  gx: [B,H,W,C], gflow: [B,H,W,8].  Workspace (caller-allocated, any contents), npix = B*H*W:
+//   ws_cnt   int [npix + 1]                       tap counts per input pixel (zeroed here)
+//   ws_off   int [npix + 1]                       list offsets (exclusive scan of the counts; the last one = total entries)
+//   ws_tiles int [ceil((npix + 1) / 1024)]        scan scratch
+//   ws_ent   8 B x [16 * npix]                    the lists: (output pixel, weight)
 int lcgan_warp_bwd(const void* gy, const void* x, const void* flow, void* gx, void* gflow,
-                   int* ws_cnt, void* ws_ent, void* ws_ovf, int ovf_cap,
+                   int* ws_cnt, int* ws_off, int* ws_tiles, void* ws_ent,
                    int B, int H, int W, int C, float scale, int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if ((C & 7) || !pow2_le64(C / 8) || H < 2 || W < 2 || (long long)B * H * W >= (1ll << 31) || ovf_cap < 1) return LCGAN_EINVAL;
+  if ((C & 7) || !pow2_le64(C / 8) || H < 2 || W < 2 || (long long)B * H * W * 16 >= (1ll << 31)) return LCGAN_EINVAL;
   const long long npix = (long long)B * H * W, n = npix * (C / 8);
   const double eb = dtype == DT_BF16 ? 2 : 4;
   ProfScope p(KID_WARP_BWD, 0, (double)n * 8 * 4 * eb + (double)npix * 16 * 8 * 2, s);
-  hipMemsetAsync(ws_cnt, 0, (size_t)(npix + 4) * sizeof(int), s);
-  int* ovf_cnt = ws_cnt + npix;
+  hipMemsetAsync(ws_cnt, 0, (size_t)(npix + 1) * sizeof(int), s);
+  const int ntiles = cdiv(npix + 1, SCAN_TILE);
   DISPATCH_T(dtype, {
-    hipLaunchKernelGGL(warp_bwd_grid_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)gy, (const T*)x, (const T*)flow, (T*)gflow, B, H, W, C, scale);
-    hipLaunchKernelGGL(warp_index_kernel<T>, grid1d(npix), dim3(TPB), 0, s, (const T*)flow, ws_cnt, (WarpEntry*)ws_ent, ovf_cnt,
-                       (WarpOverflow*)ws_ovf, ovf_cap, B, H, W, scale);
-    hipLaunchKernelGGL(warp_gather_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)gy, ws_cnt, (const WarpEntry*)ws_ent, ovf_cnt,
-                       (const WarpOverflow*)ws_ovf, ovf_cap, (T*)gx, npix, C);
+    hipLaunchKernelGGL(warp_bwd_grid_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)gy, (const T*)x, (const T*)flow, (T*)gflow, ws_cnt,
+                       B, H, W, C, scale);
+    hipLaunchKernelGGL(warp_scan_tiles_kernel, dim3(ntiles), dim3(256), 0, s, ws_cnt, ws_off, ws_tiles, npix + 1);
+    hipLaunchKernelGGL(warp_scan_sums_kernel, dim3(1), dim3(1024), 0, s, ws_tiles, ntiles);
+    hipLaunchKernelGGL(warp_scan_add_kernel, grid1d(npix + 1), dim3(TPB), 0, s, ws_off, ws_tiles, npix + 1);
+    hipLaunchKernelGGL(warp_fill_kernel<T>, grid1d(npix), dim3(TPB), 0, s, (const T*)flow, ws_cnt, ws_off, (WarpEntry*)ws_ent, B, H, W, scale);
+    hipLaunchKernelGGL(warp_gather_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)gy, ws_off, (const WarpEntry*)ws_ent, (T*)gx, npix, C);
   });
   return launch_status();
 }

@@ -293,13 +293,13 @@ class HipKernels:
         self._chk(gy, x, flow)
         B, H, W, Cc = x.shape
         npix = B * H * W
-        ovf_cap = 1 << 20
-        ws_cnt = torch.empty((npix + 4,), dtype=torch.int32, device=x.device)
-        ws_ent = torch.empty((npix * 32, 2), dtype=torch.int32, device=x.device)
-        ws_ovf = torch.empty((ovf_cap, 3), dtype=torch.int32, device=x.device)
+        ws_cnt = torch.empty((npix + 1,), dtype=torch.int32, device=x.device)
+        ws_off = torch.empty((npix + 1,), dtype=torch.int32, device=x.device)
+        ws_tiles = torch.empty(((npix + 1 + 1023) // 1024,), dtype=torch.int32, device=x.device)
+        ws_ent = torch.empty((npix * 16, 2), dtype=torch.int32, device=x.device)
         gx, gflow = torch.empty_like(x), torch.empty_like(flow)
         self._call("lcgan_warp_bwd", gy.data_ptr(), x.data_ptr(), flow.data_ptr(), gx.data_ptr(), gflow.data_ptr(), ws_cnt.data_ptr(),
-                   ws_ent.data_ptr(), ws_ovf.data_ptr(), ovf_cap, B, H, W, Cc, float(scale), dt_code(x.dtype), self._stream())
+                   ws_off.data_ptr(), ws_tiles.data_ptr(), ws_ent.data_ptr(), B, H, W, Cc, float(scale), dt_code(x.dtype), self._stream())
         return gx, gflow
 
     def mbstd_fwd(self, x: Tensor, G: int, Cy: int) -> Tensor:

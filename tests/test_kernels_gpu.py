@@ -261,9 +261,9 @@ def test_warp(H, dtype, shape):
     check(gf_g, gf_r, dtype, "warp gflow")
 
 
-def test_warp_bwd_overflow_lists(H):
-    """Every output pixel samples (almost) the same point: the per-input-pixel lists (capacity 32) overflow into the
-    global overflow list; the gather must still be exact."""
+def test_warp_bwd_collapsing_flow(H):
+    """Every output pixel samples (almost) the same point: 16 * 256 taps land on a handful of input pixels.  The backward's
+    per-input-pixel lists are exact CSR lists (count, scan, fill), so the gather must still be exact."""
     B, Hh, W, C = 2, 16, 16, 32
     dtype = torch.float32
     x, gy = feat((B, Hh, W, C), dtype, 54), feat((B, Hh, W, C), dtype, 55)
@@ -273,8 +273,24 @@ def test_warp_bwd_overflow_lists(H):
     flow[..., 1] = -(2 * gyy / (Hh - 1) - 1) - 0.021
     gx_r, gf_r = E.warp_bwd(gy, x, flow, 1.0)
     gx_g, gf_g = H.warp_bwd(gy.cuda(), x.cuda(), flow.cuda(), 1.0)
-    check(gx_g, gx_r, dtype, "overflow gx")
-    check(gf_g, gf_r, dtype, "overflow gflow")
+    check(gx_g, gx_r, dtype, "collapsed gx")
+    check(gf_g, gf_r, dtype, "collapsed gflow")
+
+
+def test_warp_bwd_rough_flow_large(H):
+    """A flow that compresses areas several-fold on a grid large enough for the multi-tile prefix scan (65 536 + 1 counts):
+    the first implementation (fixed 32-entry lists + capped overflow list) dropped entries here."""
+    B, Hh, W, C = 1, 256, 256, 16
+    dtype = torch.float32
+    x, gy = feat((B, Hh, W, C), dtype, 56), feat((B, Hh, W, C), dtype, 57)
+    g = torch.Generator().manual_seed(58)
+    coarse = torch.randn(B, 2, 8, 8, generator=g)
+    flow = torch.zeros(B, Hh, W, 8)
+    flow[..., :2] = torch.tanh(torch.nn.functional.interpolate(coarse, size=(Hh, W), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)) * 4
+    gx_r, gf_r = E.warp_bwd(gy, x, flow, 0.1)
+    gx_g, gf_g = H.warp_bwd(gy.cuda(), x.cuda(), flow.cuda(), 0.1)
+    check(gx_g, gx_r, dtype, "rough gx")
+    check(gf_g, gf_r, dtype, "rough gflow")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
