@@ -39,18 +39,16 @@ __global__ void box3_act_kernel(const T* __restrict__ x, T* __restrict__ y, int 
   const int strip = (int)(t % strips), b = (int)(t / strips);
   const int h0 = strip * BOX_RH, h1 = min(h0 + BOX_RH, H);
   const T* xb = x + (size_t)b * H * W * C + v * 8;
+  // branch-free taps: the column neighbours are clamped and masked once per thread, a row outside the image contributes zero
+  const int xl = max(w - 1, 0) * C, xc = w * C, xr = min(w + 1, W - 1) * C;
+  const float ml = w > 0 ? 1.f : 0.f, mr = w + 1 < W ? 1.f : 0.f;
   auto rowsum = [&](int hh) {
     F8 s = f8_zero();
     if ((unsigned)hh >= (unsigned)H) return s;
     const T* row = xb + (size_t)hh * W * C;
+    const F8 a = Feat<T>::load(row + xl), c = Feat<T>::load(row + xc), d = Feat<T>::load(row + xr);
 #pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) {
-      const int xx = w + dx;
-      if ((unsigned)xx >= (unsigned)W) continue;
-      const F8 q = Feat<T>::load(row + (size_t)xx * C);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s.v[j] += q.v[j];
-    }
+    for (int j = 0; j < 8; ++j) s.v[j] = a.v[j] * ml + c.v[j] + d.v[j] * mr;
     return s;
   };
   F8 r0 = rowsum(h0 - 1), r1 = rowsum(h0);
@@ -93,18 +91,15 @@ __global__ void box3_actbwd_reduce_kernel(const T* __restrict__ gy, const T* __r
     const int strip = (int)(t % strips), b = (int)(t / strips);
     const int h0 = strip * BOXB_RH, h1 = min(h0 + BOXB_RH, H);
     const T* gb = gy + (size_t)b * H * W * C + v * 8;
+    const int xl = max(w - 1, 0) * C, xc = w * C, xr = min(w + 1, W - 1) * C;     // branch-free column taps (see box3_act_kernel)
+    const float ml = w > 0 ? 1.f : 0.f, mr = w + 1 < W ? 1.f : 0.f;
     auto rowsum = [&](int hh) {
       F8 s = f8_zero();
       if ((unsigned)hh >= (unsigned)H) return s;
       const T* row = gb + (size_t)hh * W * C;
+      const F8 a = Feat<T>::load(row + xl), c = Feat<T>::load(row + xc), d = Feat<T>::load(row + xr);
 #pragma unroll
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int xx = w + dx;
-        if ((unsigned)xx >= (unsigned)W) continue;
-        const F8 q = Feat<T>::load(row + (size_t)xx * C);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s.v[j] += q.v[j];
-      }
+      for (int j = 0; j < 8; ++j) s.v[j] = a.v[j] * ml + c.v[j] + d.v[j] * mr;
       return s;
     };
     F8 r0 = rowsum(h0 - 1), r1 = rowsum(h0);
@@ -148,22 +143,22 @@ __global__ void box3_act_bwd_kernel(const T* __restrict__ gy, const T* __restric
   const int strip = (int)(t % strips), b = (int)(t / strips);
   const int h0 = strip * BOX_RH, h1 = min(h0 + BOX_RH, H);
   const size_t base = (size_t)b * H * W * C + v * 8;
+  const int xo[3] = {max(w - 1, 0), w, min(w + 1, W - 1)};          // branch-free column taps (see box3_act_kernel)
+  const float mk[3] = {w > 0 ? 1.f : 0.f, 1.f, w + 1 < W ? 1.f : 0.f};
   auto rowsum = [&](int hh) {
     F8 s = f8_zero();
     if ((unsigned)hh >= (unsigned)H) return s;
 #pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) {
-      const int xx = w + dx;
-      if ((unsigned)xx >= (unsigned)W) continue;
-      const size_t off = base + ((size_t)hh * W + xx) * C;
+    for (int d = 0; d < 3; ++d) {
+      const size_t off = base + ((size_t)hh * W + xo[d]) * C;
       const F8 g = Feat<T>::load(gy + off);
       if (act == ACT_NONE) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s.v[j] += g.v[j] * gain;
+        for (int j = 0; j < 8; ++j) s.v[j] += g.v[j] * (gain * mk[d]);
       } else {
         const F8 yo = Feat<T>::load(y + off);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s.v[j] += g.v[j] * act_grad_from_out(yo.v[j], act, gain);
+        for (int j = 0; j < 8; ++j) s.v[j] += g.v[j] * (act_grad_from_out(yo.v[j], act, gain) * mk[d]);
       }
     }
     return s;
