@@ -190,22 +190,16 @@ __global__ void up2box_kernel(const T* __restrict__ x, const T* __restrict__ res
   // output row Y=2i: (x[i-1] + 2 x[i]) / 3 ; Y=2i+1: (2 x[i] + x[i+1]) / 3
   const int i = Y >> 1, j = X >> 1;
   const int i2 = (Y & 1) ? i + 1 : i - 1, j2 = (X & 1) ? j + 1 : j - 1;
-  F8 s = f8_zero();
+  // branch-free taps: the neighbour row / column is clamped and weighted 0 outside the image
+  const float wy2 = ((unsigned)i2 < (unsigned)H) ? (1.f / 3.f) : 0.f, wx2 = ((unsigned)j2 < (unsigned)W) ? (1.f / 3.f) : 0.f;
+  const int i2c = min(max(i2, 0), H - 1), j2c = min(max(j2, 0), W - 1);
+  const T* xb = x + (size_t)b * H * W * C + v * 8;
+  const F8 t00 = Feat<T>::load(xb + ((size_t)i * W + j) * C), t01 = Feat<T>::load(xb + ((size_t)i * W + j2c) * C);
+  const F8 t10 = Feat<T>::load(xb + ((size_t)i2c * W + j) * C), t11 = Feat<T>::load(xb + ((size_t)i2c * W + j2c) * C);
+  F8 s;
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int yy = a ? i2 : i;
-    if ((unsigned)yy >= (unsigned)H) continue;
-    const float wy = a ? (1.f / 3.f) : (2.f / 3.f);
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int xx = c ? j2 : j;
-      if ((unsigned)xx >= (unsigned)W) continue;
-      const float wgt = wy * (c ? (1.f / 3.f) : (2.f / 3.f));
-      const F8 t = Feat<T>::load(x + (((size_t)b * H + yy) * W + xx) * C + v * 8);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) s.v[q] += t.v[q] * wgt;
-    }
-  }
+  for (int q = 0; q < 8; ++q)
+    s.v[q] = (2.f / 3.f) * ((2.f / 3.f) * t00.v[q] + wx2 * t01.v[q]) + wy2 * ((2.f / 3.f) * t10.v[q] + wx2 * t11.v[q]);
   const size_t off = (size_t)pix * C + v * 8;
   if (res) {
     const F8 r = Feat<T>::load(res + off);
