@@ -125,14 +125,40 @@ __global__ __launch_bounds__(TPB) void linear_bwd_data_kernel(const LinGroup g, 
 }
 
 // gw_l[o,i] = scale_l * sum_m gy_l[m,o] x[m,i]
+// Block = 16 rows o x 256 columns i: the 16 x M slice of gy is staged in LDS once (broadcast reads), x is read coalesced and
+// reused for the 16 rows from registers.  (One block per row re-read x 512 times and was latency-bound: 18 us for 512 x 512.)
+constexpr int LW_OT = 16, LW_MC = 64;
 __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(const LinGroup g, const float* __restrict__ x, int M, int I) {
+  __shared__ float gs[LW_MC][LW_OT];
   const int l = blockIdx.z, O = g.O[l];
-  const int i = blockIdx.x * TPB + threadIdx.x, o = blockIdx.y;
-  if (i >= I || o >= O) return;
+  const int o0 = blockIdx.y * LW_OT;
+  if (o0 >= O) return;
+  const int i = blockIdx.x * TPB + threadIdx.x;
   const float* __restrict__ gy = g.aux[l];
-  float acc = 0.f;
-  for (int m = 0; m < M; ++m) acc += gy[(size_t)m * O + o] * x[(size_t)m * I + i];
-  g.out[l][(size_t)o * I + i] = acc * g.scale[l];
+  float acc[LW_OT];
+#pragma unroll
+  for (int r = 0; r < LW_OT; ++r) acc[r] = 0.f;
+  for (int m0 = 0; m0 < M; m0 += LW_MC) {
+    const int mc = min(LW_MC, M - m0);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < mc * LW_OT; idx += TPB) {
+      const int mm = idx / LW_OT, r = idx - mm * LW_OT;
+      gs[mm][r] = (o0 + r < O) ? gy[(size_t)(m0 + mm) * O + o0 + r] : 0.f;
+    }
+    __syncthreads();
+    if (i < I) {
+      for (int mm = 0; mm < mc; ++mm) {
+        const float xv = x[(size_t)(m0 + mm) * I + i];
+#pragma unroll
+        for (int r = 0; r < LW_OT; ++r) acc[r] += gs[mm][r] * xv;
+      }
+    }
+  }
+  if (i < I) {
+#pragma unroll
+    for (int r = 0; r < LW_OT; ++r)
+      if (o0 + r < O) g.out[l][(size_t)(o0 + r) * I + i] = acc[r] * g.scale[l];
+  }
 }
 
 // gb_l[o] = bscale_l * sum_m gy_l[m,o]
@@ -439,7 +465,7 @@ int lcgan_linear_wgrad(const float* gy, const float* x, float* gw, int M, int I,
   ProfScope p(KID_LINEAR, 2.0 * M * I * O, 4.0 * I * O, s);
   LinGroup g = {};
   g.aux[0] = gy; g.out[0] = gw; g.O[0] = O; g.scale[0] = scale;
-  hipLaunchKernelGGL(linear_wgrad_kernel, dim3(cdiv(I, TPB), O, 1), dim3(TPB), 0, s, g, x, M, I);
+  hipLaunchKernelGGL(linear_wgrad_kernel, dim3(cdiv(I, TPB), cdiv(O, LW_OT), 1), dim3(TPB), 0, s, g, x, M, I);
   return launch_status();
 }
 int lcgan_colsum(const float* gy, float* gb, int M, int O, float scale, void* stream) {
@@ -477,7 +503,7 @@ int lcgan_linear_group_bwd(const float* const* gy, const float* x, const float* 
   if (gx) { const int rc = linear_group_bwd_data(g, L, maxO, gx, M, I, s); if (rc) return rc; }
   if (gw) {
     for (int l = 0; l < L; ++l) g.out[l] = gw[l];
-    hipLaunchKernelGGL(linear_wgrad_kernel, dim3(cdiv(I, TPB), maxO, L), dim3(TPB), 0, s, g, x, M, I);
+    hipLaunchKernelGGL(linear_wgrad_kernel, dim3(cdiv(I, TPB), cdiv(maxO, LW_OT), L), dim3(TPB), 0, s, g, x, M, I);
   }
   if (gb) {
     for (int l = 0; l < L; ++l) g.out[l] = gb[l];
