@@ -71,6 +71,7 @@ class HipKernels:
     def __init__(self):
         self.lib = _lib.load()
         self._zeros = _ZeroPool()
+        self._prep_tables = {}                 # cached device job tables of prep_weight_group
         import os
         for kv in filter(None, os.environ.get("LCGAN_OPTIONS", "").split(",")):     # tuning switches, e.g. LCGAN_OPTIONS="4=1,5=0"
             k, v = kv.split("=")
@@ -115,7 +116,6 @@ class HipKernels:
                                               ("kk", "<i4"), ("transpose", "<i4"), ("parts", "<i4"), ("N", "<i4"), ("Kc", "<i4"),
                                               ("Kpad", "<i4"), ("scale", "<f4"), ("pad", "<i4")])
             assert HipKernels._PREP_DESC.itemsize == 64
-            self._prep_tables = {}
         dev = jobs[0][0].device
         sig = tuple((w.data_ptr(), tuple(w.shape), float(sc), bool(tr), bool(lo), bool(ws)) for w, sc, tr, lo, ws in jobs)
         tab = self._prep_tables.get(sig)

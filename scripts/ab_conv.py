@@ -21,6 +21,7 @@ def kernels_for(path):
     k.lib = lib
     from lcgan_amd.kernels import _ZeroPool
     k._zeros = _ZeroPool()
+    k._prep_tables = {}
     return k
 
 
