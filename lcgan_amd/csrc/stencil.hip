@@ -627,7 +627,7 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 
 template <typename T>
 __global__ void mbstd_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int G, int HW, int C, int Cy) {
-  __shared__ float sh[8];
+  __shared__ float sh[16];
   const int M = N / G, m = blockIdx.x, I = HW * C;
   float part = 0.f;
   for (int i = threadIdx.x; i < I; i += blockDim.x) {
@@ -653,7 +653,7 @@ __global__ void mbstd_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int
 template <typename T>
 __global__ void mbstd_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x, T* __restrict__ gx,
                                  int N, int G, int HW, int C, int Cy) {
-  __shared__ float sh[8];
+  __shared__ float sh[16];
   const int M = N / G, m = blockIdx.x, I = HW * C;
   float part = 0.f;
   for (int i = threadIdx.x; i < G * HW; i += blockDim.x) {
@@ -684,7 +684,7 @@ __global__ void mbstd_bwd_kernel(const T* __restrict__ gy, const T* __restrict__
 template <typename T>
 __global__ void mbstd_bwd2_kernel(const T* __restrict__ v, const T* __restrict__ gy, const T* __restrict__ x,
                                   T* __restrict__ ggy, T* __restrict__ gx2, int N, int G, int HW, int C, int Cy) {
-  __shared__ float sh[8];
+  __shared__ float sh[16];
   const int M = N / G, m = blockIdx.x, I = HW * C;
   float part = 0.f;
   for (int i = threadIdx.x; i < G * HW; i += blockDim.x) {
@@ -1016,14 +1016,14 @@ int lcgan_mbstd_fwd(const void* x, void* y, int N, int G, int HW, int C, int Cy,
   hipStream_t s = (hipStream_t)stream;
   if (G < 1 || N % G || Cy <= C) return LCGAN_EINVAL;
   ProfScope p(KID_SMALL, 0, 0, s);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(mbstd_fwd_kernel<T>, dim3(N / G), dim3(512), 0, s, (const T*)x, (T*)y, N, G, HW, C, Cy));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(mbstd_fwd_kernel<T>, dim3(N / G), dim3(1024), 0, s, (const T*)x, (T*)y, N, G, HW, C, Cy));
   return launch_status();
 }
 int lcgan_mbstd_bwd(const void* gy, const void* x, void* gx, int N, int G, int HW, int C, int Cy, int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (G < 1 || N % G || Cy <= C) return LCGAN_EINVAL;
   ProfScope p(KID_SMALL, 0, 0, s);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(mbstd_bwd_kernel<T>, dim3(N / G), dim3(512), 0, s, (const T*)gy, (const T*)x, (T*)gx, N, G, HW, C, Cy));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(mbstd_bwd_kernel<T>, dim3(N / G), dim3(1024), 0, s, (const T*)gy, (const T*)x, (T*)gx, N, G, HW, C, Cy));
   return launch_status();
 }
 int lcgan_mbstd_bwd2(const void* v, const void* gy, const void* x, void* ggy, void* gx2,
@@ -1031,7 +1031,7 @@ int lcgan_mbstd_bwd2(const void* v, const void* gy, const void* x, void* ggy, vo
   hipStream_t s = (hipStream_t)stream;
   if (G < 1 || N % G || Cy <= C) return LCGAN_EINVAL;
   ProfScope p(KID_SMALL, 0, 0, s);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(mbstd_bwd2_kernel<T>, dim3(N / G), dim3(512), 0, s, (const T*)v, (const T*)gy, (const T*)x,
+  DISPATCH_T(dtype, hipLaunchKernelGGL(mbstd_bwd2_kernel<T>, dim3(N / G), dim3(1024), 0, s, (const T*)v, (const T*)gy, (const T*)x,
                                        (T*)ggy, (T*)gx2, N, G, HW, C, Cy));
   return launch_status();
 }
