@@ -137,8 +137,9 @@ int lcgan_l2norm_fwd(const float* x, float* y, float* nsave, int B, int D, float
 int lcgan_l2norm_bwd(const float* gy, const float* y, const float* nsave, float* gx, int B, int D, void* stream);
 int lcgan_powsum(const float* x, long long n, int pw, float coef, float* out, void* stream);          /* out zeroed by caller */
 int lcgan_powsum_bwd(const float* x, long long n, int pw, float coef, const float* gout, float* g, void* stream);
-/* torch.qr(tanh(basis))[0] custom_layers.py:274-276: Householder QR (LAPACK sign convention) of an n x n matrix, n <= 64 */
-int lcgan_qr_householder(const float* A, float* Q, float* R, int n, void* stream);
+/* torch.qr(tanh(basis))[0] custom_layers.py:274-276: Householder QR (LAPACK sign convention) of nb n x n matrices [nb][n][n],
+ * n <= 64, one workgroup per matrix (the geometry and the appearance mapping network share one launch) */
+int lcgan_qr_householder(const float* A, float* Q, float* R, int nb, int n, void* stream);
 /* cnn.py:95-97 */
 int lcgan_avg_latent(const float* w, float* avg, int B, int D, float beta, void* stream);
 

@@ -58,7 +58,7 @@ SIGNATURES = {
     "lcgan_l2norm_bwd": [P, P, P, P, I, I, P],
     "lcgan_powsum": [P, LL, I, F, P, P],
     "lcgan_powsum_bwd": [P, LL, I, F, P, P, P],
-    "lcgan_qr_householder": [P, P, P, I, P],
+    "lcgan_qr_householder": [P, P, P, I, I, P],
     "lcgan_avg_latent": [P, P, I, I, F, P],
     "lcgan_multi_tensor": [P, P, P, I, I, F, F, F, D, P],
     "lcgan_set_option": [I, I],

@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from . import config, ops
 from . import kernels as KM
-from .custom_layers import (DiscriminatorBlock, DiscriminatorEpilogue, EqualizedConv2d, MappingNetwork, ProjectionHead,
+from .custom_layers import (DiscriminatorBlock, DiscriminatorEpilogue, EqualizedConv2d, MappingNetwork, ProjectionHead, mapping_matrices,
                             SynthesisBlock, ToRGBBlock)
 from .kernels import ACT_LRELU
 
@@ -100,8 +100,9 @@ class Generator(torch.nn.Module):
 
     def forward(self, rand_noise1, rand_noise2, w_psi=-1.0):
         batch_size = rand_noise1.size(0)
-        geometry_code = self.geometry_mapping(rand_noise1.float())
-        appearance_code = self.appearance_mapping(rand_noise2.float())
+        Lg, La = mapping_matrices((self.geometry_mapping, self.appearance_mapping))      # both QR factorisations in one launch
+        geometry_code = self.geometry_mapping(rand_noise1.float(), Lg)
+        appearance_code = self.appearance_mapping(rand_noise2.float(), La)
 
         if w_psi <= 0:                                   # running latent means (cnn.py:95-97), one tiny kernel each
             KM.K.avg_latent(geometry_code.detach(), self.avg_latent1, self.w_avg_beta)

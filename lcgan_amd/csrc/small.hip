@@ -335,6 +335,7 @@ __global__ void avg_latent_kernel(const float* __restrict__ w, float* __restrict
 constexpr int QR_MAX = 64;
 __global__ __launch_bounds__(2 * QR_MAX) void qr_householder_kernel(const float* __restrict__ A, float* __restrict__ Q,
                                                                      float* __restrict__ R, int n) {
+  A += (size_t)blockIdx.x * n * n; Q += (size_t)blockIdx.x * n * n; R += (size_t)blockIdx.x * n * n;   // one matrix per workgroup
   __shared__ __attribute__((aligned(16))) float vrow[2][QR_MAX];
   __shared__ float taus[2];
   const int c = threadIdx.x & (QR_MAX - 1);
@@ -586,12 +587,12 @@ int lcgan_powsum_bwd(const float* x, long long n, int pw, float coef, const floa
   hipLaunchKernelGGL(powsum_bwd_kernel, dim3(cdiv(n, TPB)), dim3(TPB), 0, s, x, n, pw, coef, gout, g);
   return launch_status();
 }
-// Q, R of the reduced QR of the row-major n x n matrix A (n <= 64), LAPACK Householder convention
-int lcgan_qr_householder(const float* A, float* Q, float* R, int n, void* stream) {
+// Q, R of the reduced QR of nb row-major n x n matrices A [nb][n][n] (n <= 64), LAPACK Householder convention; one workgroup each
+int lcgan_qr_householder(const float* A, float* Q, float* R, int nb, int n, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (n < 1 || n > QR_MAX) return LCGAN_EINVAL;
+  if (n < 1 || n > QR_MAX || nb < 1) return LCGAN_EINVAL;
   ProfScope p(KID_SMALL, 0, 0, s);
-  hipLaunchKernelGGL(qr_householder_kernel, dim3(1), dim3(2 * QR_MAX), 0, s, A, Q, R, n);
+  hipLaunchKernelGGL(qr_householder_kernel, dim3(nb), dim3(2 * QR_MAX), 0, s, A, Q, R, n);
   return launch_status();
 }
 int lcgan_avg_latent(const float* w, float* avg, int B, int D, float beta, void* stream) {

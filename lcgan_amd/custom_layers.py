@@ -279,12 +279,26 @@ class MappingNetwork(nn.Module):
     def mapping_matrix(self):
         return self.orthogonalize(torch.tanh(self.basis_params)) * (self.diagonal_params.abs() + self.eps).unsqueeze(0)
 
-    def forward(self, z):
-        L = self.mapping_matrix().contiguous()                                  # [m,m]; 64x64 torch glue
+    def forward(self, z, L=None):
+        """L: this network's mapping matrix when the caller computed it together with another network's (mapping_matrices)"""
+        if L is None:
+            L = self.mapping_matrix()
+        L = L.contiguous()                                                      # [m,m]; 64x64 torch glue
         x = ops.LinearFn.apply(z.contiguous(), L, None, 1.0, 0.0, ACT_NONE, 1.0)   # x_b = L z_b  (:283-285)
         for layer in self.mlp:
             x = layer(x)
         return x
+
+
+def mapping_matrices(nets):
+    """[net.mapping_matrix() for net in nets] with ONE QR launch when the matrices have the same size (the geometry and the
+    appearance network: two 64 x 64 factorisations, one workgroup each)."""
+    nets = list(nets)
+    if len({n.matrix_size for n in nets}) != 1 or nets[0].matrix_size > 64:
+        return [n.mapping_matrix() for n in nets]
+    Q = ops.QrQFn.apply(torch.tanh(torch.stack([n.basis_params for n in nets])))
+    d = torch.stack([n.diagonal_params for n in nets]).abs() + nets[0].eps
+    return list((Q * d.unsqueeze(1)).unbind(0))
 
 
 class ProjectionHead(nn.Module):

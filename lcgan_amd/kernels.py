@@ -528,12 +528,12 @@ class HipKernels:
         return g
 
     def qr(self, A: Tensor) -> Tuple[Tensor, Tensor]:
-        """(Q, R) of the reduced Householder QR of a square matrix (n <= 64), LAPACK sign convention"""
+        """(Q, R) of the reduced Householder QR of square matrices [n,n] or [nb,n,n] (n <= 64), LAPACK sign convention"""
         self._chk(A)
-        n = A.shape[0]
-        assert A.shape == (n, n) and n <= 64 and A.dtype == torch.float32
+        n = A.shape[-1]
+        assert A.shape[-2] == n and n <= 64 and A.dtype == torch.float32 and A.dim() in (2, 3)
         Q, R = torch.empty_like(A), torch.empty_like(A)
-        self._call("lcgan_qr_householder", A.data_ptr(), Q.data_ptr(), R.data_ptr(), n, self._stream())
+        self._call("lcgan_qr_householder", A.data_ptr(), Q.data_ptr(), R.data_ptr(), A.numel() // (n * n), n, self._stream())
         return Q, R
 
     def avg_latent(self, w: Tensor, avg: Tensor, beta: float) -> None:

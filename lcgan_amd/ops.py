@@ -690,8 +690,8 @@ class WarpFn(Function):
 
 
 class QrQFn(Function):
-    """Q of the reduced Householder QR of a square matrix (torch.qr(.)[0], custom_layers.py:274-276) in one HIP workgroup.
-    Backward (Q only, A = QR square and invertible): with G = Q^T gQ,  gA = Q tril(G - G^T, -1) R^{-T}
+    """Q of the reduced Householder QR of square matrices [n,n] or [nb,n,n] (torch.qr(.)[0], custom_layers.py:274-276), one HIP
+    workgroup per matrix.  Backward (Q only, A = QR square and invertible): with G = Q^T gQ,  gA = Q tril(G - G^T, -1) R^{-T}
     (from Q^T dA R^{-1} = Q^T dQ + dR R^{-1}: antisymmetric + upper-triangular); a 64 x 64 triangular solve of torch glue."""
 
     @staticmethod
@@ -704,8 +704,8 @@ class QrQFn(Function):
     @once_differentiable
     def backward(ctx, gQ):
         Q, R = ctx.saved_tensors
-        G = Q.t() @ gQ
-        return torch.linalg.solve_triangular(R.t(), Q @ torch.tril(G - G.t(), -1), upper=False, left=False)
+        G = Q.transpose(-1, -2) @ gQ
+        return torch.linalg.solve_triangular(R.transpose(-1, -2), Q @ torch.tril(G - G.transpose(-1, -2), -1), upper=False, left=False)
 
 
 # =====================================================================================================
