@@ -167,3 +167,56 @@ def test_qr_backward_formula_matches_torch():
     A.grad = None
     (ops.QrQFn.apply(A) * gQ).sum().backward()
     assert rel(A.grad, ref) <= 1e-4
+
+
+def test_qr_batched_backward_matches_torch():
+    """the batched form (both mapping networks in one launch) against autograd through torch.linalg.qr"""
+    from lcgan_amd import ops
+    A = torch.tanh(seeded_tensor((2, 16, 16), 7)).requires_grad_(True)
+    gQ = seeded_tensor((2, 16, 16), 8)
+    (torch.linalg.qr(A, mode="reduced")[0] * gQ).sum().backward()
+    ref = A.grad.clone()
+    A.grad = None
+    (ops.QrQFn.apply(A) * gQ).sum().backward()
+    assert rel(A.grad, ref) <= 1e-4
+
+
+def test_prepared_weights_are_rebuilt_in_groups_after_an_optimiser_step():
+    """ops._prep: the first iteration prepares weights one by one and records the recipes; after Adam invalidated a network's
+    parameters the first miss rebuilds ALL its recorded variants in one grouped call, and the results are the same tensors a
+    single preparation gives."""
+    import lcgan_amd.kernels as KM
+    from lcgan_amd import loader, ops
+    from tests.helpers import make_args
+    calls = {"single": 0, "group": 0, "jobs": 0}
+    be = KM._Lazy._impl
+    single, group = be.prep_weight, be.prep_weight_group
+
+    def count_single(*a, **k):
+        calls["single"] += 1
+        return single(*a, **k)
+
+    def count_group(jobs):
+        calls["group"] += 1
+        calls["jobs"] += len(jobs)
+        return [single(*j) for j in jobs]
+
+    be.prep_weight, be.prep_weight_group = count_single, count_group
+    try:
+        w = seeded_worker(32, 4, torch.device("cpu"))
+        args = make_args(32, 4)
+        loader.train_iteration(w, args, 1)
+        first = dict(calls)
+        # nothing recorded at first: one by one (only the generator, already stepped by Adam when the D step runs it again,
+        # can take the grouped path inside the first iteration)
+        assert first["single"] > 20 and first["group"] <= 1
+        loader.train_iteration(w, args, 3)
+        assert calls["group"] - first["group"] >= 2 and calls["jobs"] > 20    # G's and D's variants, each rebuilt by one grouped call
+        assert calls["single"] - first["single"] < first["single"] // 4    # hardly any single preparation left
+        # the cache holds what a fresh single preparation returns
+        conv = w.discriminator.module.shared_model[2].conv0.weight
+        pw, _ = ops._prep(conv.weight, conv.c, False, True)
+        ref, _ = single(conv.weight, conv.c, False, True)
+        assert torch.equal(pw.P4, ref.P4)
+    finally:
+        be.prep_weight, be.prep_weight_group = single, group
