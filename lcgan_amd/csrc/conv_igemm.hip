@@ -35,6 +35,7 @@ int g_wgrad3_small = 0;                   // lcgan_set_option(5, ...): row-segme
 int g_wgrad3_wgs = 0;                     // lcgan_set_option(2, ...): 0 = cost-model split of the row-segment wgrad kernel, > 0 = explicit workgroup target
 int g_halo_min_wgs = 128;                 // lcgan_set_option(6, ...): halo launches with fewer workgroups go to the split-K implicit GEMM
 int g_wgrad_slab_min = 4;                 // lcgan_set_option(8, ...): row-segment wgrad launches with at least this many splits reduce through a slab instead of atomics (0 = never)
+int g_halo_narrow_min_wgs = 256;          // lcgan_set_option(7, ...): narrow-layer halo kernel (Cout <= 64, 32 x 32 tiles) from this many workgroups; 0 = never
 int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): experiments, bit mask (the wgrad3 no-atomics switch is gone: it sat in the epilogue);
                                           // halo kernel: 8 = linear tile order (the store / emit / main-loop skipping switches used for the
                                           // fixed-cost analysis in DESIGN.md were removed again: they sat in the hot epilogue)
@@ -537,6 +538,208 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
   }
 }
 
+// =========================================================================================================
+// halo-tile kernel for NARROW layers (Cout <= 64: the C = 32 / 64 octaves of the 512 x 512 and 1024 x 1024 networks), stride-1
+// geometries.  conv_halo_kernel's 128-channel N tile wastes 2-4x of its MFMA work there and its 256-position tiles pay the
+// per-workgroup fixed cost 131 072 times per 1024 x 1024 launch (3.2 ms for a layer whose HBM traffic is worth 0.9 ms).  Here a
+// workgroup owns (8 RW) x 32 positions x all (<= 64) channels: each of the 8 waves RW image rows (RW x NT accumulators of 32 x 32).
+// RW = 2 (16 x 32 tiles) keeps two workgroups per CU; RW = 4 (32 x 32, one workgroup per CU) measured slower: with a 9-step
+// main loop the exposed first-load / store-drain latency of a lone workgroup dominates.  Same staging / tap / epilogue scheme
+// as conv_halo_kernel.
+// =========================================================================================================
+constexpr int NTW = 32;                       // tile width (positions); height = 8 waves x RW rows
+template <int NT, int RW, int EPI>
+__global__ __launch_bounds__(512, RW == 2 ? 4 : 2) void conv_halo_narrow_kernel(HaloArgs a) {
+  constexpr bool SR = EPI == 3;
+  constexpr int BNn = 32 * NT;
+  constexpr int NTH = 8 * RW;                 // RW = 2: 16 x 32 tiles, <= 128 VGPRs and < 80 KB of LDS: two workgroups per CU
+  constexpr int NI = ((NTH + 2) * (NTW + 2) * 4 + 511) / 512;   // halo items per thread
+  constexpr int BTILE = BNn * HROW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16* halo = (__bf16*)smem;
+  __bf16* Bt = halo + a.halo_elems;           // 2 x [BNn][HROW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
+  const int phase = gridDim.z - 1 - blockIdx.z, n0 = blockIdx.y * BNn;
+  int tile = blockIdx.x;
+  if ((gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous tiles
+  const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
+  const TapTable& tt = a.taps[phase];
+  const int hy0 = a.hy0[phase], hx0 = a.hx0[phase], hh = a.hh[phase], hw = a.hw[phase];
+  const int gy0 = ty * NTH + hy0, gx0 = tx * NTW + hx0;
+
+  const int hvec = tid & 3;
+  int goff[NI], loff[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int hp = (tid >> 2) + k * 128;
+    loff[k] = -1; goff[k] = -1;
+    if (hp < hh * hw) {
+      const int hy = hp / hw, hx = hp - hy * hw;
+      const int gy = gy0 + hy, gx = gx0 + hx;
+      loff[k] = hp * HROW + hvec * 8;
+      if ((unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win) goff[k] = ((b * a.Hin + gy) * a.Win + gx) * a.Cin + hvec * 8;
+    }
+  }
+  bf16x8 hreg[NI];
+  auto halo_load = [&](int c0) {
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const bool ok = goff[k] >= 0 && c0 + hvec * 8 < a.Cin;
+      hreg[k] = ok ? *(const bf16x8*)(a.x + (size_t)goff[k] + c0) : zero_bf16x8();
+    }
+    if (a.pre) {
+      const float* ps = a.pre + (size_t)b * a.Cin + c0 + hvec * 8;
+      float sc[8];
+      if (c0 + hvec * 8 < a.Cin) {
+        const f32x4 p0 = *(const f32x4*)ps, p1 = *(const f32x4*)(ps + 4);
+        sc[0] = p0[0]; sc[1] = p0[1]; sc[2] = p0[2]; sc[3] = p0[3]; sc[4] = p1[0]; sc[5] = p1[1]; sc[6] = p1[2]; sc[7] = p1[3];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sc[j] = 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < NI; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hreg[k][j] = (__bf16)((float)hreg[k][j] * sc[j]);
+    }
+  };
+  auto halo_store = [&]() {
+#pragma unroll
+    for (int k = 0; k < NI; ++k)
+      if (loff[k] >= 0) *(bf16x8*)(halo + loff[k]) = hreg[k];
+  };
+
+  // weight tile: BNn rows x 4 vectors, one item per thread (threads beyond it idle); prefetched two taps ahead
+  const int brow = tid >> 2;
+  const int ntaps = tt.n, nchunks = a.kc_per_tap, total = ntaps * nchunks;
+  const size_t wrow = (size_t)(n0 + brow) * a.Kpad + hvec * 8;
+  const bool bthread = brow < BNn, bvalid = bthread && n0 + brow < a.N;
+  auto b_load = [&](int c, int t) -> bf16x8 {
+    return bvalid ? *(const bf16x8*)(a.w + (size_t)tt.wt[t] * a.N * a.Kpad + wrow + c * BK) : zero_bf16x8();
+  };
+  auto b_store = [&](int buf, const bf16x8& r) { if (bthread) *(bf16x8*)(Bt + buf * BTILE + brow * HROW + hvec * 8) = r; };
+
+  const int lrow = lane & 31, lk = (lane >> 5) * 8;
+  const int abase0 = ((wm * RW) * hw + lrow) * HROW + lk;         // + mi * hw * HROW: tile pixel (row wm*RW + mi, column lane & 31)
+  const int bbase = lrow * HROW + lk;                             // + ni * 32 * HROW
+
+  f32x16 acc[RW][NT];
+#pragma unroll
+  for (int i = 0; i < RW; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int lc = 0, lt = 0;
+  auto advance = [&]() { if (++lt == ntaps) { lt = 0; ++lc; } };
+
+  halo_load(0);
+  halo_store();
+  b_store(0, b_load(0, 0));
+  advance();
+  bf16x8 r0 = (1 < total) ? b_load(lc, lt) : zero_bf16x8();
+  advance();
+  bf16x8 r1 = zero_bf16x8();
+  __syncthreads();
+
+  int c = 0, t = 0;
+  auto step = [&](int q, bf16x8& rs, bf16x8& rl) {
+    if (t == 0 && c + 1 < nchunks) halo_load((c + 1) * BK);
+    if (q + 2 < total) { rl = b_load(lc, lt); advance(); }
+    const int toff = ((tt.dy[t] - hy0) * hw + (tt.dx[t] - hx0)) * HROW;
+    const __bf16* Bc = Bt + (q & 1) * BTILE + bbase;
+    const __bf16* Ab = halo + abase0 + toff;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[RW], bf[NT];
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) bf[ni] = *(const bf16x8*)(Bc + ni * 32 * HROW + ks * 16);
+#pragma unroll
+      for (int mi = 0; mi < RW; ++mi) af[mi] = *(const bf16x8*)(Ab + mi * hw * HROW + ks * 16);
+#pragma unroll
+      for (int mi = 0; mi < RW; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    }
+    if (t == ntaps - 1 && c + 1 < nchunks) {
+      __syncthreads();
+      halo_store();
+    }
+    if (q + 1 < total) b_store((q + 1) & 1, rs);
+    __syncthreads();
+    if (++t == ntaps) { t = 0; ++c; }
+  };
+  for (int q = 0; q < total; q += 2) {
+    step(q, r0, r1);
+    if (q + 1 < total) step(q + 1, r1, r0);
+  }
+
+  // ---- epilogue: registers -> bf16 tile [NTH*32][OROW] in LDS -> 16-byte coalesced stores -------------------------------------
+  constexpr int OROW = BNn + 8, NV = BNn / 8;                       // NV vectors per output row
+  constexpr int NIT = NTH * NTW * NV / 512;                         // (row, vector) items per thread
+  __bf16* ot = (__bf16*)smem;
+  float* colbuf = (float*)(smem + (size_t)NTH * NTW * OROW * sizeof(__bf16));
+  const __bf16* side = SR ? a.xs : a.residual;
+  if (SR && tid < BNn) colbuf[tid] = 0.f;
+  if (EPI != 0) {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int idx = tid + k * 512;
+      const int row = idx / NV, vv = idx - row * NV;
+      const int py = ty * NTH + (row >> 5), px = tx * NTW + (row & 31);
+      const int n = n0 + vv * 8;
+      bf16x8 rr = zero_bf16x8();
+      if (py < a.Hm && px < a.Wm && n < a.Cout) {
+        const int oy = py * a.out_mul + (phase >> 1), ox = px * a.out_mul + (phase & 1);
+        rr = (EPI == 2) ? *(const bf16x8*)(side + ((size_t)(b * (a.Hout >> 1) + (oy >> 1)) * (a.Wout >> 1) + (ox >> 1)) * a.Cout + n)
+                        : *(const bf16x8*)(side + ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n);
+      }
+      *(bf16x8*)(ot + row * OROW + vv * 8) = rr;
+    }
+    __syncthreads();
+  }
+  constexpr float res_scale = EPI == 2 ? 0.25f : 1.f;
+#pragma unroll
+  for (int ni = 0; ni < NT; ++ni) {
+    const int nl = ni * 32 + (lane & 31);
+    const int n = n0 + nl;
+    const float bv = (a.bias && n < a.N) ? a.bias[n] * a.bias_scale : 0.f;
+    const float pv = (a.post && n < a.Cout) ? a.post[(size_t)b * a.Cout + n] : 1.f;
+    float cs = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < RW; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * RW + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const float accv = acc[mi][ni][r];
+        float v = accv * pv + bv;
+        v = (a.act == ACT_LRELU ? (v > 0.f ? v : v * LRELU_SLOPE) : v) * a.gain;
+        if (SR) cs += accv * (float)ot[row * OROW + nl];
+        else if (EPI != 0) v += res_scale * (float)ot[row * OROW + nl];
+        ot[row * OROW + nl] = (__bf16)v;
+      }
+    if (SR) {
+      cs += __shfl_xor(cs, 32, 64);
+      if (lane < 32) atomicAdd(&colbuf[nl], cs);
+    }
+  }
+  __syncthreads();
+  if (SR && tid < BNn && n0 + tid < a.Cout) atomicAdd(a.gs + (size_t)b * a.Cout + n0 + tid, colbuf[tid]);
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int idx = tid + k * 512;
+    const int row = idx / NV, vv = idx - row * NV;
+    const int py = ty * NTH + (row >> 5), px = tx * NTW + (row & 31);
+    const int n = n0 + vv * 8;
+    if (py >= a.Hm || px >= a.Wm || n >= a.Cout) continue;
+    const int oy = py * a.out_mul + (phase >> 1), ox = px * a.out_mul + (phase & 1);
+    *(bf16x8*)(a.y + ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n) = *(const bf16x8*)(ot + row * OROW + vv * 8);
+  }
+}
+
 // fp32 scratch of the split-K paths ([output pixel][Cout] partial sums met by atomics).  Grow-only, owned by the library,
 // zeroed once when allocated: conv_finalize_kernel re-zeroes what it consumes, so launches need no memset.
 float* g_splitk_ws = nullptr;
@@ -562,10 +765,60 @@ void launch_finalize(const ConvArgs& a, float* ws, hipStream_t s) {
                      (const T*)a.residual, npix, a.Hout * a.Wout, a.Cout, a.N, a.bias_scale, a.gain, a.act, a.res_half, a.Wout);
 }
 
+// narrow layers (Cout <= 64), stride-1 geometries whose grid holds whole 32 x 32 tiles and fills the chip
+bool try_launch_halo_narrow(const ConvArgs& c, int nphase, hipStream_t s) {
+  constexpr int RW = 2, NTH = 8 * RW;
+  if (c.Cout > 64 || (c.Hm % NTH) || (c.Wm % NTW)) return false;
+  HaloArgs a = {};
+  a.x = (const __bf16*)c.x; a.w = c.w; a.y = (__bf16*)c.y; a.pre = c.pre; a.post = c.post; a.bias = c.bias;
+  a.residual = (const __bf16*)c.residual; a.res_half = c.res_half; a.dbg = g_dbg_no_atomics;
+  a.xs = (const __bf16*)c.xs; a.gs = c.gs;
+  a.B = c.B; a.Hin = c.Hin; a.Win = c.Win; a.Cin = c.Cin; a.Hout = c.Hout; a.Wout = c.Wout; a.Cout = c.Cout;
+  a.Hm = c.Hm; a.Wm = c.Wm; a.N = c.N; a.Kpad = c.Kpad; a.kc_per_tap = c.kc_per_tap; a.out_mul = c.out_mul;
+  a.tiles_x = c.Wm / NTW; a.tiles_y = c.Hm / NTH;
+  a.bias_scale = c.bias_scale; a.gain = c.gain; a.act = c.act;
+  const int nt = c.Cout <= 32 ? 1 : 2, bnn = 32 * nt;
+  const long long wgs = (long long)c.B * a.tiles_x * a.tiles_y * cdiv(c.Cout, bnn) * nphase;
+  if (wgs < g_halo_narrow_min_wgs) return false;
+  int max_halo = 0;
+  for (int p = 0; p < nphase; ++p) {
+    a.taps[p] = c.taps[p];
+    int ymin = 99, ymax = -99, xmin = 99, xmax = -99;
+    for (int t = 0; t < c.taps[p].n; ++t) {
+      ymin = std::min(ymin, c.taps[p].dy[t]); ymax = std::max(ymax, c.taps[p].dy[t]);
+      xmin = std::min(xmin, c.taps[p].dx[t]); xmax = std::max(xmax, c.taps[p].dx[t]);
+    }
+    a.hy0[p] = ymin; a.hx0[p] = xmin;
+    a.hh[p] = (NTH - 1) + (ymax - ymin) + 1; a.hw[p] = (NTW - 1) + (xmax - xmin) + 1;
+    max_halo = std::max(max_halo, a.hh[p] * a.hw[p]);
+  }
+  if (max_halo > (NTH + 2) * (NTW + 2)) return false;
+  a.halo_elems = max_halo * HROW;
+  const size_t smem = std::max(((size_t)a.halo_elems + 2 * bnn * HROW) * sizeof(__bf16),
+                               (size_t)NTH * NTW * (bnn + 8) * sizeof(__bf16) + bnn * sizeof(float));
+  dim3 grid((unsigned)(c.B * a.tiles_x * a.tiles_y), cdiv(c.Cout, bnn), nphase);
+#define LAUNCH_NARROW(NTT, EP)                                                                                          \
+  {                                                                                                                     \
+    static bool set = false;                                                                                            \
+    if (!set) { hipFuncSetAttribute((const void*)conv_halo_narrow_kernel<NTT, RW, EP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
+    hipLaunchKernelGGL((conv_halo_narrow_kernel<NTT, RW, EP>), grid, dim3(512), smem, s, a);                            \
+  }
+#define LAUNCH_NARROW_EPI(NTT)                                                                                          \
+  {                                                                                                                     \
+    if (a.xs) LAUNCH_NARROW(NTT, 3) else if (a.residual && a.res_half) LAUNCH_NARROW(NTT, 2)                            \
+    else if (a.residual) LAUNCH_NARROW(NTT, 1) else LAUNCH_NARROW(NTT, 0)                                               \
+  }
+  if (nt == 1) LAUNCH_NARROW_EPI(1) else LAUNCH_NARROW_EPI(2)
+#undef LAUNCH_NARROW_EPI
+#undef LAUNCH_NARROW
+  return true;
+}
+
 // host side: returns true when the halo kernel was launched for this geometry
 bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   if (c.Hm < HT || c.Wm < HT || c.act == ACT_TANH) return false;
   if ((long long)c.B * c.Hin * c.Win * c.Cin >= (1ll << 31) || (long long)c.B * c.Hout * c.Wout * c.Cout >= (1ll << 31)) return false;
+  if (in_mul == 1 && g_halo_narrow_min_wgs > 0 && try_launch_halo_narrow(c, nphase, s)) return true;
   HaloArgs a = {};
   a.x = (const __bf16*)c.x; a.w = c.w; a.y = (__bf16*)c.y; a.pre = c.pre; a.post = c.post; a.bias = c.bias;
   a.residual = (const __bf16*)c.residual; a.res_half = c.res_half; a.dbg = g_dbg_no_atomics;
@@ -1137,6 +1390,7 @@ int lcgan_set_option(int option, int value) {
   if (option == 4) { const int old = g_mfma16; g_mfma16 = value; return old; }
   if (option == 5) { const int old = g_wgrad3_small; g_wgrad3_small = value; return old; }
   if (option == 6) { const int old = g_halo_min_wgs; g_halo_min_wgs = value; return old; }
+  if (option == 7) { const int old = g_halo_narrow_min_wgs; g_halo_narrow_min_wgs = value; return old; }
   if (option == 8) { const int old = g_wgrad_slab_min; g_wgrad_slab_min = value; return old; }
   return LCGAN_EINVAL;
 }

@@ -155,6 +155,51 @@ def test_conv_bwd_data(H, dtype, case):
               E.conv_bwd_data(g, pw_e, Ci, k, stride, residual=rh, residual_half=True), dtype, "half-res residual")
 
 
+NARROW_CASES = [
+    # B, H, W, Cin, Cout, stride: layers with <= 64 output channels on grids of whole 32 x 32 tiles (the C = 32 / 64 octaves of the
+    # 512 x 512 and 1024 x 1024 networks) -> conv_halo_narrow_kernel (forced here for small grids through option 7)
+    (1, 64, 64, 32, 32, 1),
+    (2, 32, 64, 64, 64, 1),
+    (1, 32, 32, 128, 24, 1),
+    (2, 64, 32, 40, 64, 1),
+]
+
+
+@pytest.mark.parametrize("case", NARROW_CASES)
+def test_conv_narrow_layers(H, case):
+    B, Hh, W, Ci, Co, _ = case
+    dtype = torch.bfloat16
+    old = H.lib.lcgan_set_option(7, 1)
+    try:
+        x = feat((B, Hh, W, ceil8(Ci)), dtype, 31, Ci)
+        w = torch.randn(Co, Ci, 3, 3, generator=torch.Generator().manual_seed(32))
+        bias = torch.randn(Co, generator=torch.Generator().manual_seed(33))
+        scale = 1 / math.sqrt(Ci * 9)
+        pw_e, _ = E.prep_weight(w, scale, False, False)
+        pw_h, _ = H.prep_weight(w.cuda(), scale, False, False)
+        check(H.conv_fwd(x.cuda(), pw_h, Co, 3, 1, bias=bias.cuda(), bias_scale=0.5, act=1, gain=1.4),
+              E.conv_fwd(x, pw_e, Co, 3, 1, bias=bias, bias_scale=0.5, act=1, gain=1.4), dtype, "bias+lrelu")
+        pre, post = vec((B, ceil8(Ci)), 34), vec((B, ceil8(Co)), 35)
+        res = feat((B, Hh, W, ceil8(Co)), dtype, 36, Co)
+        check(H.conv_fwd(x.cuda(), pw_h, Co, 3, 1, pre=pre.cuda(), post=post.cuda(), bias=bias.cuda(), residual=res.cuda()),
+              E.conv_fwd(x, pw_e, Co, 3, 1, pre=pre, post=post, bias=bias, residual=res), dtype, "mod+residual")
+        y_h, gs_h = H.conv_fwd(x.cuda(), pw_h, Co, 3, 1, pre=pre.cuda(), post=post.cuda(), xs=res.cuda())
+        y_e, gs_e = E.conv_fwd(x, pw_e, Co, 3, 1, pre=pre, post=post, xs=res)
+        check(y_h, y_e, dtype, "fused y")
+        check(gs_h, gs_e, dtype, "fused gs", l2_scale=3.0)
+        # data gradient (stride 1: Cin output channels must be <= 64 to stay on the narrow kernel) and the 4-phase transposed conv
+        g = feat((B, Hh, W, ceil8(Co)), dtype, 37, Co)
+        pwt_e, _ = E.prep_weight(w, scale, True, False)
+        pwt_h, _ = H.prep_weight(w.cuda(), scale, True, False)
+        rh = feat((B, Hh // 2, W // 2, ceil8(Ci)), dtype, 38, Ci)
+        check(H.conv_bwd_data(g.cuda(), pwt_h, Ci, 3, 1, residual=rh.cuda(), residual_half=True),
+              E.conv_bwd_data(g, pwt_e, Ci, 3, 1, residual=rh, residual_half=True), dtype, "dgrad + half-res residual")
+        check(H.conv_bwd_data(g.cuda(), pwt_h, Ci, 3, 2, pre=post.cuda(), bias=None, act=0),
+              E.conv_bwd_data(g, pwt_e, Ci, 3, 2, pre=post, bias=None, act=0), dtype, "transposed conv")
+    finally:
+        H.lib.lcgan_set_option(7, old)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES + [(2, 16, 16, 64, 2, 3, 2),
                                   # row-segment bf16 kernel (k = 3, output-side width a multiple of 32)
