@@ -36,6 +36,7 @@ int g_wgrad3_wgs = 0;                     // lcgan_set_option(2, ...): 0 = cost-
 int g_halo_min_wgs = 128;                 // lcgan_set_option(6, ...): halo launches with fewer workgroups go to the split-K implicit GEMM
 int g_wgrad_slab_min = 4;                 // lcgan_set_option(8, ...): row-segment wgrad launches with at least this many splits reduce through a slab instead of atomics (0 = never)
 int g_halo_narrow_min_wgs = 256;          // lcgan_set_option(7, ...): narrow-layer halo kernel (Cout <= 64, 32 x 32 tiles) from this many workgroups; 0 = never
+int g_wgrad3_pack = 1;                    // lcgan_set_option(9, ...): packed channel groups in the row-segment wgrad kernel for layers with <= 64 channels
 int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): experiments, bit mask (the wgrad3 no-atomics switch is gone: it sat in the epilogue);
                                           // halo kernel: 8 = linear tile order (the store / emit / main-loop skipping switches used for the
                                           // fixed-cost analysis in DESIGN.md were removed again: they sat in the hot epilogue)
@@ -1042,8 +1043,15 @@ __device__ __forceinline__ bf16x8 tr_frag_rows(const __bf16* tile, int row_a, in
 
 // SEG   = positions per chunk (64 or 32) = ROWS image rows x SEGW columns (SEGW = min(SEG, grid width): narrow layers take
 //         several rows per chunk);   NKX = 3 (3x3 kernel: one kernel row per workgroup) or 1 (1x1 kernel)
-template <int STRIDE, int SEG, int SEGW, int NKX>
+// PK > 1 (narrow layers, <= 128 / PK channels on both sides: the C = 32 / 64 octaves of the high-resolution networks): the 128
+// staged columns hold PK GROUPS of channels, group g carrying image row row0 + g, so one chunk moves PK x 64 positions through
+// the same staging / barrier / fragment pipeline (its cost per chunk does not depend on how many columns are real: the 32 -> 32
+// layer at 1024 x 1024 took 4.9 ms for 0.9 ms worth of HBM traffic).  The 128 x 128 product then holds PK x PK blocks of which
+// only the diagonal ones (same rows on both sides) are weight-gradient terms; they are summed by the epilogue's atomics.
+template <int STRIDE, int SEG, int SEGW, int NKX, int PK>
 __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
+  static_assert(PK == 1 || (SEG == 64 && SEGW == 64), "packed groups: one image row per group");
+  constexpr int CG = 128 / PK, VG = 16 / PK;                 // channels / 8-channel vectors per group
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PAD = NKX == 3 ? 1 : 0;
   constexpr int ROWS = SEG / SEGW;                           // image rows per chunk
@@ -1061,7 +1069,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
   // so the 2nd and 3rd reads are served by the Infinity Cache instead of HBM
   const int split = blockIdx.z / NKX, ky = blockIdx.z - split * NKX;
   const int segs = a.Wm / SEGW;                              // segments per image row (1 for narrow layers)
-  const int rgroups = a.Hm / ROWS;                           // row groups per sample
+  const int rgroups = a.Hm / (ROWS * PK);                    // row groups per sample
   // split = (group, part).  With per-sample style / demod scales a group is ONE sample, so the scales can be applied once to
   // the fp32 accumulator in the epilogue instead of to every staged operand vector; without scales (discriminator convs) the
   // whole batch is one group and a workgroup's chunk range may span samples (low-resolution layers: few chunks per sample).
@@ -1073,18 +1081,19 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
   const __bf16* __restrict__ x = (const __bf16*)a.x;
   const __bf16* __restrict__ g = (const __bf16*)a.g;
   const int lpos = tid >> 4, lvec = tid & 15;
-  const bool ga_ok = a0 + lvec * 8 < a.Cg, xc_ok = c0 + lvec * 8 < a.Cx;
+  const int lgrp = PK == 1 ? 0 : lvec / VG, cvec = PK == 1 ? lvec : lvec - lgrp * VG;   // this thread's group (image row) and vector in it
+  const bool ga_ok = a0 + cvec * 8 < a.Cg, xc_ok = c0 + cvec * 8 < a.Cx;
 
   struct Stage { bf16x8 g[NG]; bf16x8 x[NX]; };
 
   auto gload = [&](int q, Stage& st) {
     const int seg = q % segs, t = q / segs;
-    const int row0 = (t % rgroups) * ROWS, b = t / rgroups, j0 = seg * SEGW;
+    const int row0 = (t % rgroups) * ROWS * PK + lgrp, b = t / rgroups, j0 = seg * SEGW;
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
       const int p = lpos + 32 * i;                           // position in the chunk
       const int pr = p / SEGW, pc = p - pr * SEGW;
-      st.g[i] = ga_ok ? *(const bf16x8*)(g + ((size_t)(b * a.Hm + row0 + pr) * a.Wm + j0 + pc) * a.Cg + a0 + lvec * 8) : zero_bf16x8();
+      st.g[i] = ga_ok ? *(const bf16x8*)(g + ((size_t)(b * a.Hm + row0 + pr) * a.Wm + j0 + pc) * a.Cg + a0 + cvec * 8) : zero_bf16x8();
     }
     const int xx0 = j0 * STRIDE - PAD;
 #pragma unroll
@@ -1093,7 +1102,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
       const int hr = r / XW, hc = r - hr * XW;
       const int yy = (row0 + hr) * STRIDE + ky - PAD, xx = xx0 + hc;
       const bool ok = r < XR && xc_ok && (unsigned)yy < (unsigned)a.Hx && (unsigned)xx < (unsigned)a.Wx;
-      st.x[k] = ok ? *(const bf16x8*)(x + ((size_t)(b * a.Hx + yy) * a.Wx + xx) * a.Cx + c0 + lvec * 8) : zero_bf16x8();
+      st.x[k] = ok ? *(const bf16x8*)(x + ((size_t)(b * a.Hx + yy) * a.Wx + xx) * a.Cx + c0 + cvec * 8) : zero_bf16x8();
     }
   };
   auto sstore = [&](int buf, const Stage& st) {
@@ -1164,11 +1173,14 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
   for (int kx = 0; kx < NKX; ++kx)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      const int cc = c0 + wn * 32 + (lane & 31);
+      // packed groups: only the diagonal (group, group) blocks are weight-gradient terms; columns fold back to channel indices
+      if (PK > 1 && (wm * 64 + mi * 32) / CG != (wn * 32) / CG) continue;
+      const int cc = PK == 1 ? c0 + wn * 32 + (lane & 31) : (wn * 32) % CG + (lane & 31);
       const float sxv = (a.pre_x && cc < a.Cx) ? a.pre_x[(size_t)bsmp * a.Cx + cc] : 1.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int aa = a0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int arow = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int aa = PK == 1 ? a0 + wm * 64 + arow : (wm * 64 + arow) % CG;
         if (aa < a.A && cc < a.Bc) {
           const float sgv = a.pre_g ? a.pre_g[(size_t)bsmp * a.Cg + aa] : 1.f;
           const size_t off = ((size_t)(ky * NKX + kx) * a.A + aa) * a.Bc + cc;
@@ -1392,6 +1404,7 @@ int lcgan_set_option(int option, int value) {
   if (option == 6) { const int old = g_halo_min_wgs; g_halo_min_wgs = value; return old; }
   if (option == 7) { const int old = g_halo_narrow_min_wgs; g_halo_narrow_min_wgs = value; return old; }
   if (option == 8) { const int old = g_wgrad_slab_min; g_wgrad_slab_min = value; return old; }
+  if (option == 9) { const int old = g_wgrad3_pack; g_wgrad3_pack = value; return old; }
   return LCGAN_EINVAL;
 }
 
@@ -1552,7 +1565,9 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
     const int tiles3 = cdiv(A, 128) * cdiv(Bc, 128) * nkx;
     const bool scaled = pre_x || pre_g;
     const int groups = scaled ? B : 1;
-    const int cps = (Hg / rows) * (Wg / segw) * (scaled ? 1 : B);   // chunks per group
+    // packed groups for narrow layers (see the kernel): PK image rows share one chunk when both sides have <= 128 / PK channels
+    const int pk = (g_wgrad3_pack && segw == 64 && k == 3) ? ((Cg <= 32 && Cx <= 32 && (Hg & 3) == 0) ? 4 : (Cg <= 64 && Cx <= 64 && (Hg & 1) == 0) ? 2 : 1) : 1;
+    const int cps = (Hg / (rows * pk)) * (Wg / segw) * (scaled ? 1 : B);   // chunks per group
     a.cps_group = cps;
     a.nchunks = groups * cps;
     const int xw = segw * stride + (k == 3 ? 2 : 0);
@@ -1572,7 +1587,7 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
       for (int pt = 1; pt <= max_parts; ++pt) {
         const int cpsplit = cdiv(cps, pt), real_parts = cdiv(cps, cpsplit);
         const long long rounds = ((long long)tiles3 * groups * real_parts + 256 * occ - 1) / (256 * occ);
-        const double cost = (double)rounds * (1024.0 + (double)cpsplit * seg);
+        const double cost = (double)rounds * (1024.0 + (double)cpsplit * seg);   // (a packed chunk costs what a plain one does)
         if (cost < best) { best = cost; parts = real_parts; }
       }
     }
@@ -1584,17 +1599,25 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
     const size_t slab_bytes = (size_t)a.nsplit * k * k * A * Bc * sizeof(float);
     // (measured per layer shape with scripts/ab_conv.py: -17 % at 16x16, -6 % at 32x32, -3..-7 % on the stride-2 layers, neutral at
     // 64x64 and 256x256, +3 % at 128x128 stride 1: the atomics of the big stride-1 layers hide under other workgroups' compute)
-    if (g_wgrad_slab_min > 0 && a.nsplit >= g_wgrad_slab_min && slab_bytes <= ((size_t)1 << 30) && (Hg * Wg <= 4096 || stride == 2 || g_wgrad_slab_min == 1))
-      a.slab = wgrad_slab_scratch(slab_bytes);
+    if (pk == 1 && g_wgrad_slab_min > 0 && a.nsplit >= g_wgrad_slab_min && slab_bytes <= ((size_t)1 << 30) && (Hg * Wg <= 4096 || stride == 2 || g_wgrad_slab_min == 1))
+      a.slab = wgrad_slab_scratch(slab_bytes);                    // (packed groups: several waves add into one element -> atomics only)
     dim3 grid3(cdiv(A, 128), cdiv(Bc, 128), nkx * a.nsplit);
 #define LAUNCH_WG3(ST, SG, SW, NK)                                                                                      \
     {                                                                                                                   \
       static bool set = false;                                                                                          \
-      if (!set) { hipFuncSetAttribute((const void*)conv_wgrad3_kernel<ST, SG, SW, NK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
-      hipLaunchKernelGGL((conv_wgrad3_kernel<ST, SG, SW, NK>), grid3, dim3(512), smem3, s, a);                          \
+      if (!set) { hipFuncSetAttribute((const void*)conv_wgrad3_kernel<ST, SG, SW, NK, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
+      hipLaunchKernelGGL((conv_wgrad3_kernel<ST, SG, SW, NK, 1>), grid3, dim3(512), smem3, s, a);                       \
+    }
+#define LAUNCH_WG3_PK(ST, PKK)                                                                                          \
+    {                                                                                                                   \
+      static bool set = false;                                                                                          \
+      if (!set) { hipFuncSetAttribute((const void*)conv_wgrad3_kernel<ST, 64, 64, 3, PKK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
+      hipLaunchKernelGGL((conv_wgrad3_kernel<ST, 64, 64, 3, PKK>), grid3, dim3(512), smem3, s, a);                      \
     }
 #define LAUNCH_WG3_K(ST, SG, SW) { if (k == 3) LAUNCH_WG3(ST, SG, SW, 3) else LAUNCH_WG3(ST, SG, SW, 1) }
-    if (stride == 1) {
+    if (pk == 4) { if (stride == 1) LAUNCH_WG3_PK(1, 4) else LAUNCH_WG3_PK(2, 4) }
+    else if (pk == 2) { if (stride == 1) LAUNCH_WG3_PK(1, 2) else LAUNCH_WG3_PK(2, 2) }
+    else if (stride == 1) {
       if (segw == 64) LAUNCH_WG3_K(1, 64, 64) else if (segw == 32) LAUNCH_WG3_K(1, 32, 32)
       else if (segw == 16) LAUNCH_WG3_K(1, 32, 16) else LAUNCH_WG3_K(1, 32, 8)
     } else {
@@ -1603,6 +1626,7 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
     }
 #undef LAUNCH_WG3_K
 #undef LAUNCH_WG3
+#undef LAUNCH_WG3_PK
     if (a.slab) {
       const int total = k * k * A * Bc;
       hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, a.slab, gwp, total, a.nsplit);

@@ -207,7 +207,10 @@ def test_conv_narrow_layers(H, case):
                                   (2, 32, 32, 256, 128, 3, 1),
                                   # narrow layers (several image rows per chunk) and 1x1 kernels on the row-segment kernel
                                   (3, 16, 16, 128, 96, 3, 1), (2, 8, 8, 64, 128, 3, 1), (2, 32, 32, 64, 40, 3, 2), (2, 16, 16, 72, 64, 3, 2),
-                                  (2, 64, 64, 128, 256, 1, 1), (2, 16, 16, 256, 128, 1, 1), (1, 128, 128, 64, 32, 1, 1)])
+                                  (2, 64, 64, 128, 256, 1, 1), (2, 16, 16, 256, 128, 1, 1), (1, 128, 128, 64, 32, 1, 1),
+                                  # <= 64 channels on both sides, 64-wide rows: packed channel groups (4 or 2 image rows per chunk)
+                                  (1, 64, 64, 32, 32, 3, 1), (2, 64, 128, 24, 16, 3, 1), (1, 64, 64, 64, 48, 3, 1), (1, 128, 128, 32, 32, 3, 2),
+                                  (2, 128, 128, 40, 64, 3, 2)])
 def test_conv_wgrad(H, dtype, case):
     B, Hh, W, Ci, Co, k, stride = case
     x = feat((B, Hh, W, ceil8(Ci)), dtype, 21, Ci)
