@@ -1,7 +1,7 @@
 """GPU diagnostic: run a G step with every kernel call executed by BOTH the HIP library and the CPU emulation on the same
 inputs; print the calls whose outputs differ."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import lcgan_amd.kernels as KM
 from lcgan_amd import config

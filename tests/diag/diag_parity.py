@@ -1,6 +1,6 @@
 """GPU diagnostic: per-parameter gradient error of the HIP path (f32 parity mode) against the CPU oracle."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from lcgan_amd import config
 from oracle import lcgan_ref as O

@@ -1,6 +1,6 @@
 """GPU diagnostic: run-to-run repeatability of the discriminator forward and of d(sum logit)/d(image), per block."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from lcgan_amd import config
 from tests.helpers import seeded_worker
