@@ -105,7 +105,7 @@ def main():
             dist.init_process_group(backend)
 
     from lcgan_amd import config, kernels, loader, worker
-    from tests.helpers import make_args
+    from lcgan_amd.config import default_args as make_args
     config.set_feature_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
     assert kernels.backend_name() == "hip"
     extra = dict(freezeD_start=0, freezeD_layer=a.freezeD_layer) if a.freezeD_layer >= 0 else {}

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.utils._python_dispatch import TorchDispatchMode
 from lcgan_amd import config, loader, worker
-from tests.helpers import make_args
+from lcgan_amd.config import default_args as make_args
 config.set_feature_dtype(torch.bfloat16)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 args = make_args(256, B)

@@ -3,7 +3,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lcgan_amd import config, loader, worker
-from tests.helpers import make_args
+from lcgan_amd.config import default_args as make_args
 config.set_feature_dtype(torch.bfloat16)
 for res, B, kw in ((512, 2, {}), (1024, 2, dict(freezeD_start=0, freezeD_layer=5, g_lr=0.001, d_lr=0.001))):
     torch.manual_seed(0)

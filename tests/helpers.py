@@ -1,6 +1,5 @@
 """Shared test helpers: argument namespaces, seeded worker construction, golden-vector comparison."""
 import os
-import types
 
 import numpy as np
 import torch
@@ -11,16 +10,7 @@ from oracle.weights import seeded_state, seeded_tensor
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def make_args(res=32, batch=8, **kw):
-    a = types.SimpleNamespace(
-        phase="train", img_resolution=res, batch_size=batch, geo_latent_dim=64, app_latent_dim=512, geo_noise_dim=64,
-        app_noise_dim=64, max_flow_scale=0.1, geo_projection_dim=256, app_projection_dim=256, tau=0.05, l_adv=1.0, l_aux=0.5,
-        l_r1=10.0, l_s=1e-7, g_lr=0.002, d_lr=0.002, beta1=0.0, beta2=0.99, g_ema_decay=0.9999, g_ema_start=0,
-        freezeD_start=100000, freezeD_layer=5, dataset_path="synthetic", model_name="", save_dir="model", sample_dir="samples",
-        best=False, epoch=1, print_interval=100, save_interval=5000, show_interval=1000)
-    for k, v in kw.items():
-        setattr(a, k, v)
-    return a
+from lcgan_amd.config import default_args as make_args  # noqa: E402,F401  (one definition: the product's defaults)
 
 
 class FixedFeed:
