@@ -35,7 +35,7 @@ int g_wgrad3_small = 0;                   // lcgan_set_option(5, ...): row-segme
 int g_wgrad3_wgs = 0;                     // lcgan_set_option(2, ...): 0 = cost-model split of the row-segment wgrad kernel, > 0 = explicit workgroup target
 int g_halo_min_wgs = 128;                 // lcgan_set_option(6, ...): halo launches with fewer workgroups go to the split-K implicit GEMM
 int g_wgrad_slab_min = 4;                 // lcgan_set_option(8, ...): row-segment wgrad launches with at least this many splits reduce through a slab instead of atomics (0 = never)
-int g_halo_narrow_min_wgs = 256;          // lcgan_set_option(7, ...): narrow-layer halo kernel (Cout <= 64, 32 x 32 tiles) from this many workgroups; 0 = never
+int g_halo_narrow_min_wgs = 256;          // lcgan_set_option(7, ...): narrow-layer halo kernel (Cout <= 64, 16 x 32 tiles) from this many workgroups; 0 = never
 int g_wgrad3_pack = 1;                    // lcgan_set_option(9, ...): packed channel groups in the row-segment wgrad kernel for layers with <= 64 channels
 int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): experiments, bit mask (the wgrad3 no-atomics switch is gone: it sat in the epilogue);
                                           // halo kernel: 8 = linear tile order (the store / emit / main-loop skipping switches used for the
