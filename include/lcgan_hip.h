@@ -156,6 +156,15 @@ int lcgan_prof_enable(int on);
 int lcgan_prof_collect(double* out_ms, double* out_flops, double* out_bytes, long long* out_count);
 int lcgan_prof_active(void);
 
+/* ---- device-side training views (the data step in front of the hot path) ---------------------------------------------
+ * replaces custom_dataset.py:59-88 (h-flip :68, albumentations Perspective :22-23,27-33, CoarseDropout :24 / ColorJitter :19-21,
+ * normalisation :81-86), which the reference runs on the host in DataLoader workers (worker.py:37,62-69).
+ * src: f32 [B][3][R][R] in [-1,1] (the resized image); params: f32 [B][32], one row of host-drawn randomness per sample
+ * (layout: lcgan_amd/csrc/views.hip); outputs f32 [B][3][R][R]: the flipped image, its perspective view (bilinear, black
+ * border) and its appearance view (one black rectangle, or brightness / contrast / saturation / hue jitter). */
+int lcgan_make_views(const float* src, const float* params, float* out_img, float* out_geo, float* out_app,
+                     int B, int R, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,7 @@ SIGNATURES = {
     "lcgan_qr_householder": [P, P, P, I, I, P],
     "lcgan_avg_latent": [P, P, I, I, F, P],
     "lcgan_multi_tensor": [P, P, P, I, I, F, F, F, D, P],
+    "lcgan_make_views": [P, P, P, P, P, I, I, P],
     "lcgan_set_option": [I, I],
     "lcgan_prof_enable": [I],
     "lcgan_prof_collect": [P, P, P, P],
@@ -75,10 +76,10 @@ def load(build_if_missing: bool = True):
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    from . import build as _build
+    if _build._stale():                      # missing, or built from other sources than the ones on disk (content hash)
         if not build_if_missing:
-            raise RuntimeError(f"{LIB_PATH} is missing (run `python -m lcgan_amd.build`); there is no CPU fallback")
-        from . import build as _build
+            raise RuntimeError(f"{LIB_PATH} is missing or stale (run `python -m lcgan_amd.build`); there is no CPU fallback")
         try:
             _build.build(verbose=False)
         except Exception as e:  # noqa: BLE001

@@ -8,22 +8,42 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblcgan_hip.so")
-SOURCES = ["conv_igemm.hip", "stencil.hip", "small.hip", "prof.hip"]
+SOURCES = ["conv_igemm.hip", "stencil.hip", "small.hip", "views.hip", "prof.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-Wno-unused-value"]
 
 
+STAMP = LIB + ".srchash"      # content hash of the sources the library was built from (travels with the .so; mtimes do not survive a copy)
+
+
+def source_hash() -> str:
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def _stale() -> bool:
-    if not os.path.exists(LIB):
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not _stale():
-        return LIB
+    import fcntl
+    with open(LIB + ".lock", "w") as lock:           # ranks of one node may reach this together: one builds, the others wait
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():
+            return LIB
+        return _build_locked(verbose)
+
+
+def _build_locked(verbose: bool) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    digest = source_hash()
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
@@ -36,6 +56,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(digest)
     return LIB
 
 

@@ -1,8 +1,8 @@
 """Tensor-level view of the C ABI (include/lcgan_hip.h): every method allocates its outputs with torch (device memory
 is plumbing), passes raw device pointers + the current HIP stream to liblcgan_hip.so and returns the outputs.
 
-`K` is the active backend.  The product only ever uses `HipKernels`; tests may install a CPU emulation of the same
-interface with `set_backend()` to exercise the host-side autograd wiring without a GPU.
+`K` resolves to `HipKernels` on first use; there is no other backend in the product (tests/helpers.py:install_backend swaps the
+object behind `K` for a CPU emulation of the same interface to exercise the host-side autograd wiring without a GPU).
 """
 from __future__ import annotations
 
@@ -541,6 +541,17 @@ class HipKernels:
         B, Dd = w.shape
         self._call("lcgan_avg_latent", w.data_ptr(), avg.data_ptr(), B, Dd, float(beta), self._stream())
 
+    # ---- training views ---------------------------------------------------------------------------------------------
+    def make_views(self, src: Tensor, params: Tensor):
+        """src f32 [B,3,R,R] in [-1,1], params f32 [B,32] (lcgan_amd.data.sample_view_params) -> (image, geometry_change, appearance_change)"""
+        self._chk(src, params)
+        B, _, R, _ = src.shape
+        assert src.dtype == torch.float32 and params.dtype == torch.float32 and params.shape == (B, 32) and src.shape[1] == 3
+        outs = [torch.empty_like(src) for _ in range(3)]
+        self._call("lcgan_make_views", src.data_ptr(), params.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
+                   B, R, self._stream())
+        return tuple(outs)
+
     # ---- multi-tensor -----------------------------------------------------------------------------------------------
     def multi_tensor(self, table, op: int, a0: float, a1: float = 0.0, a2: float = 0.0) -> None:
         """table: lcgan_amd.optim.TensorTable (device descriptor + chunk arrays)."""
@@ -574,11 +585,6 @@ class _Lazy:
 
 
 K = _Lazy()
-
-
-def set_backend(impl) -> None:
-    """Test hook: install another implementation of the HipKernels interface (None restores the HIP library)."""
-    _Lazy._impl = impl
 
 
 def backend_name() -> str:

@@ -43,9 +43,15 @@ def train_iteration(gan_worker, args, epoch):
 
 def load_worker(local_rank, args, gpus_per_node, port_number):
     multi_gpu_setup(local_rank, args, gpus_per_node, port_number)
+    if args.phase == "fake_image_generation":                             # loader.py:95-99
+        gan_worker = worker.WORKER(args, local_rank, gpus_per_node)
+        gan_worker.load_model()
+        _barrier(gan_worker)
+        gan_worker.fake_image_generation(num_images=args.num_fakes)
+        return
     if args.phase != "train":
-        raise NotImplementedError(f"phase {args.phase!r}: evaluation / visualisation tooling is outside the accelerated path "
-                                  "(SURVEY.md section 2); checkpoints are compatible with the reference's tools")
+        raise NotImplementedError(f"phase {args.phase!r}: FID (needs downloaded InceptionV3 weights) and the PyAV video tooling are "
+                                  "outside the accelerated path (SURVEY.md section 2); checkpoints are compatible with the reference's tools")
     with open(os.path.join(args.model_name, "args.txt"), "w") as f:
         json.dump(args.__dict__, f, indent=2)
     gan_worker = worker.WORKER(args, local_rank, gpus_per_node)

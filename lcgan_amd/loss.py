@@ -14,9 +14,11 @@ def contrastive_loss(anchor, p_sample, n_sample, tau):
 
 
 def cal_derivative(inputs, outputs, device=None):
-    """reference loss.py:27-34 (create_graph=True: the backward graph itself runs on the HIP kernels)."""
-    return autograd.grad(outputs=outputs, inputs=inputs, grad_outputs=torch.ones_like(outputs),
-                         create_graph=True, retain_graph=True, only_inputs=True)[0]
+    """reference loss.py:27-34 (create_graph=True: the backward graph itself runs on the HIP kernels).  only_inputs=True: the
+    parameter gradients of this pass are never formed (ops.inputs_only)."""
+    with ops.inputs_only():
+        return autograd.grad(outputs=outputs, inputs=inputs, grad_outputs=torch.ones_like(outputs),
+                             create_graph=True, retain_graph=True, only_inputs=True)[0]
 
 
 def cal_r1_reg(adv_output, images, device=None):

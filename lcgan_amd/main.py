@@ -11,7 +11,7 @@ from . import loader
 
 # (flag, type, default, help) -- the reference's 34 flags, main.py:16-60
 _FLAGS = [
-    ("phase", str, "train", "train (other phases live in the reference's tooling)"),
+    ("phase", str, "train", "train | fake_image_generation"),
     ("tau", float, 0.05, "temperature of the contrastive loss"),
     ("l_adv", float, 1.0, "adversarial weight (parsed but unused, as in the reference)"),
     ("l_aux", float, 0.5, "weight of the auxiliary (contrastive) loss"),

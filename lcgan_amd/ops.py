@@ -31,6 +31,32 @@ def _need_lo(x: Tensor) -> bool:
     return x.dtype == torch.float32
 
 
+# ---- "inputs only" backward ---------------------------------------------------------------------------------------
+# autograd.grad(outputs, inputs=images, only_inputs=True) (loss.py:27-34 of the reference) asks for the image gradient only; ATen's
+# convolution_backward then skips the weight / bias gradients through its output_mask.  A Python autograd.Function only sees
+# needs_input_grad, which is fixed at forward time, so loss.cal_derivative raises this flag around its autograd.grad call and the
+# first-order backward of every parameterised node drops its (discarded) parameter gradients: one whole discriminator weight-gradient
+# pass per R1 iteration.  The graph from the data gradient to the WEIGHT (ConvTransposeFn / LinearTFn / RGBReduceFn take w as an
+# input) is untouched, so the second backward still reaches the parameters.  The autograd engine runs these backward()s on its own
+# device thread, hence a plain module global (autograd.grad blocks until they are done).
+_inputs_only = False
+
+
+class inputs_only:
+    def __enter__(self):
+        global _inputs_only
+        self.prev, _inputs_only = _inputs_only, True
+
+    def __exit__(self, *exc):
+        global _inputs_only
+        _inputs_only = self.prev
+
+
+def _wants(ctx, i: int) -> bool:
+    """does this backward owe a gradient for PARAMETER input i?"""
+    return ctx.needs_input_grad[i] and not _inputs_only
+
+
 # ---- prepared-weight cache -------------------------------------------------------------------------------------------
 # A conv weight is used several times per iteration (D runs 2-3 forwards and as many backwards between two optimiser
 # steps); its bf16 GEMM-layout copy only changes when the parameter does.  Valid for (parameter object, torch version counter,
@@ -156,13 +182,13 @@ class Conv2dFn(Function):
         k, stride, act, gain, wscale, bias_scale, has_bias, has_res = ctx.cfg
         gy = gy.contiguous()
         A = w.shape[0]
-        want_gb = has_bias and ctx.needs_input_grad[2]
+        want_gb = has_bias and _wants(ctx, 2)
         if act != ACT_NONE or want_gb:
             gz, gb = ActBwdFn.apply(gy, y, act, gain, A, want_gb, bias_scale)
         else:
             gz, gb = gy, None
         gx = ConvTransposeFn.apply(gz, w, k, stride, wscale, x.shape[-1], None) if ctx.needs_input_grad[0] else None
-        gw = ConvWeightGradFn.apply(x, gz, k, stride, wscale, w.shape[0], w.shape[1]) if ctx.needs_input_grad[1] else None
+        gw = ConvWeightGradFn.apply(x, gz, k, stride, wscale, w.shape[0], w.shape[1]) if _wants(ctx, 1) else None
         gres = gy if (has_res and ctx.needs_input_grad[3]) else None
         return gx, gw, (gb if want_gb else None), gres, None, None, None, None, None, None
 
@@ -213,7 +239,7 @@ class ConvPoolFn(Function):
         x, w, y = ctx.saved_tensors
         k, act, gain, wscale, bias_scale, has_bias, box = ctx.cfg
         A = w.shape[0]
-        want_gb = has_bias and ctx.needs_input_grad[2]
+        want_gb = has_bias and _wants(ctx, 2)
         if gy is None:                                                   # only the pooled branch was used
             gx = AvgPool2TFn.apply(gpooled.contiguous()) if ctx.needs_input_grad[0] else None
             return gx, None, None, None, None, None, None, None, None
@@ -230,7 +256,7 @@ class ConvPoolFn(Function):
         gx = None
         if ctx.needs_input_grad[0]:
             gx = ConvTransposeFn.apply(gz, w, k, 1, wscale, x.shape[-1], None if gpooled is None else gpooled.contiguous())
-        gw = ConvWeightGradFn.apply(x, gz, k, 1, wscale, w.shape[0], w.shape[1]) if ctx.needs_input_grad[1] else None
+        gw = ConvWeightGradFn.apply(x, gz, k, 1, wscale, w.shape[0], w.shape[1]) if _wants(ctx, 1) else None
         return gx, gw, (gb if want_gb else None), None, None, None, None, None, None
 
 
@@ -359,13 +385,13 @@ class RGBExpandFn(Function):
         img, wt, y = ctx.saved_tensors
         bias_scale, clog, act, gain, has_bias = ctx.cfg
         gy = gy.contiguous()
-        want_gb = has_bias and ctx.needs_input_grad[2]
+        want_gb = has_bias and _wants(ctx, 2)
         if act != ACT_NONE or want_gb:
             gz, gb = ActBwdFn.apply(gy, y, act, gain, clog, want_gb, bias_scale)
         else:
             gz, gb = gy, None
         gimg = RGBReduceFn.apply(gz, wt, None, 0.0) if ctx.needs_input_grad[0] else None
-        gwt = RGBWeightGradFn.apply(img, gz, wt.shape[0] > 1) if ctx.needs_input_grad[1] else None
+        gwt = RGBWeightGradFn.apply(img, gz, wt.shape[0] > 1) if _wants(ctx, 1) else None
         return gimg, gwt, (gb if want_gb else None), None, None, None, None, None
 
 
@@ -495,8 +521,8 @@ class LinearFn(Function):
         gy = gy.contiguous()
         gz = ActBwdF32Fn.apply(gy, y, act, gain) if act != ACT_NONE else (gy * gain if gain != 1.0 else gy)
         gx = LinearTFn.apply(gz, w, scale) if ctx.needs_input_grad[0] else None
-        gw = LinearWeightGradFn.apply(gz, x, scale) if ctx.needs_input_grad[1] else None
-        gb = _K().colsum(gz.detach().contiguous(), bias_scale) if (has_bias and ctx.needs_input_grad[2]) else None
+        gw = LinearWeightGradFn.apply(gz, x, scale) if _wants(ctx, 1) else None
+        gb = _K().colsum(gz.detach().contiguous(), bias_scale) if (has_bias and _wants(ctx, 2)) else None
         return gx, gw, gb, None, None, None, None
 
 

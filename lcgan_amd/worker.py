@@ -3,8 +3,10 @@
 Kept: class name, constructor signature, `train_generator` / `train_discriminator` / `ema_update` / `freeze_discriminator` /
 `requires_grad` / `save_model` / `load_model`, attribute names (`generator`, `discriminator`, `generator_ema`, `g_optimizer`,
 `d_optimizer`, `local_batch_size`), the order of random draws, loss assembly and the `module.`-prefixed checkpoints.
-Out of scope: the PIL/albumentations data pipeline, FID and video tooling -- `--dataset_path synthetic`
-feeds uniform [-1,1] tensors of the dataset's shape/range (custom_dataset.py:81-86); a real folder needs torchvision.
+Data: `--dataset_path synthetic` feeds uniform [-1,1] tensors of the dataset's shape/range (custom_dataset.py:81-86); any other
+path is an image folder `<path>/train/<class>/*` read with PIL on the host (lcgan_amd/data.py) whose geometry / appearance views are
+generated on the device.  Inference: `fake_image_generation` (worker.py:427-441).  Out of scope: FID and the
+PyAV video tooling.
 """
 from __future__ import annotations
 
@@ -19,87 +21,52 @@ from .ema import Ema
 from .optim import Adam, DataParallel
 
 
-class LazyLoss(float):
-    """What train_generator / train_discriminator return: a float whose value is fetched from the device ON DEMAND.
-    The reference calls `.item()` right after the optimiser step (worker.py:177, 214), which drains the GPU queue twice per
-    iteration; here the scalar is copied asynchronously into pinned memory and `float()` / formatting waits for that copy only
-    when somebody looks (log lines every print_interval).  Behaves as a float in arithmetic and formatting."""
+class LazyLoss:
+    """What train_generator / train_discriminator return: a handle on the loss scalar whose value is fetched from the device ON
+    DEMAND.  The reference calls `.item()` right after the optimiser step (worker.py:177, 214), which drains the GPU queue twice
+    per iteration; here the scalar is copied asynchronously into pinned memory and `float()` / `.item()` / formatting / arithmetic
+    wait for that copy only when somebody looks (log lines every print_interval).  Deliberately NOT a float subclass: C-level
+    consumers (math.isnan, json, numpy) go through __float__ and get the real value, never a placeholder."""
+    __slots__ = ("_host", "_event")
 
-    def __new__(cls, tensor):
-        obj = super().__new__(cls, float("nan"))
+    def __init__(self, tensor):
         if tensor.is_cuda:
-            obj._host = torch.empty((), dtype=torch.float32, pin_memory=True)
-            obj._host.copy_(tensor.detach(), non_blocking=True)
-            obj._event = torch.cuda.Event()
-            obj._event.record()
+            self._host = torch.empty((), dtype=torch.float32, pin_memory=True)
+            self._host.copy_(tensor.detach(), non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
         else:
-            obj._host, obj._event = tensor.detach().float().clone(), None
-        return obj
-
-    def _value(self):
-        if self._event is not None:
-            self._event.synchronize()
-        return float(self._host)
+            self._host, self._event = tensor.detach().float().clone(), None
 
     def __float__(self):
-        return self._value()
+        if self._event is not None:
+            self._event.synchronize()
+            self._event = None
+        return float(self._host)
 
-    def item(self):
-        return self._value()
+    item = __float__
 
     def __format__(self, spec):
-        return format(self._value(), spec)
+        return format(float(self), spec)
 
     def __repr__(self):
-        return repr(self._value())
-
-    __str__ = __repr__
-
-    def __eq__(self, o):
-        return self._value() == float(o)
-
-    def __ne__(self, o):
-        return self._value() != float(o)
+        return repr(float(self))
 
     def __hash__(self):
-        return hash(self._value())
+        return hash(float(self))
 
-    def __lt__(self, o):
-        return self._value() < float(o)
+    def __array__(self, dtype=None, copy=None):
+        import numpy as np
+        return np.asarray(float(self), dtype=dtype)
 
-    def __gt__(self, o):
-        return self._value() > float(o)
 
-    def __le__(self, o):
-        return self._value() <= float(o)
+def _delegate(name):
+    op = getattr(float, name)
+    return lambda self, *o: op(float(self), *(float(v) for v in o))
 
-    def __ge__(self, o):
-        return self._value() >= float(o)
 
-    def __abs__(self):
-        return abs(self._value())
-
-    def __add__(self, o):
-        return self._value() + float(o)
-
-    __radd__ = __add__
-
-    def __sub__(self, o):
-        return self._value() - float(o)
-
-    def __rsub__(self, o):
-        return float(o) - self._value()
-
-    def __mul__(self, o):
-        return self._value() * float(o)
-
-    __rmul__ = __mul__
-
-    def __truediv__(self, o):
-        return self._value() / float(o)
-
-    def __rtruediv__(self, o):
-        return float(o) / self._value()
+for _n in ("eq", "ne", "lt", "le", "gt", "ge", "add", "radd", "sub", "rsub", "mul", "rmul", "truediv", "rtruediv", "neg", "abs"):
+    setattr(LazyLoss, f"__{_n}__", _delegate(f"__{_n}__"))
 
 
 class SyntheticTriples:
@@ -161,8 +128,9 @@ class WORKER(object):
         path = str(getattr(self.args, "dataset_path", "synthetic"))
         if path.startswith("synthetic"):
             return SyntheticTriples(self.local_batch_size, self.args.img_resolution, self.device, seed=1234 + self.local_rank)
-        raise NotImplementedError("the image-folder pipeline (custom_dataset.py) is outside the accelerated hot path; "
-                                  "run with --dataset_path synthetic")
+        from .data import FolderTriples                                            # custom_dataset.py:10-100, worker.py:44-73
+        return FolderTriples(path, self.args.img_resolution, self.local_batch_size, self.device, rank=self.local_rank,
+                             world=self.gpus_per_node, train=getattr(self.args, "phase", "train") == "train")
 
     def sample_data_basket(self):
         return self.data.next()
@@ -276,21 +244,46 @@ class WORKER(object):
     def _paths(self, best=False):
         d = os.path.join(self.args.model_name, self.args.save_dir)
         sfx = "_best" if best else ""
-        return (f"{d}/gen_model{sfx}.ckpt", f"{d}/gen_ema_model{sfx}.ckpt", f"{d}/disc_model{sfx}.ckpt")
+        return (f"{d}/gen_model{sfx}.ckpt", f"{d}/gen_ema_model{sfx}.ckpt", f"{d}/disc_model{sfx}.ckpt", f"{d}/optim_state{sfx}.ckpt")
 
     def save_model(self, best=False):
         self.flush()
-        g, e, d = self._paths(best)
+        g, e, d, o = self._paths(best)
         torch.save(self.generator.state_dict(), g)
         torch.save(self.generator_ema.state_dict(), e)
         torch.save(self.discriminator.state_dict(), d)
+        # not in the reference (its Adam moments restart from zero on resume, worker.py:239-253): an extra file its tools ignore
+        torch.save({"g": self.g_optimizer.state_dict(), "d": self.d_optimizer.state_dict()}, o)
 
     def save_best_model(self):
         self.save_model(best=True)
 
     def load_model(self):
         self.flush()
-        g, e, d = self._paths(bool(getattr(self.args, "best", False)))
+        g, e, d, o = self._paths(bool(getattr(self.args, "best", False)))
         self.generator.load_state_dict(torch.load(g, map_location=self.device))
         self.generator_ema.load_state_dict(torch.load(e, map_location=self.device))
         self.discriminator.load_state_dict(torch.load(d, map_location=self.device))
+        from . import ops
+        ops.bump_weight_epoch()                    # load_state_dict copies in place: every prepared weight is stale
+        if os.path.exists(o):                      # a checkpoint written by the reference has none: moments start at zero, as there
+            st = torch.load(o, map_location=self.device)
+            self.g_optimizer.load_state_dict(st["g"])
+            self.d_optimizer.load_state_dict(st["d"])
+
+    # ---- inference (worker.py:427-441) ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, geometry_code, appearance_code, w_psi=None):
+        """generator_ema(geo, app, w_psi) under no_grad (worker.py:277-281, 406, 433, 462): forward only -- no autograd graph, so
+        no activation is kept beyond its consumer."""
+        return self.generator_ema(geometry_code, appearance_code, float(self.args.w_psi if w_psi is None else w_psi))
+
+    def fake_image_generation(self, num_images=50):
+        """worker.py:427-441: `num_images` files, each the local batch stacked in one column (save_image(nrow=1, padding=0))."""
+        from .data import save_image_column
+        folder = os.path.join(self.args.model_name, "fakes")
+        os.makedirs(folder, exist_ok=True)
+        for count in range(num_images):
+            fake = self.generate(self._randn(self.args.geo_noise_dim), self._randn(self.args.app_noise_dim))
+            fake = ((fake + 1) / 2).clamp(0.0, 1.0)
+            save_image_column(fake, os.path.join(folder, "{num:04d}_images.jpg".format(num=count)))

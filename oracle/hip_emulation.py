@@ -2,7 +2,7 @@
 
 Each method restates, with plain torch fp32 ops (and torch autograd for the backward kernels), what the HIP kernel of
 the same name computes on the same NHWC operands.  Uses:
-  * CPU tests install it with `lcgan_amd.kernels.set_backend()` to check the host-side autograd wiring (ops.py,
+  * CPU tests install it with `tests/helpers.py:install_backend()` to check the host-side autograd wiring (ops.py,
     custom_layers.py, cnn.py, worker.py) against the oracle without a GPU;
   * GPU tests call the HIP kernel and this emulation on identical inputs (per-kernel parity).
 Only tests may import this module.
@@ -53,6 +53,26 @@ def act_grad_from_out(y, act, gain):
 def rb(x, like_dtype):
     """round to the feature dtype the HIP kernel stages operands in (bf16 mode rounds, f32 mode keeps ~fp32)"""
     return x.to(torch.bfloat16).float() if like_dtype == torch.bfloat16 else x
+
+
+def _hue_shift(r, g, b, shift):
+    """RGB -> HSV, h += shift (mod 1), -> RGB; the same sector arithmetic as csrc/views.hip:hue_shift"""
+    mx, mn = torch.maximum(r, torch.maximum(g, b)), torch.minimum(r, torch.minimum(g, b))
+    d = mx - mn
+    safe = torch.where(d > 0, d, torch.ones_like(d))
+    h = torch.where(mx == r, (g - b) / safe, torch.where(mx == g, 2 + (b - r) / safe, 4 + (r - g) / safe)) / 6
+    h = torch.where(d > 0, h - torch.floor(h), torch.zeros_like(h))
+    s = torch.where(mx > 0, d / torch.where(mx > 0, mx, torch.ones_like(mx)), torch.zeros_like(mx))
+    v = mx
+    h = h + shift
+    h = h - torch.floor(h)
+    h6 = h * 6
+    fi = torch.floor(h6)
+    f = h6 - fi
+    i = fi.long() % 6
+    p, q, t = v * (1 - s), v * (1 - s * f), v * (1 - s * (1 - f))
+    sel = lambda opts: sum(torch.where(i == k, o, torch.zeros_like(o)) for k, o in enumerate(opts))
+    return sel([v, q, p, p, t, v]), sel([t, v, v, q, p, p]), sel([p, p, t, v, v, q])
 
 
 class EmuWeight:
@@ -366,6 +386,50 @@ class EmulatedKernels:
     def avg_latent(self, w, avg, beta):
         m = w.mean(0)
         avg.copy_(m + beta * (avg - m))
+
+    # ---- training views (csrc/views.hip; custom_dataset.py:59-88) ---------------------------------------------------------
+    def make_views(self, src, params):
+        B, _, R, _ = src.shape
+        x01 = (src.float() + 1) * 0.5
+        outs = [torch.empty_like(src) for _ in range(3)]
+        ys, xs = torch.meshgrid(torch.arange(R, dtype=torch.float32), torch.arange(R, dtype=torch.float32), indexing="ij")
+        for b in range(B):
+            P = params[b].float()
+            img = x01[b].flip(-1) if P[0] != 0 else x01[b]
+            outs[0][b] = (img * 2 - 1).clamp(-1, 1)
+            w = P[7] * xs + P[8] * ys + P[9]
+            iw = torch.where(w.abs() > 1e-12, 1.0 / w, torch.zeros_like(w))
+            sx, sy = (P[1] * xs + P[2] * ys + P[3]) * iw, (P[4] * xs + P[5] * ys + P[6]) * iw
+            far = ~((sx > -2) & (sy > -2) & (sx < R + 1) & (sy < R + 1))
+            fx, fy = torch.floor(sx), torch.floor(sy)
+            ax, ay = sx - fx, sy - fy
+            x0 = torch.where(far, torch.full_like(fx, -4), fx).long()
+            y0 = torch.where(far, torch.full_like(fy, -4), fy).long()
+
+            def fetch(yy, xx):
+                ok = (yy >= 0) & (yy < R) & (xx >= 0) & (xx < R)
+                v = img[:, yy.clamp(0, R - 1), xx.clamp(0, R - 1)]
+                return torch.where(ok.unsqueeze(0), v, torch.zeros_like(v))
+            g = (1 - ay) * ((1 - ax) * fetch(y0, x0) + ax * fetch(y0, x0 + 1)) + ay * ((1 - ax) * fetch(y0 + 1, x0) + ax * fetch(y0 + 1, x0 + 1))
+            outs[1][b] = (g * 2 - 1).clamp(-1, 1)
+            r, gch, bl = img[0].clone(), img[1].clone(), img[2].clone()
+            if P[10] == 0:
+                hole = (xs >= int(P[11])) & (xs < int(P[13])) & (ys >= int(P[12])) & (ys < int(P[14]))
+                r, gch, bl = (torch.where(hole, torch.zeros_like(c), c) for c in (r, gch, bl))
+            else:
+                for k in range(4):
+                    op = int(P[19 + k])
+                    if op == 0:
+                        r, gch, bl = ((c * P[15]).clamp(0, 1) for c in (r, gch, bl))
+                    elif op == 1:
+                        r, gch, bl = (((c - P[23]) * P[16] + P[23]).clamp(0, 1) for c in (r, gch, bl))
+                    elif op == 2:
+                        gr = 0.299 * r + 0.587 * gch + 0.114 * bl
+                        r, gch, bl = ((gr + (c - gr) * P[17]).clamp(0, 1) for c in (r, gch, bl))
+                    else:
+                        r, gch, bl = _hue_shift(r, gch, bl, float(P[18]))
+            outs[2][b] = torch.stack([r, gch, bl]) * 2 - 1
+        return tuple(outs)
 
     # ---- multi-tensor ---------------------------------------------------------------------------------------------------
     def multi_tensor(self, table, op, a0, a1=0.0, a2=0.0):

@@ -46,7 +46,7 @@ def sample(t: torch.Tensor, n: int = 257) -> np.ndarray:
 def summarize(prefix: str, t: torch.Tensor, d: dict):
     d[prefix + "/sample"] = sample(t)
     d[prefix + "/sum"] = np.float64(t.detach().double().sum().item())
-    st = grad_stats(t, prefix.split("/grad/")[-1])
+    st = grad_stats(t, prefix.split("/grad/")[-1].split("/r1grad/")[-1])        # projections are keyed by the PARAMETER name
     d[prefix + "/abssum"] = np.float64(st["abssum"])
     d[prefix + "/l2"] = np.float64(st["l2"])
     d[prefix + "/proj"] = st["proj"]
@@ -275,6 +275,15 @@ def step_fixtures(CNN, LOSS, res=32, B=8):
             if epoch % 8 == 1:
                 r1 = LOSS.cal_r1_reg(real_logit, image, "cpu")
                 d[f"{tag}/r1"] = r1.detach().numpy()
+                if not frozen:
+                    # the gradient of the R1 term ALONE (loss.py:18-34: the double backward through D): it is < 1 % of the D gradient,
+                    # so the full-step statistics below cannot pin it
+                    params = dict(D.named_parameters())
+                    gr1 = torch.autograd.grad(r1 * HP["l_r1"], list(params.values()), retain_graph=True, allow_unused=True)
+                    for (k, _), g in zip(params.items(), gr1):
+                        if g is not None:
+                            summarize(f"{tag}/r1grad/{k}", g, d)
+                    d[f"{tag}/r1grad_none"] = np.array([k for (k, _), g in zip(params.items(), gr1) if g is None] or [""])
                 loss = loss + r1 * HP["l_r1"]
         else:
             real_logit, gf, af = D(image, True)
@@ -299,20 +308,20 @@ def step_fixtures(CNN, LOSS, res=32, B=8):
     print(f"step_r{res}.npz", len(d), "arrays")
 
 
-def forward_fixtures(CNN, res=256, B=1):
-    """Whole-network forward at the benchmark resolution (cnn.py:33-43, 89-115)."""
-    d = {"res": np.int64(res), "B": np.int64(B)}
+def forward_fixtures(CNN, res=256, B=1, stride=16):
+    """Whole-network forward at the benchmark resolutions (cnn.py:33-43, 89-115): 256 (config 2), 512 (config 3), 1024 (config 4)."""
+    d = {"res": np.int64(res), "B": np.int64(B), "stride": np.int64(stride)}
     a = args_for(res)
     G, D = CNN.Generator(a), CNN.Discriminator(a)
     load(G, module_state(G, 1001)), load(D, module_state(D, 1002))
     z1, z2 = seeded_tensor((B, 64), 3000), seeded_tensor((B, 64), 3001)
     with torch.no_grad():
         img = G(z1, z2)
-        d["img/slice"] = img[:, :, ::16, ::16].numpy().copy()
+        d["img/slice"] = img[:, :, ::stride, ::stride].numpy().copy()
         d["img/sum"], d["img/abssum"] = np.float64(img.double().sum()), np.float64(img.double().abs().sum())
         d["avg_latent1"], d["avg_latent2"] = G.avg_latent1.numpy().copy(), G.avg_latent2.numpy().copy()
         img_t = G(z1, z2, 0.7)                                   # truncation branch, cnn.py:99-101
-        d["img_trunc/slice"] = img_t[:, :, ::16, ::16].numpy().copy()
+        d["img_trunc/slice"] = img_t[:, :, ::stride, ::stride].numpy().copy()
         real = seeded_tensor((B, 3, res, res), 3002, "uniform_pm1")
         logit, ge, ae = D(real, True)
         d["logit"], d["geo_emb"], d["app_emb"] = logit.numpy(), ge.numpy(), ae.numpy()
@@ -320,6 +329,29 @@ def forward_fixtures(CNN, res=256, B=1):
         d["logit_fake"] = logit_f.numpy()
     np.savez_compressed(os.path.join(OUT, f"forward_r{res}.npz"), **d)
     print(f"forward_r{res}.npz", len(d), "arrays")
+
+
+def freeze_fixtures(CNN, LOSS):
+    """Which discriminator parameters end an odd+R1 D step WITHOUT a gradient under the README's freezeD recipes (worker.py:127-131,
+    cnn.py:17,54; README.md:29,37,49): frozen layers + the projection heads that odd iterations do not evaluate (cnn.py:38).
+    One real-image pass at batch 1 is enough to see the set; the values are not stored."""
+    d = {}
+    for res, layer in ((256, 3), (512, 4), (1024, 5)):
+        D = CNN.Discriminator(args_for(res))
+        load(D, module_state(D, 1002))
+        for i, (_, m) in enumerate(D.shared_model.named_children()):
+            if i < layer + 2:
+                for p in m.parameters():
+                    p.requires_grad_(False)
+        image = seeded_tensor((1, 3, res, res), 2100, "uniform_pm1").requires_grad_(True)
+        logit, _, _ = D(image, False)
+        loss = F.binary_cross_entropy_with_logits(logit, torch.ones(1, 1)) + LOSS.cal_r1_reg(logit, image, "cpu") * HP["l_r1"]
+        loss.backward()
+        d[f"r{res}_layer{layer}/grad_none"] = np.array([k for k, p in D.named_parameters() if p.grad is None])
+        d[f"r{res}_layer{layer}/n_params"] = np.int64(len(list(D.parameters())))
+        d[f"r{res}_layer{layer}/frozen_numel"] = np.int64(sum(p.numel() for p in D.parameters() if not p.requires_grad))
+        print(f"freeze r{res} layer {layer}:", len(d[f"r{res}_layer{layer}/grad_none"]), "params without grad")
+    np.savez_compressed(os.path.join(OUT, "freeze_sets.npz"), **d)
 
 
 def main():
@@ -330,6 +362,9 @@ def main():
     layer_fixtures(CL, LOSS, EMA)
     step_fixtures(CNN, LOSS, res=32, B=8)
     forward_fixtures(CNN, res=256, B=1)
+    forward_fixtures(CNN, res=512, B=1, stride=32)
+    forward_fixtures(CNN, res=1024, B=1, stride=64)
+    freeze_fixtures(CNN, LOSS)
 
 
 if __name__ == "__main__":

@@ -7,7 +7,7 @@ import lcgan_amd.kernels as KM
 from lcgan_amd import config
 from lcgan_amd.kernels import HipKernels, PreparedWeight
 from oracle.hip_emulation import EmulatedKernels, EmuWeight
-from tests.helpers import FixedFeed, seeded_worker
+from tests.helpers import install_backend, FixedFeed, seeded_worker
 
 H, E = HipKernels(), EmulatedKernels()
 LOG = []
@@ -67,7 +67,7 @@ class Checked:
 
 res, B = int(sys.argv[1]), int(sys.argv[2])
 config.set_feature_dtype(torch.float32)
-KM.set_backend(Checked())
+install_backend(Checked())
 w = seeded_worker(res, B, "cuda:0")
 FixedFeed(w, B, res, "cuda:0")
 w.g_optimizer.step = lambda: None

@@ -20,11 +20,11 @@ def _rank_main(rank, world, port, out_dir):
     import lcgan_amd.kernels as KM
     from lcgan_amd import config
     from oracle.hip_emulation import EmulatedKernels
-    from tests.helpers import FixedFeed, seeded_worker
+    from tests.helpers import install_backend, FixedFeed, seeded_worker
     from oracle.weights import seeded_tensor
     torch.set_num_threads(2)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    KM.set_backend(EmulatedKernels())
+    install_backend(EmulatedKernels())
     config.set_feature_dtype(torch.float32)
     res, Bl = 16, 2
     w = seeded_worker(res, Bl, "cpu", gpus=world)
@@ -53,9 +53,9 @@ def _single(rank_seed_offsets, out):
     import lcgan_amd.kernels as KM
     from lcgan_amd import config
     from oracle.hip_emulation import EmulatedKernels
-    from tests.helpers import FixedFeed, seeded_worker
+    from tests.helpers import install_backend, FixedFeed, seeded_worker
     from oracle.weights import seeded_tensor
-    KM.set_backend(EmulatedKernels())
+    install_backend(EmulatedKernels())
     config.set_feature_dtype(torch.float32)
     res, Bl = 16, 2
     grads = []
@@ -68,7 +68,7 @@ def _single(rank_seed_offsets, out):
         w.d_optimizer.step = lambda: None
         w.train_discriminator(1)
         grads.append({k: (None if p.grad is None else p.grad.clone()) for k, p in w.discriminator.module.named_parameters()})
-    KM.set_backend(None)
+    install_backend(None)
     return grads
 
 
@@ -94,11 +94,11 @@ def _iter_main(rank, world, port, out_dir, defer):
     import lcgan_amd.kernels as KM
     from lcgan_amd import config, loader
     from oracle.hip_emulation import EmulatedKernels
-    from tests.helpers import FixedFeed, make_args, seeded_worker
+    from tests.helpers import install_backend, FixedFeed, make_args, seeded_worker
     from oracle.weights import seeded_tensor
     torch.set_num_threads(2)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    KM.set_backend(EmulatedKernels())
+    install_backend(EmulatedKernels())
     config.set_feature_dtype(torch.float32)
     res, Bl = 16, 2
     torch.manual_seed(0)                                      # the EMA copy starts from the (random) constructor weights

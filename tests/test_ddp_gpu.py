@@ -28,14 +28,19 @@ def _feed(w, Bl, res, dev, rank):
     return feed
 
 
-def _rank_main(rank, world, port, out_dir):
+def _rank_main(rank, world, port, out_dir, backend="gloo"):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from lcgan_amd import config
     from tests.helpers import seeded_worker
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    dev_index = rank if backend == "nccl" else 0                  # RCCL: one device per rank; gloo: both ranks on the one GPU
+    torch.cuda.set_device(dev_index)
+    if backend == "nccl":
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", dev_index))
+    else:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     config.set_feature_dtype(torch.float32)
-    res, Bl, dev = 32, 4, "cuda:0"
+    res, Bl, dev = 32, 4, f"cuda:{dev_index}"
     w = seeded_worker(res, Bl, dev, gpus=world)
     _feed(w, Bl, res, dev, rank)
     w.requires_grad(w.generator, True), w.requires_grad(w.discriminator, False)
@@ -82,3 +87,17 @@ def test_two_ranks_one_gpu(tmp_path):
         else:
             assert torch.equal(r0["params"][k], r1["params"][k]), k              # replicas in lock-step after Adam
     assert r0["loss"] != r1["loss"]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL path needs two devices (the test box has one)")
+def test_two_ranks_rccl(tmp_path):
+    """The same two-rank G step with backend "nccl" (= RCCL over xGMI), one device per rank: exercised the first time the test
+    box has two GPUs.  Both ranks must hold the identical reduced bucket and identical parameters after Adam."""
+    world, port = 2, _free_port()
+    mp.spawn(_rank_main, args=(world, port, str(tmp_path), "nccl"), nprocs=world, join=True)
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(world))
+    for k in r0["grads"]:
+        assert torch.equal(r0["grads"][k], r1["grads"][k]), k
+    for k in r0["params"]:
+        if not k.startswith("avg_latent"):
+            assert torch.equal(r0["params"][k], r1["params"][k]), k

@@ -257,17 +257,56 @@ def test_discriminator_step(S, epoch, frozen):
     _check_grads(S, tag, grads)
 
 
-def test_forward_256():
-    Fw = np.load(os.path.join(GOLD, "forward_r256.npz"))
-    res, B = int(Fw["res"]), int(Fw["B"])
+def test_r1_gradient_alone(S):
+    """The oracle's double backward (r1_penalty: loss.py:18-34) against the reference's gradient of l_r1 * r1 ALONE."""
+    from oracle.weights import grad_stats
+    res, B = int(S["res"]), int(S["B"])
+    DP = seeded_state(O.d_param_shapes(res), 1002)
+    D = {k: v.detach().clone().requires_grad_(True) for k, v in DP.items()}
+    image = seeded_tensor((B, 3, res, res), 2100, "uniform_pm1").requires_grad_(True)
+    logit, _, _ = O.discriminator_forward(D, image, res, False)
+    r1 = O.r1_penalty(logit, image)
+    close(r1, S["d1/r1"], what="r1")
+    (r1 * O.Hyper.l_r1).backward()
+    none_ref = set(S["d1/r1grad_none"]) - {""}
+    for k, v in D.items():
+        if k in none_ref:
+            assert v.grad is None, k
+            continue
+        ref_l2 = float(S[f"d1/r1grad/{k}/l2"])
+        if v.grad is None:
+            assert ref_l2 == 0.0, k
+            continue
+        st = grad_stats(v.grad, k)
+        err = max(abs(st["l2"] - ref_l2), float(np.abs(st["proj"] - S[f"d1/r1grad/{k}/proj"]).max())) / max(ref_l2, 1e-30)
+        assert (ref_l2 == 0.0 and st["l2"] == 0.0) or err <= 1e-3, (k, err)
+
+
+def test_freeze_sets_follow_the_recipes():
+    """tests/golden/freeze_sets.npz (captured from the reference under the README's freezeD recipes) against the oracle's key
+    inventory: frozen = shared_model.0 .. shared_model.<layer+1>, plus the projection heads an odd iteration never evaluates."""
+    FS = np.load(os.path.join(GOLD, "freeze_sets.npz"))
+    for res, layer in ((256, 3), (512, 4), (1024, 5)):
+        keys = list(O.d_param_shapes(res))
+        frozen = [k for k in keys if k.startswith(tuple(f"shared_model.{i}." for i in range(layer + 2)))]
+        heads = [k for k in keys if k.startswith("projection_header")]
+        assert sorted(FS[f"r{res}_layer{layer}/grad_none"]) == sorted(frozen + heads)
+        assert int(FS[f"r{res}_layer{layer}/frozen_numel"]) == sum(int(np.prod(O.d_param_shapes(res)[k])) for k in frozen)
+
+
+@pytest.mark.parametrize("res_", [256, 512])
+def test_forward_full_resolution(res_):
+    """(the 1024 x 1024 fixture is checked against the HIP path on the GPU only: ~1 min of CPU here)"""
+    Fw = np.load(os.path.join(GOLD, f"forward_r{res_}.npz"))
+    res, B, st = int(Fw["res"]), int(Fw["B"]), int(Fw["stride"])
     GP, DP = seeded_state(O.g_param_shapes(res), 1001), seeded_state(O.d_param_shapes(res), 1002)
     z1, z2 = seeded_tensor((B, 64), 3000), seeded_tensor((B, 64), 3001)
     with torch.no_grad():
         img = O.generator_forward(GP, z1, z2, res)
-        close(img[:, :, ::16, ::16], Fw["img/slice"], what="img")
+        close(img[:, :, ::st, ::st], Fw["img/slice"], what="img")
         close(GP["avg_latent1"], Fw["avg_latent1"]), close(GP["avg_latent2"], Fw["avg_latent2"])
         img_t = O.generator_forward(GP, z1, z2, res, w_psi=0.7)
-        close(img_t[:, :, ::16, ::16], Fw["img_trunc/slice"], what="img_trunc")
+        close(img_t[:, :, ::st, ::st], Fw["img_trunc/slice"], what="img_trunc")
         real = seeded_tensor((B, 3, res, res), 3002, "uniform_pm1")
         logit, ge, ae = O.discriminator_forward(DP, real, res, True)
         close(logit, Fw["logit"]), close(ge, Fw["geo_emb"]), close(ae, Fw["app_emb"])

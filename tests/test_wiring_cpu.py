@@ -1,6 +1,6 @@
 """Host-side logic on CPU: the autograd wiring (ops.py), the nn.Module surface (custom_layers.py, cnn.py), the losses and the
 worker's step sequencing are driven with a CPU emulation of the kernel interface (oracle/hip_emulation.py, installed through
-the test hook lcgan_amd.kernels.set_backend) and compared with the golden vectors captured from the reference.
+tests/helpers.py:install_backend) and compared with the golden vectors captured from the reference.
 The HIP kernels themselves are checked on the GPU (test_kernels_gpu.py, test_parity_gpu.py)."""
 import copy
 import os
@@ -12,7 +12,7 @@ import torch
 from oracle import lcgan_ref as O
 from oracle.hip_emulation import EmulatedKernels
 from oracle.weights import seeded_state, seeded_tensor
-from tests.helpers import GOLD, FixedFeed, check_grads_vs_golden, seeded_worker
+from tests.helpers import install_backend, GOLD, FixedFeed, check_grads_vs_golden, seeded_worker
 
 TOL = 1e-3        # north_star tolerance (relative, fp32)
 # Gradients are compared through L1 / L2 norms and seeded random projections (tests/helpers.py): elementwise maxima are
@@ -28,10 +28,10 @@ TOL_EVEN_GRADS = 3e-3
 def emulated_backend():
     import lcgan_amd.kernels as KM
     from lcgan_amd import config
-    KM.set_backend(EmulatedKernels())
+    install_backend(EmulatedKernels())
     with config.feature_dtype_as(torch.float32):
         yield
-    KM.set_backend(None)
+    install_backend(None)
 
 
 @pytest.fixture(scope="module")
@@ -140,10 +140,97 @@ def test_ema_matches_reference_semantics():
     assert all(torch.equal(a, b) for a, b in zip(e.target.state_dict().values(), src.state_dict().values()))
 
 
+def test_checkpoint_round_trip_and_reference_layout(S, tmp_path):
+    """worker.py:219-253, loader.py:35-42: (1) save_model -> load_model into a fresh WORKER restores G, G_ema, D (same outputs) and
+    the Adam state; (2) the files carry the `module.`-prefixed keys of the reference's DDP-wrapped modules (key dump captured from
+    the reference: g_keys / d_keys of step_r32.npz); (3) a checkpoint WRITTEN in the reference's layout (those keys, no optimizer
+    file) loads."""
+    from lcgan_amd import loader
+    from tests.helpers import make_args
+    res, B = 16, 2
+    args = dict(model_name=str(tmp_path / "run"), save_dir="model")
+    os.makedirs(tmp_path / "run" / "model")
+    torch.manual_seed(3)
+    w = seeded_worker(res, B, "cpu", **args)
+    FixedFeed(w, B, res, "cpu")
+    for epoch in (0, 1):
+        loader.train_iteration(w, w.args, epoch)                    # moves G, D, G_ema and both Adam states
+    w.save_model()
+    files = sorted(os.listdir(tmp_path / "run" / "model"))
+    assert files == ["disc_model.ckpt", "gen_ema_model.ckpt", "gen_model.ckpt", "optim_state.ckpt"]
+    sd_g, sd_d = torch.load(tmp_path / "run" / "model" / "gen_model.ckpt"), torch.load(tmp_path / "run" / "model" / "disc_model.ckpt")
+    g_ref = {"module." + k for k in O.g_param_shapes(res)}          # the oracle's inventory == the reference's dump (test_oracle_golden)
+    assert set(sd_g) == g_ref and set(sd_d) == {"module." + k for k in O.d_param_shapes(res)}
+    assert sorted(k[len("module."):] for k in torch.load(tmp_path / "run" / "model" / "gen_ema_model.ckpt")) == sorted(O.g_param_shapes(res))
+
+    torch.manual_seed(4)
+    w2 = worker_mod().WORKER(make_args(res, B, **args), 0, 1, device="cpu")   # different random init
+    w2.load_model()
+    for a, b in ((w.generator, w2.generator), (w.generator_ema, w2.generator_ema), (w.discriminator, w2.discriminator)):
+        for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+            assert torch.equal(va, vb), k
+    assert w2.g_optimizer.steps == w.g_optimizer.steps and w2.d_optimizer.steps == w.d_optimizer.steps
+    assert all(torch.equal(a, b) for a, b in zip(w.d_optimizer.exp_avg_sq, w2.d_optimizer.exp_avg_sq))
+    z1, z2 = seeded_tensor((B, 64), 1), seeded_tensor((B, 64), 2)
+    with torch.no_grad():
+        assert torch.equal(w.generate(z1, z2, 0.7), w2.generate(z1, z2, 0.7))
+    # resumed training continues identically (Adam moments included)
+    FixedFeed(w2, B, res, "cpu")
+    FixedFeed(w, B, res, "cpu")
+    la, lb = loader.train_iteration(w, w.args, 3), loader.train_iteration(w2, w2.args, 3)
+    assert float(la[0]) == float(lb[0]) and float(la[1]) == float(lb[1])
+    for (k, va), (_, vb) in zip(w.discriminator.state_dict().items(), w2.discriminator.state_dict().items()):
+        assert torch.equal(va, vb), k
+
+    # (3) a reference-written checkpoint: state_dicts keyed exactly like the reference's dump, no optimizer file
+    ref_dir = tmp_path / "ref" / "model"
+    os.makedirs(ref_dir)
+    GP, DP = seeded_state(O.g_param_shapes(res), 77), seeded_state(O.d_param_shapes(res), 78)
+    torch.save({"module." + k: v for k, v in GP.items()}, ref_dir / "gen_model.ckpt")
+    torch.save({"module." + k: v for k, v in GP.items()}, ref_dir / "gen_ema_model.ckpt")
+    torch.save({"module." + k: v for k, v in DP.items()}, ref_dir / "disc_model.ckpt")
+    w3 = worker_mod().WORKER(make_args(res, B, model_name=str(tmp_path / "ref"), save_dir="model"), 0, 1, device="cpu")
+    w3.load_model()
+    assert all(torch.equal(v, GP[k]) for k, v in w3.generator.module.state_dict().items())
+    assert all(torch.equal(v, DP[k]) for k, v in w3.discriminator.module.state_dict().items())
+    with torch.no_grad():
+        img = w3.generate(z1, z2, 0.7)
+    assert rel(img, O.generator_forward({k: v.clone() for k, v in GP.items()}, z1, z2, res, w_psi=0.7)) <= TOL
+
+
+def worker_mod():
+    from lcgan_amd import worker
+    return worker
+
+
+def test_fake_image_generation_phase(tmp_path):
+    """loader.py:95-99 + worker.py:427-441: load the checkpoints, write num_fakes column images of the EMA generator's output."""
+    from PIL import Image
+    from lcgan_amd import loader
+    from tests.helpers import make_args
+    res, B = 16, 2
+    run = tmp_path / "run"
+    os.makedirs(run / "model")
+    w = seeded_worker(res, B, "cpu", model_name=str(run), save_dir="model")
+    w.save_model()
+    args = make_args(res, B, model_name=str(run), save_dir="model", phase="fake_image_generation", num_fakes=3, w_psi=0.7)
+    torch.manual_seed(11)
+    gw = worker_mod().WORKER(args, 0, 1, device="cpu")
+    gw.load_model()
+    gw.fake_image_generation(num_images=args.num_fakes)
+    names = sorted(os.listdir(run / "fakes"))
+    assert names == ["0000_images.jpg", "0001_images.jpg", "0002_images.jpg"]
+    assert Image.open(run / "fakes" / names[0]).size == (res, B * res)
+    torch.manual_seed(11)                                            # the same draws -> the first file's pixels
+    ref = ((w.generate(torch.randn(B, 64), torch.randn(B, 64), 0.7) + 1) / 2).clamp(0, 1)
+    got = torch.from_numpy(np.array(Image.open(run / "fakes" / names[0]))).float() / 255
+    assert float((got - ref.permute(0, 2, 3, 1).reshape(B * res, res, 3)).abs().mean()) < 0.05      # JPEG is lossy
+
+
 def test_product_has_no_cpu_fallback():
     """Without the test hook the product path must refuse CPU tensors loudly (no silent eager fallback)."""
     import lcgan_amd.kernels as KM
-    KM.set_backend(None)
+    install_backend(None)
     try:
         w = None
         with pytest.raises((RuntimeError, AssertionError)):
@@ -154,7 +241,7 @@ def test_product_has_no_cpu_fallback():
             from lcgan_amd import ops
             ops.Box3Fn.apply(torch.zeros(1, 4, 4, 8))
     finally:
-        KM.set_backend(EmulatedKernels())
+        install_backend(EmulatedKernels())
 
 
 def test_qr_backward_formula_matches_torch():
