@@ -96,6 +96,7 @@ def main():
                     help="BASELINE config 4: freeze the first discriminator layers (main.py --freezeD_layer, with freezeD_start 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--launch-table", default="", help="write the per-launch table (HIP events, conv geometry tags) of one more iteration here")
     ap.add_argument("--no-cycle", action="store_true", help="skip the extra 8-iteration cycle (epoch 8..15) reported beside the R1 line")
     a = ap.parse_args()
 
@@ -209,6 +210,12 @@ def main():
             top = max(hbm, key=lambda k: hbm[k]["ms"])
             out["roofline_hbm"] = {"bound": "hbm", "kernel": top, "achieved": hbm[top]["GBps"], "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                                    "frac": hbm[top]["frac"], "traffic": None, "families": hbm}
+        if a.launch_table:                                  # per-launch in-iteration table: shape -> us -> TFLOP/s (profiles/*_launch_table.csv)
+            K.prof_enable(True)
+            loader.train_iteration(w, args, epoch_of(a.warmup + a.steps + 1))
+            torch.cuda.synchronize()
+            K.prof_dump(a.launch_table)
+            K.prof_enable(False)
     elif world > 1 and not a.no_roofline:
         loader.train_iteration(w, args, epoch_of(a.warmup + a.steps))       # keep the ranks in lock-step
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -155,6 +155,8 @@ int lcgan_set_option(int option, int value);
 int lcgan_prof_enable(int on);
 int lcgan_prof_collect(double* out_ms, double* out_flops, double* out_bytes, long long* out_count);
 int lcgan_prof_active(void);
+/* one CSV row per recorded launch, in launch order: kid, ms, flops, bytes, tag (convolutions tag their geometry); clears the records */
+int lcgan_prof_dump(const char* path);
 
 /* ---- device-side training views (the data step in front of the hot path) ---------------------------------------------
  * replaces custom_dataset.py:59-88 (h-flip :68, albumentations Perspective :22-23,27-33, CoarseDropout :24 / ColorJitter :19-21,

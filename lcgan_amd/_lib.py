@@ -66,6 +66,7 @@ SIGNATURES = {
     "lcgan_prof_enable": [I],
     "lcgan_prof_collect": [P, P, P, P],
     "lcgan_prof_active": [],
+    "lcgan_prof_dump": [P],
 }
 
 _lib = None

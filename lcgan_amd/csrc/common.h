@@ -97,15 +97,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 #define KID_COUNT 13
 
 extern "C" int lcgan_prof_active();
-void lcgan_prof_begin(int kid, double flops, double bytes, hipStream_t s);
-void lcgan_prof_end(hipStream_t s);
+int lcgan_prof_begin(int kid, double flops, double bytes, hipStream_t s, const char* tag);
+void lcgan_prof_end(int idx, hipStream_t s);
 
 struct ProfScope {
-  hipStream_t s; bool on;
-  ProfScope(int kid, double flops, double bytes, hipStream_t st) : s(st), on(lcgan_prof_active() != 0) {
-    if (on) lcgan_prof_begin(kid, flops, bytes, s);
+  hipStream_t s; bool on; int idx;
+  ProfScope(int kid, double flops, double bytes, hipStream_t st, const char* tag = nullptr) : s(st), on(lcgan_prof_active() != 0), idx(-1) {
+    if (on) idx = lcgan_prof_begin(kid, flops, bytes, s, tag);
   }
-  ~ProfScope() { if (on) lcgan_prof_end(s); }
+  ~ProfScope() { if (on) lcgan_prof_end(idx, s); }
 };
 
 static inline int launch_status() {

@@ -21,6 +21,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdio>
 
 extern "C" int lcgan_scale_reduce(void* u, const void* x, const float* sc, float* gs, int B, int HW, int C, int dtype, void* stream);
 
@@ -1477,7 +1478,9 @@ int lcgan_conv_fwd(const void* x, const void* wp, void* y,
   t.n = k * k;
   for (int ky = 0; ky < k; ++ky)
     for (int kx = 0; kx < k; ++kx) { const int i = ky * k + kx; t.dy[i] = ky - pad; t.dx[i] = kx - pad; t.wt[i] = i; }
-  ProfScope p(KID_CONV_IGEMM, 2.0 * M * N * Cin * k * k, 0, s);
+  char tag[96] = "";
+  if (lcgan_prof_active()) snprintf(tag, sizeof(tag), "fwd B%d %dx%d C%d->%d k%d s%d%s%s", B, Hin, Win, Cin, N, k, stride, pre ? " mod" : "", xs ? " +gs" : residual ? " +res" : "");
+  ProfScope p(KID_CONV_IGEMM, 2.0 * M * N * Cin * k * k, 0, s, tag);
   return dispatch_igemm(a, 1, dtype, s);
 }
 
@@ -1532,7 +1535,9 @@ int lcgan_conv_bwd_data(const void* g, const void* wpT, void* gx,
       }
     taps_total = 9.0 / 4.0;   // average taps per output pixel
   }
-  ProfScope p(KID_CONV_IGEMM, 2.0 * (double)B * a.Hout * a.Wout * N * Cg * taps_total, 0, s);
+  char tag[96] = "";
+  if (lcgan_prof_active()) snprintf(tag, sizeof(tag), "dgrad B%d %dx%d C%d->%d k%d s%d%s%s", B, Hg, Wg, Cg, N, k, stride, pre ? " mod" : "", xs ? " +gs" : residual ? (residual_half ? " +res/2" : " +res") : "");
+  ProfScope p(KID_CONV_IGEMM, 2.0 * (double)B * a.Hout * a.Wout * N * Cg * taps_total, 0, s, tag);
   return dispatch_igemm(a, nphase, dtype, s);
 }
 
@@ -1556,7 +1561,9 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
   a.chunks_per_split = cdiv(a.nchunks, nsplit);
   a.nsplit = cdiv(a.nchunks, a.chunks_per_split);
   dim3 grid(cdiv(A, 128), cdiv(Bc, 128), k * k * a.nsplit);
-  ProfScope p(KID_CONV_WGRAD, 2.0 * M * A * Bc * k * k, 0, s);
+  char tag[96] = "";
+  if (lcgan_prof_active()) snprintf(tag, sizeof(tag), "wgrad B%d %dx%d A%d Bc%d k%d s%d%s", B, Hg, Wg, A, Bc, k, stride, (pre_x || pre_g) ? " mod" : "");
+  ProfScope p(KID_CONV_WGRAD, 2.0 * M * A * Bc * k * k, 0, s, tag);
   const int segw = (Wg & 63) == 0 ? 64 : (Wg & 31) == 0 ? 32 : (Wg == 16 ? 16 : (Wg == 8 ? 8 : 0));
   if (dtype == DT_BF16 && g_use_halo && segw != 0 && Hg * Wg >= 64 && (Hg & 3) == 0 && (g_wgrad3_small == 1 || (k == 3 && segw >= 32) || (g_wgrad3_small == 0 && !(pre_x || pre_g))) &&
       (long long)B * Hx * Wx * Cx < (1ll << 31) && (long long)B * Hg * Wg * Cg < (1ll << 31)) {

@@ -562,6 +562,10 @@ class HipKernels:
     def prof_enable(self, on: bool) -> None:
         self.lib.lcgan_prof_enable(int(on))
 
+    def prof_dump(self, path: str) -> None:
+        """per-launch CSV (kid, ms, flops, bytes, tag) of everything recorded since prof_enable(True); clears the records"""
+        _lib.check(self.lib.lcgan_prof_dump(path.encode()), "lcgan_prof_dump")
+
     def prof_collect(self):
         import ctypes as C
         n = 13

@@ -92,6 +92,46 @@ class DualBackend:
         return [f"{mx:.2e} (l2 {l2:.2e}) {tag} {shape}" for mx, l2, tag, shape in sorted(self.diffs, reverse=True)[:k]]
 
 
+class MaskRecorder:
+    """Wraps ONE backend and keeps the sign pattern (and, for the CPU side, the values) of every leaky-ReLU output, keyed by the
+    call's sequence number.  Two recordings of the same step -- the HIP chain on the GPU and the CPU emulation chain, each fed by its
+    OWN earlier outputs -- are then compared call by call (compare_masks): unlike DualBackend's per-call comparison on identical
+    inputs, this also sees a pre-activation that the accumulated upstream difference (~1e-6) carried across zero.  The emulation
+    chain reproduces the reference within the strict 1e-3 criterion on every tensor (tests/test_wiring_cpu.py), so it stands in
+    for the reference's masks."""
+    name = "hip"
+
+    def __init__(self, inner, keep_values=False):
+        self.inner, self.keep_values, self.n, self.masks = inner, keep_values, 0, []
+
+    def __getattr__(self, item):
+        f = getattr(self.inner, item)
+        if not callable(f) or item not in _ACT_ARG:
+            return f
+
+        def call(*args, **kw):
+            out = f(*args, **kw)
+            name, pos = _ACT_ARG[item]
+            act = kw.get(name, args[pos] if (pos is not None and len(args) > pos) else 0)
+            if act == ACT_LRELU:
+                y = (out[0] if isinstance(out, (tuple, list)) else out).detach().float().cpu()
+                self.masks.append((f"#{len(self.masks)} {item}{tuple(y.shape)}", y > 0, y if self.keep_values else None))
+            return out
+        return call
+
+
+def compare_masks(hip: "MaskRecorder", cpu: "MaskRecorder"):
+    """-> [(count, numel, max |y_cpu| at a flip / max |y_cpu|, tag)] over the leaky-ReLU outputs where the two chains disagree"""
+    assert len(hip.masks) == len(cpu.masks), (len(hip.masks), len(cpu.masks))
+    flips = []
+    for (tag, mh, _), (tag_c, mc, yc) in zip(hip.masks, cpu.masks):
+        assert mh.shape == mc.shape, (tag, tag_c)
+        bad = mh != mc
+        if bool(bad.any()):
+            flips.append((int(bad.sum()), bad.numel(), float(yc[bad].abs().max() / yc.abs().max().clamp_min(1e-30)), tag))
+    return flips
+
+
 class dual_backend:
     """with dual_backend() as rec: ... run a step ...; rec.flips / rec.diffs"""
 

@@ -96,13 +96,13 @@ def check_grads_vs_golden_kink_tolerant(S, tag, named_params, tol, kink_tol=1e-2
     v = np.array(sorted(errs.values()))
     over = {k: e for k, e in errs.items() if e > tol}
     report = f"{tag}: median {np.median(v):.2e} worst {v[-1]:.2e}; {len(over)}/{len(v)} tensors > {tol}"
-    if rec is not None:
+    if rec is not None:        # rec: [(count, numel, relative |pre-activation| at the flips, call tag)] from tests/dual_backend.py
         report += "".join(f"\n    over: {k} {e:.2e}" for k, e in sorted(over.items(), key=lambda kv: -kv[1]))
-        report += "".join(f"\n    flip: {l}" for l in rec.flip_report()) + "".join(f"\n    call: {l}" for l in rec.worst_calls(3))
+        report += "".join(f"\n    flip: {c}/{n} sign flips, |pre-act| <= {m:.1e} of the tensor's max, in {t}" for c, n, m, t in rec)
         print(report)
         if over:
-            assert rec.flips, f"{len(over)} tensors above {tol} and NO activation-mask flip was recorded: not a kink effect\n{report}"
-            assert all(m <= 1e-4 for _, _, m, _ in rec.flips), f"mask flips at non-negligible pre-activations\n{report}"
+            assert rec, f"{len(over)} tensors above {tol} and NO activation-mask flip against the CPU chain: not a kink effect\n{report}"
+            assert all(m <= 1e-4 for _, _, m, _ in rec), f"mask flips at non-negligible pre-activations\n{report}"
     assert float(np.median(v)) <= median_tol, f"{tag}: median gradient error {np.median(v):.2e} > {median_tol}"
     assert len(over) <= kink_frac * len(v), f"{tag}: {len(over)}/{len(v)} tensors above {tol}: {sorted(over.items(), key=lambda kv: -kv[1])[:5]}"
     assert v[-1] <= kink_tol, f"{tag}: worst tensor {v[-1]:.2e} > {kink_tol}: {max(errs, key=errs.get)}"

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import lcgan_ref as O                      # noqa: E402
 from oracle.weights import seeded_state, seeded_tensor  # noqa: E402
-from tests.dual_backend import dual_backend            # noqa: E402
+from tests.dual_backend import MaskRecorder, compare_masks   # noqa: E402
 from tests.helpers import GOLD, FixedFeed, check_grads_vs_golden_kink_tolerant as check_grads_vs_golden, make_args, seeded_worker   # noqa: E402
 
 TOL, TOL_EVEN_GRADS = 1e-3, 3e-3      # see tests/test_wiring_cpu.py for the even-iteration allowance
@@ -52,18 +52,37 @@ def f32_mode():
         yield
 
 
+def both_chains(run):
+    """run(device) -> result, once on the HIP kernels and once on the CPU emulation chain (the stand-in for the reference's
+    activation masks, see tests/dual_backend.py:MaskRecorder); returns (HIP result, mask flips between the two chains)."""
+    from lcgan_amd.kernels import HipKernels
+    from oracle.hip_emulation import EmulatedKernels
+    from tests.helpers import install_backend
+    hip, cpu = MaskRecorder(HipKernels()), MaskRecorder(EmulatedKernels(), keep_values=True)
+    try:
+        install_backend(hip)
+        out = run(DEV)
+        install_backend(cpu)
+        run("cpu")
+    finally:
+        install_backend(None)
+    return out, compare_masks(hip, cpu)
+
+
 @pytest.mark.parametrize("epoch", [0, 1])
 def test_train_generator_vs_golden(S, f32_mode, epoch):
     res, B = int(S["res"]), int(S["B"])
-    with dual_backend() as rec:                     # every kernel call also runs on the CPU emulation: activation-mask flips are recorded
-        w = seeded_worker(res, B, DEV)
-        FixedFeed(w, B, res, DEV)
+
+    def run(dev):
+        w = seeded_worker(res, B, dev)
+        FixedFeed(w, B, res, dev)
         w.g_optimizer.step = lambda: None
         w.requires_grad(w.generator, True), w.requires_grad(w.discriminator, False)
-        g_loss = w.train_generator(epoch)
+        return w, w.train_generator(epoch)
+    (w, g_loss), flips = both_chains(run)
     assert rel(g_loss, S[f"g{epoch}/loss"]) <= TOL
     worst, report = check_grads_vs_golden(S, f"g{epoch}", w.generator.module.named_parameters(), TOL if epoch % 2 else TOL_EVEN_GRADS,
-                                          median_tol=2e-4 if epoch % 2 else 1e-3, rec=rec)
+                                          median_tol=2e-4 if epoch % 2 else 1e-3, rec=flips)
     record(f"f32_train_generator_epoch{epoch}", loss_rel=rel(g_loss, S[f"g{epoch}/loss"]), grad_worst=worst, report=report)
     assert rel(w.generator.module.avg_latent1, S[f"g{epoch}/avg_latent1"]) <= TOL
     assert rel(w.generator.module.avg_latent2, S[f"g{epoch}/avg_latent2"]) <= TOL
@@ -73,17 +92,19 @@ def test_train_generator_vs_golden(S, f32_mode, epoch):
 def test_train_discriminator_vs_golden(S, f32_mode, epoch, frozen):
     res, B = int(S["res"]), int(S["B"])
     tag = f"d{epoch}" + (f"_freeze{frozen}" if frozen else "")
-    with dual_backend() as rec:
-        w = seeded_worker(res, B, DEV)
-        FixedFeed(w, B, res, DEV)
+
+    def run(dev):
+        w = seeded_worker(res, B, dev)
+        FixedFeed(w, B, res, dev)
         w.d_optimizer.step = lambda: None
         w.requires_grad(w.generator, False), w.requires_grad(w.discriminator, True)
         if frozen:
             w.freeze_discriminator(frozen)
-        d_loss = w.train_discriminator(epoch)
+        return w, w.train_discriminator(epoch)
+    (w, d_loss), flips = both_chains(run)
     assert rel(d_loss, S[f"{tag}/loss"]) <= TOL
     worst, report = check_grads_vs_golden(S, tag, w.discriminator.module.named_parameters(), TOL if epoch % 2 else TOL_EVEN_GRADS,
-                                          median_tol=2e-4 if epoch % 2 else 1e-3, rec=rec)
+                                          median_tol=2e-4 if epoch % 2 else 1e-3, rec=flips)
     record(f"f32_train_discriminator_{tag}", loss_rel=rel(d_loss, S[f"{tag}/loss"]), grad_worst=worst, report=report)
 
 
@@ -92,13 +113,15 @@ def test_r1_value_and_gradient_vs_golden(S, f32_mode):
     the discriminator) against the reference.  In the full D step this term is < 1 % of the gradient, so the step tests cannot pin it."""
     from lcgan_amd import loss
     res, B = int(S["res"]), int(S["B"])
-    with dual_backend() as rec:
-        w = seeded_worker(res, B, DEV)
+    def run(dev):
+        w = seeded_worker(res, B, dev)
         w.requires_grad(w.discriminator, True)
-        image = seeded_tensor((B, 3, res, res), 2100, "uniform_pm1").to(DEV).requires_grad_(True)
+        image = seeded_tensor((B, 3, res, res), 2100, "uniform_pm1").to(dev).requires_grad_(True)
         logit, _, _ = w.discriminator(image, False)
-        r1 = loss.cal_r1_reg(logit, image, DEV)
+        r1 = loss.cal_r1_reg(logit, image, dev)
         (r1 * 10.0).backward()                                   # l_r1 = 10 (worker.py:160)
+        return w, (logit, r1)
+    (w, (logit, r1)), flips = both_chains(run)
     assert rel(logit, S["d1/real_logit"]) <= TOL
     assert rel(r1, S["d1/r1"]) <= TOL, (float(r1), float(S["d1/r1"]))
     none_ref = set(S["d1/r1grad_none"]) - {""}
@@ -115,7 +138,7 @@ def test_r1_value_and_gradient_vs_golden(S, f32_mode):
     for k, p in named:
         if float(S[f"d1/r1grad/{k}/l2"]) == 0.0:
             assert float(p.grad.abs().max()) == 0.0, k
-    worst, report = check_grads_vs_golden(S, "d1", nonzero, TOL, rec=rec, group="r1grad")
+    worst, report = check_grads_vs_golden(S, "d1", nonzero, TOL, rec=flips, group="r1grad")
     record("f32_r1_only", r1_rel=rel(r1, S["d1/r1"]), grad_worst=worst, report=report)
 
 
