@@ -90,7 +90,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--batch", type=int, default=32, help="GLOBAL batch (worker.py:35 splits it over the ranks)")
-    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--dtype", choices=["bf16", "f32", "fp8"], default="bf16",
+                    help="fp8 = BASELINE configs[4]: MX-fp8 operands on the eligible convolutions, bf16 feature maps")
     ap.add_argument("--epoch-type", choices=["r1", "odd", "even", "cycle"], default="r1")
     ap.add_argument("--freezeD-layer", type=int, default=-1,
                     help="BASELINE config 4: freeze the first discriminator layers (main.py --freezeD_layer, with freezeD_start 0)")
@@ -118,7 +119,8 @@ def main():
 
     from lcgan_amd import config, kernels, loader, worker
     from lcgan_amd.config import default_args as make_args
-    config.set_feature_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
+    config.set_feature_dtype(torch.float32 if a.dtype == "f32" else torch.bfloat16)
+    config.set_conv_operands("fp8" if a.dtype == "fp8" else "bf16")
     assert kernels.backend_name() == "hip"
     extra = dict(freezeD_start=0, freezeD_layer=a.freezeD_layer) if a.freezeD_layer >= 0 else {}
     args = make_args(a.res, a.batch, **extra)

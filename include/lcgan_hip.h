@@ -158,6 +158,22 @@ int lcgan_prof_active(void);
 /* one CSV row per recorded launch, in launch order: kid, ms, flops, bytes, tag (convolutions tag their geometry); clears the records */
 int lcgan_prof_dump(const char* path);
 
+/* ---- MX-fp8 convolution path (BASELINE configs[4]: fp8 MFMA operands, fp32 accumulate, bf16 feature maps) ------------------
+ * the same reference calls as lcgan_conv_fwd / lcgan_conv_bwd_data (F.conv2d custom_layers.py:41,43,83; F.conv_transpose2d :78;
+ * modulation :62-72) with OCP e4m3 operands and one E8M0 power-of-two scale per 32 reduction channels (v_mfma_scale_f32_32x32x64_f8f6f4):
+ * activations are quantised while they are staged, weights once per optimiser step by lcgan_conv_weight_prep_fp8.
+ * wp: e4m3 [k*k][N][K64][64], wsc: E8M0 [k*k][N][K64][2], K64 = ceil(reduction channels / 64) (layout: csrc/conv_fp8.hip).
+ * Restrictions: bf16 feature maps, output grids of at least 16 x 16 positions, no tanh, no fused style-gradient reduction. */
+int lcgan_conv_weight_prep_fp8(const float* w, int A, int Bc, int k, float scale, int transpose, void* wp, void* wsc, void* stream);
+int lcgan_conv_fwd_fp8(const void* x, const void* wp, const void* wsc, void* y,
+                       int B, int Hin, int Win, int Cin, int Cout, int N, int k, int stride,
+                       const float* pre, const float* post, const float* bias, float bias_scale,
+                       int act, float gain, const void* residual, int residual_half, void* stream);
+int lcgan_conv_bwd_data_fp8(const void* g, const void* wpT, const void* wscT, void* gx,
+                            int B, int Hg, int Wg, int Cg, int Cout, int N, int k, int stride,
+                            const float* pre, const float* post, const float* bias, float bias_scale,
+                            int act, float gain, const void* residual, int residual_half, void* stream);
+
 /* ---- device-side training views (the data step in front of the hot path) ---------------------------------------------
  * replaces custom_dataset.py:59-88 (h-flip :68, albumentations Perspective :22-23,27-33, CoarseDropout :24 / ColorJitter :19-21,
  * normalisation :81-86), which the reference runs on the host in DataLoader workers (worker.py:37,62-69).

@@ -62,6 +62,9 @@ SIGNATURES = {
     "lcgan_avg_latent": [P, P, I, I, F, P],
     "lcgan_multi_tensor": [P, P, P, I, I, F, F, F, D, P],
     "lcgan_make_views": [P, P, P, P, P, I, I, P],
+    "lcgan_conv_weight_prep_fp8": [P, I, I, I, F, I, P, P, P],
+    "lcgan_conv_fwd_fp8": [P, P, P, P, I, I, I, I, I, I, I, I, P, P, P, F, I, F, P, I, P],
+    "lcgan_conv_bwd_data_fp8": [P, P, P, P, I, I, I, I, I, I, I, I, P, P, P, F, I, F, P, I, P],
     "lcgan_set_option": [I, I],
     "lcgan_prof_enable": [I],
     "lcgan_prof_collect": [P, P, P, P],

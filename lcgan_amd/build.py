@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblcgan_hip.so")
-SOURCES = ["conv_igemm.hip", "stencil.hip", "small.hip", "views.hip", "prof.hip"]
+SOURCES = ["conv_igemm.hip", "conv_fp8.hip", "stencil.hip", "small.hip", "views.hip", "prof.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-Wno-unused-value"]
 
 

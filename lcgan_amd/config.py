@@ -12,6 +12,7 @@ import contextlib
 import torch
 
 _feature_dtype = torch.bfloat16
+_conv_operands = "bf16"      # "bf16" | "fp8": MFMA operand type of the eligible convolution launches (feature maps stay bf16)
 
 
 def feature_dtype() -> torch.dtype:
@@ -23,6 +24,30 @@ def set_feature_dtype(dtype: torch.dtype) -> None:
     if dtype not in (torch.bfloat16, torch.float32):
         raise ValueError("feature dtype must be torch.bfloat16 or torch.float32")
     _feature_dtype = dtype
+
+
+def conv_operands() -> str:
+    return _conv_operands
+
+
+def set_conv_operands(kind: str) -> None:
+    """"fp8" = BASELINE configs[4]: the stride-1 3x3 / 1x1 forward and data-gradient convolutions on grids >= 16 x 16 run on MX block-scaled
+    e4m3 operands (v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate, bf16 feature maps); weight gradients, stride-2 / transposed
+    convolutions and low-resolution layers stay bf16.  Precision: ~4 % relative L2 per convolution output (tests/test_kernels_gpu.py)."""
+    global _conv_operands
+    if kind not in ("bf16", "fp8"):
+        raise ValueError("conv operands must be 'bf16' or 'fp8'")
+    _conv_operands = kind
+
+
+@contextlib.contextmanager
+def conv_operands_as(kind: str):
+    old = _conv_operands
+    set_conv_operands(kind)
+    try:
+        yield
+    finally:
+        set_conv_operands(old)
 
 
 @contextlib.contextmanager

@@ -42,6 +42,14 @@ class PreparedWeight:
         self.buf, self.parts, self.N, self.Kpad, self.k = buf, parts, N, Kpad, k
 
 
+class PreparedWeightFp8:
+    """MX-fp8 copy of a conv weight: e4m3 [k*k][N][K64][64] + E8M0 block scales [k*k][N][K64][2] (csrc/conv_fp8.hip)."""
+    __slots__ = ("buf", "scales", "N", "K64", "k")
+
+    def __init__(self, buf, scales, N, K64, k):
+        self.buf, self.scales, self.N, self.K64, self.k = buf, scales, N, K64, k
+
+
 class _ZeroPool:
     """Zero-initialised fp32 scratch carved out of one pre-cleared slab: the atomically accumulated outputs (weight / bias /
     style gradients) are many and small, and one fill per 64 MB replaces ~370 fill launches per iteration.  A slice keeps
@@ -204,6 +212,40 @@ class HipKernels:
         self._call("lcgan_conv_wgrad", x.data_ptr(), g.data_ptr(), gwp.data_ptr(), B, Hx, Wx, Cx, Hg, Wg, Cg, A, Bc, k, stride,
                    _p(pre_x), _p(pre_g), dt_code(x.dtype), self._stream())
         return gwp
+
+    # ---- MX-fp8 convolution path (BASELINE configs[4]) ------------------------------------------------------------------
+    def prep_weight_fp8(self, w: Tensor, scale: float, transpose: bool):
+        self._chk(w)
+        A, Bc, k, _ = w.shape
+        N, Kc = (Bc, A) if transpose else (A, Bc)
+        K64 = (Kc + 63) // 64
+        buf = torch.empty((k * k, N, K64, 64), dtype=torch.uint8, device=w.device)
+        sc = torch.empty((k * k, N, K64, 2), dtype=torch.uint8, device=w.device)
+        self._call("lcgan_conv_weight_prep_fp8", w.data_ptr(), A, Bc, k, float(scale), int(transpose), buf.data_ptr(), sc.data_ptr(),
+                   self._stream())
+        return PreparedWeightFp8(buf, sc, N, K64, k)
+
+    def conv_fwd_fp8(self, x: Tensor, pw, N: int, k: int, stride: int, pre=None, post=None, bias=None, bias_scale: float = 1.0,
+                     act: int = ACT_NONE, gain: float = 1.0, residual=None, residual_half: bool = False) -> Tensor:
+        self._chk(x, pre, post, bias, residual)
+        assert x.dtype == torch.bfloat16
+        B, H, W, Cin = x.shape
+        Cout = ceil8(N)
+        y = torch.empty((B, (H + stride - 1) // stride, (W + stride - 1) // stride, Cout), dtype=x.dtype, device=x.device)
+        self._call("lcgan_conv_fwd_fp8", x.data_ptr(), pw.buf.data_ptr(), pw.scales.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, N, k, stride,
+                   _p(pre), _p(post), _p(bias), float(bias_scale), act, float(gain), _p(residual), int(residual_half), self._stream())
+        return y
+
+    def conv_bwd_data_fp8(self, g: Tensor, pw, N: int, k: int, stride: int, pre=None, post=None, bias=None, bias_scale: float = 1.0,
+                          act: int = ACT_NONE, gain: float = 1.0, residual=None, residual_half: bool = False) -> Tensor:
+        self._chk(g, pre, post, bias, residual)
+        assert g.dtype == torch.bfloat16
+        B, H, W, Cg = g.shape
+        Cout = ceil8(N)
+        gx = torch.empty((B, H * stride, W * stride, Cout), dtype=g.dtype, device=g.device)
+        self._call("lcgan_conv_bwd_data_fp8", g.data_ptr(), pw.buf.data_ptr(), pw.scales.data_ptr(), gx.data_ptr(), B, H, W, Cg, Cout, N, k,
+                   stride, _p(pre), _p(post), _p(bias), float(bias_scale), act, float(gain), _p(residual), int(residual_half), self._stream())
+        return gx
 
     # ---- stencils ---------------------------------------------------------------------------------------
     def box3_act(self, x: Tensor, act: int, gain: float) -> Tensor:

@@ -42,7 +42,8 @@ def parse_args(argv=None):
     for name, typ, default, help_ in _FLAGS:
         parser.add_argument("--" + name, type=typ, default=default, help=help_)
     parser.add_argument("--best", default=False, action="store_true", help="load the *_best checkpoints")
-    parser.add_argument("--feature_dtype", choices=["bf16", "f32"], default="bf16", help="feature-map dtype of the HIP path")
+    parser.add_argument("--feature_dtype", choices=["bf16", "f32", "fp8"], default="bf16",
+                        help="feature-map dtype of the HIP path (fp8: bf16 feature maps, MX-fp8 operands on the eligible convolutions)")
     return check_args(parser.parse_args(argv))
 
 
@@ -61,7 +62,8 @@ def check_args(args):
 
 def _run(local_rank, args, gpus, port):
     from . import config
-    config.set_feature_dtype(torch.bfloat16 if args.feature_dtype == "bf16" else torch.float32)
+    config.set_feature_dtype(torch.float32 if args.feature_dtype == "f32" else torch.bfloat16)
+    config.set_conv_operands("fp8" if args.feature_dtype == "fp8" else "bf16")
     loader.load_worker(local_rank, args, gpus, port)
 
 

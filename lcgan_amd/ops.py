@@ -106,7 +106,10 @@ def _prep_group(grp) -> None:
         rec = _recipes.get(id(p)) if p is not None else None
         if rec is None or rec[0]() is not p:
             continue
-        for (scale, transpose, need_lo), want_wsq in rec[1].items():
+        for key, want_wsq in rec[1].items():
+            if key[3]:
+                continue                                             # MX-fp8 copies are rebuilt one by one (their own kernel)
+            scale, transpose, need_lo, _ = key
             jobs.append((p, scale, transpose, need_lo, want_wsq))
             owners.append(p)
     if len(jobs) < 2:
@@ -116,15 +119,17 @@ def _prep_group(grp) -> None:
         if ent is None or ent[0]() is not p or ent[1] != p._version or ent[2] != _weight_epoch:
             ent = [weakref.ref(p), p._version, _weight_epoch, {}]
             _prep_cache[id(p)] = ent
-        ent[3][(scale, transpose, need_lo)] = hit
+        ent[3][(scale, transpose, need_lo, False)] = hit
 
 
-def _prep(w: Tensor, scale: float, transpose: bool, need_lo: bool, want_wsq: bool = False):
+def _prep(w: Tensor, scale: float, transpose: bool, need_lo: bool, want_wsq: bool = False, fp8: bool = False):
+    """-> (prepared weight, wsq | None); fp8: the MX-fp8 copy (kernels.PreparedWeightFp8) instead of the bf16 one"""
     import weakref
     K = _K()
+    build = (lambda ww: (K.prep_weight_fp8(w, scale, transpose), None)) if fp8 else (lambda ww: K.prep_weight(w, scale, transpose, need_lo, ww))
     if not isinstance(w, torch.nn.Parameter):
-        return K.prep_weight(w, scale, transpose, need_lo, want_wsq)
-    key = (float(scale), bool(transpose), bool(need_lo))
+        return build(want_wsq)
+    key = (float(scale), bool(transpose), bool(need_lo), bool(fp8))
     ent = _prep_cache.get(id(w))
     valid = ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == _weight_epoch
     hit = ent[3].get(key) if valid else None
@@ -153,9 +158,17 @@ def _prep(w: Tensor, scale: float, transpose: bool, need_lo: bool, want_wsq: boo
             _prep_cache.clear()
         ent = [weakref.ref(w), w._version, _weight_epoch, {}]
         _prep_cache[id(w)] = ent
-    hit = K.prep_weight(w, scale, transpose, need_lo, want_wsq or (hit is not None and hit[1] is not None))
+    hit = build(want_wsq or (hit is not None and hit[1] is not None))
     ent[3][key] = hit
     return hit
+
+
+def _use_fp8(x: Tensor, k: int, stride: int) -> bool:
+    """MX-fp8 operands for this convolution launch?  (config.conv_operands() == "fp8": BASELINE configs[4]; the stride-1 3x3 / 1x1 forward
+    and data-gradient launches on grids of at least 16 x 16 positions -- 60 % of the step's FLOPs; everything else stays bf16)"""
+    from . import config
+    return (config.conv_operands() == "fp8" and x.dtype == torch.bfloat16 and stride == 1 and x.shape[1] >= 16 and x.shape[2] >= 16
+            and x.shape[3] >= 64)
 
 
 # =====================================================================================================
@@ -170,8 +183,12 @@ class Conv2dFn(Function):
         assert act != ACT_NONE or gain == 1.0, "fold the gain of an act-free conv into wscale"
         K = _K()
         A = w.shape[0]
-        pw, _ = _prep(w, wscale, False, _need_lo(x))
-        y = K.conv_fwd(x, pw, A, k, stride, bias=bias, bias_scale=bias_scale, act=act, gain=gain, residual=residual)
+        if _use_fp8(x, k, stride):
+            pw, _ = _prep(w, wscale, False, False, fp8=True)
+            y = K.conv_fwd_fp8(x, pw, A, k, stride, bias=bias, bias_scale=bias_scale, act=act, gain=gain, residual=residual)
+        else:
+            pw, _ = _prep(w, wscale, False, _need_lo(x))
+            y = K.conv_fwd(x, pw, A, k, stride, bias=bias, bias_scale=bias_scale, act=act, gain=gain, residual=residual)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.cfg = (k, stride, act, gain, wscale, bias_scale, bias is not None, residual is not None)
         return y
@@ -200,8 +217,12 @@ class ConvTransposeFn(Function):
     @staticmethod
     def forward(ctx, g, w, k, stride, wscale, cin_alloc, res_half):
         K = _K()
-        pw, _ = _prep(w, wscale, True, _need_lo(g))
-        gx = K.conv_bwd_data(g, pw, w.shape[1], k, stride, residual=res_half, residual_half=res_half is not None)
+        if _use_fp8(g, k, stride):
+            pw, _ = _prep(w, wscale, True, False, fp8=True)
+            gx = K.conv_bwd_data_fp8(g, pw, w.shape[1], k, stride, residual=res_half, residual_half=res_half is not None)
+        else:
+            pw, _ = _prep(w, wscale, True, _need_lo(g))
+            gx = K.conv_bwd_data(g, pw, w.shape[1], k, stride, residual=res_half, residual_half=res_half is not None)
         assert gx.shape[-1] == cin_alloc
         ctx.save_for_backward(g, w)
         ctx.cfg = (k, stride, wscale)
@@ -228,8 +249,12 @@ class ConvPoolFn(Function):
     @staticmethod
     def forward(ctx, x, w, bias, k, act, gain, wscale, bias_scale, box):
         K = _K()
-        pw, _ = _prep(w, wscale, False, _need_lo(x))
-        y = K.conv_fwd(x, pw, w.shape[0], k, 1, bias=bias, bias_scale=bias_scale, act=act, gain=gain)
+        if _use_fp8(x, k, 1):
+            pw, _ = _prep(w, wscale, False, False, fp8=True)
+            y = K.conv_fwd_fp8(x, pw, w.shape[0], k, 1, bias=bias, bias_scale=bias_scale, act=act, gain=gain)
+        else:
+            pw, _ = _prep(w, wscale, False, _need_lo(x))
+            y = K.conv_fwd(x, pw, w.shape[0], k, 1, bias=bias, bias_scale=bias_scale, act=act, gain=gain)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.cfg = (k, act, gain, wscale, bias_scale, bias is not None, box)
         return (K.box3_act(y, ACT_NONE, 1.0) if box else y), K.avgpool2(x)
@@ -632,6 +657,9 @@ class ModConvFn(Function):
         d = K.demod_fwd(s, wsq, ceil8(O))
         if up == 2:
             y = K.conv_bwd_data(x, pw, O, k, 2, pre=s, post=d, bias=bias, bias_scale=1.0, act=act, gain=gain)
+        elif _use_fp8(x, k, 1):
+            pw8, _ = _prep(w, c_eq, False, False, fp8=True)
+            y = K.conv_fwd_fp8(x, pw8, O, k, 1, pre=s, post=d, bias=bias, bias_scale=1.0, act=act, gain=gain)
         else:
             y = K.conv_fwd(x, pw, O, k, 1, pre=s, post=d, bias=bias, bias_scale=1.0, act=act, gain=gain)
         ctx.save_for_backward(x, w, bias, s, d, wsq, y)

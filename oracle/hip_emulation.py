@@ -155,6 +155,47 @@ class EmulatedKernels:
             return self._sr(nhwc(v, torch.float32, ceil8(N)), post, xs, g.dtype)
         return self._epilogue(v, N, post, bias, bias_scale, act, gain, residual, g.dtype)
 
+    # ---- MX-fp8 convolution path (csrc/conv_fp8.hip): the same quantisation rule, then exact fp32 products --------------------
+    @staticmethod
+    def mx_quant(t, dim):
+        """Quantise `t` along `dim` in blocks of 32 like the kernels: power-of-two block scale 2^ex with max|.| / 448 = f 2^ex,
+        f in [0.5, 1) (so the block maximum lands in [224, 448)), e4m3 round-to-nearest-even; returns the DEQUANTISED tensor."""
+        t = t.float().movedim(dim, -1)
+        n = t.shape[-1]
+        pad = (-n) % 32
+        tp = F.pad(t, (0, pad)).reshape(*t.shape[:-1], (n + pad) // 32, 32)
+        m = tp.abs().amax(dim=-1, keepdim=True)
+        _, ex = torch.frexp(m * (1.0 / 448.0))
+        ex = torch.where(m > 0, ex, torch.zeros_like(ex)).clamp(-126, 127)
+        scale = torch.ldexp(torch.ones_like(m), ex)
+        q = (tp / scale).to(torch.float8_e4m3fn).float() * scale
+        return q.reshape(*t.shape[:-1], n + pad)[..., :n].movedim(-1, dim)
+
+    def prep_weight_fp8(self, w, scale, transpose):
+        ws = w.detach().float() * scale
+        P4 = ws.transpose(0, 1).contiguous() if transpose else ws            # [N][Kc][k][k]
+        return EmuWeight(self.mx_quant(P4, 1), P4.shape[0], (P4.shape[1] + 63) // 64 * 64, w.shape[-1], False)
+
+    def conv_fwd_fp8(self, x, pw, N, k, stride, pre=None, post=None, bias=None, bias_scale=1.0, act=ACT_NONE, gain=1.0, residual=None,
+                     residual_half=False):
+        residual = self._res(residual, residual_half)
+        Kc = pw.P4.shape[1]
+        xin = nchw(x)[:, :Kc]
+        if pre is not None:
+            xin = xin * pre[:, :Kc, None, None]
+        v = F.conv2d(self.mx_quant(xin, 1), pw.P4, stride=stride, padding=k // 2)
+        return self._epilogue(v, N, post, bias, bias_scale, act, gain, residual, x.dtype)
+
+    def conv_bwd_data_fp8(self, g, pw, N, k, stride, pre=None, post=None, bias=None, bias_scale=1.0, act=ACT_NONE, gain=1.0, residual=None,
+                          residual_half=False):
+        residual = self._res(residual, residual_half)
+        Kc = pw.P4.shape[1]
+        gs = nchw(g)[:, :Kc]
+        if pre is not None:
+            gs = gs * pre[:, :Kc, None, None]
+        v = F.conv_transpose2d(self.mx_quant(gs, 1), pw.P4.permute(1, 0, 2, 3), stride=stride, padding=k // 2, output_padding=stride - 1)
+        return self._epilogue(v, N, post, bias, bias_scale, act, gain, residual, g.dtype)
+
     def conv_wgrad(self, x, g, A, Bc, k, stride, pre_x=None, pre_g=None):
         # exact math: the row-segment kernel applies the per-sample scales in fp32 on the accumulator; the generic kernel
         # scales the staged operands (one extra bf16 rounding in bf16 mode, covered by the test tolerance)

@@ -488,3 +488,54 @@ def test_qr_householder(H, n):
     check(Qg, Qr, torch.float32, "Q")
     check(Rg, Rr, torch.float32, "R")
     assert (torch.sign(torch.diagonal(Rg.cpu())) == torch.sign(torch.diagonal(Rr))).all()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# MX-fp8 convolution path (csrc/conv_fp8.hip, BASELINE configs[4]).  Two checks per case:
+#  (1) against the CPU emulation that quantises with the SAME rule (oracle/hip_emulation.py:mx_quant): products are exact in fp32,
+#      so only the summation order and the final bf16 rounding differ -- the bf16 tolerances of the other conv tests apply; this pins
+#      the operand layout, the block scales and every tap / phase / epilogue variant;
+#  (2) against the UNQUANTISED convolution: the stated precision of the path.  e4m3 keeps 3 mantissa bits (relative rounding error
+#      <= 2^-4 per operand, uniform on average 2^-5), and a K-term dot product of independent errors comes out at ~3-4 % of the
+#      output's RMS: bound 6e-2 relative L2.
+FP8_CASES = [
+    # B, H, W, Cin, Cout, k, stride
+    (2, 32, 32, 64, 128, 3, 1),
+    (1, 64, 64, 128, 128, 3, 1),
+    (2, 32, 32, 192, 96, 3, 2),      # Cin not a multiple of 128, Cout ragged
+    (2, 16, 32, 72, 24, 3, 1),       # Cin not a multiple of 64 (zero-padded MX block), ragged tile
+    (2, 32, 32, 128, 256, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", FP8_CASES)
+def test_conv_fp8(H, case):
+    B, Hh, W, Ci, Co, k, stride = case
+    dtype = torch.bfloat16
+    x = feat((B, Hh, W, ceil8(Ci)), dtype, 31, Ci)
+    w = torch.randn(Co, Ci, k, k, generator=torch.Generator().manual_seed(32))
+    bias = torch.randn(Co, generator=torch.Generator().manual_seed(33))
+    scale = 1 / math.sqrt(Ci * k * k)
+    pw_e, pw_h = E.prep_weight_fp8(w, scale, False), H.prep_weight_fp8(w.cuda(), scale, False)
+    pre, post = vec((B, ceil8(Ci)), 34), vec((B, ceil8(Co)), 35)
+    res = feat((B, Hh // stride, W // stride, ceil8(Co)), dtype, 36, Co)
+    variants = [dict(), dict(bias=bias, bias_scale=0.5, act=1, gain=1.4), dict(pre=pre, post=post, bias=bias, act=1), dict(residual=res)]
+    if stride == 1:                                                          # (the stride-2 forward conv stays on the bf16 kernel)
+        for kw in variants:
+            got = H.conv_fwd_fp8(x.cuda(), pw_h, Co, k, 1, **{a: dev(b) if isinstance(b, torch.Tensor) else b for a, b in kw.items()})
+            check(got, E.conv_fwd_fp8(x, pw_e, Co, k, 1, **kw), dtype, f"fp8 fwd {sorted(kw)}")
+        # precision against the unquantised convolution
+        pw_ref, _ = E.prep_weight(w, scale, False, True)
+        ref = E.conv_fwd(x.float(), pw_ref, Co, k, 1).float()
+        got = H.conv_fwd_fp8(x.cuda(), pw_h, Co, k, 1).float().cpu()
+        err = float((got - ref).norm() / ref.norm())
+        assert err <= 6e-2, err
+    # data gradient / transposed convolution (g on the strided grid)
+    if not (stride == 2 and k != 3):
+        Hg, Wg = Hh // stride, W // stride
+        g = feat((B, Hg, Wg, ceil8(Co)), dtype, 37, Co, scale=1e-3)            # gradient-sized values: the block scales carry them
+        pwT_e, pwT_h = E.prep_weight_fp8(w, scale, True), H.prep_weight_fp8(w.cuda(), scale, True)
+        rh = feat((B, Hg * stride // 2, Wg * stride // 2, ceil8(Ci)), dtype, 38, Ci, scale=1e-3)
+        for kw in (dict(), dict(pre=post, post=pre), dict(residual=rh, residual_half=True)):
+            got = H.conv_bwd_data_fp8(g.cuda(), pwT_h, Ci, k, stride, **{a: dev(b) if isinstance(b, torch.Tensor) else b for a, b in kw.items()})
+            check(got, E.conv_bwd_data_fp8(g, pwT_e, Ci, k, stride, **kw), dtype, f"fp8 dgrad {sorted(kw)}")

@@ -2,9 +2,10 @@
 with (a) the golden vectors captured from the reference (tests/golden/*.npz) and (b) the CPU oracle on the same inputs.
 
 Tolerances: parity mode (f32 features, 3-way bf16 split MFMA) 1e-3 relative -- BASELINE.json's north_star tolerance --
-on outputs / losses (max-abs relative) and on gradients through the kink-robust statistics of tests/helpers.py; bf16 features (the benchmark dtype) are
-compared with the oracle at 5e-2 on losses / relative-L2 0.15 on gradients (bf16 has 8 mantissa bits: 2^-9 per rounding,
-accumulated over ~40 layers and the backward pass)."""
+on outputs / losses (max-abs relative) and on gradients through the kink-robust statistics of tests/helpers.py, where a tensor above
+1e-3 must be EXPLAINED by recorded activation-mask flips against the CPU chain (tests/dual_backend.py); bf16 features (the benchmark
+dtype) are compared with the oracle at 2e-3 on losses / 1e-2 on the R1 value / relative-L2 0.10 on gradients (achieved: 2e-4 / 2e-3 /
+0.03-0.05; bf16 has 8 mantissa bits: 2^-9 per rounding, accumulated over ~40 layers and the backward pass)."""
 import os
 
 import numpy as np
@@ -202,12 +203,24 @@ def _oracle_step(res, B, epoch, feed):
     return O.g_step(GP, DP, res, epoch, tuple(z)), O.d_step(GP, DP, res, epoch, (z[0], z[1]), real)
 
 
-@pytest.mark.parametrize("dtype,loss_tol,grad_l2", [(torch.float32, 1e-3, 2e-3), (torch.bfloat16, 5e-2, 0.15)])
+# bf16 (the benchmark dtype) against the fp32 oracle: achieved on the MI355X (profiles/r02_parity_achieved.json) losses 2e-4, R1 value
+# 2e-3, relative L2 of ALL gradients 0.03 (G) / 0.05 (D) -- 8 mantissa bits per stored activation over ~40 layers and a double backward.
+# The bounds below are 2-3x the achieved values; the 1e-3 north-star tolerance is held by the f32 parity mode.
+# "fp8" (BASELINE configs[4]): bf16 feature maps, MX-fp8 (e4m3 + one power-of-two scale per 32 channels) operands on the stride-1
+# forward / data-gradient convolutions with grids >= 16 x 16.  Stated tolerance of the path: losses 1e-2, R1 value 0.1, relative L2 of
+# all gradients 0.30 (achieved on the MI355X: 3e-3 / 5e-4 / 0.13-0.16; 3 mantissa bits per operand = ~4 % per convolution output,
+# through ~20 quantised convolutions and the double backward).
+@pytest.mark.parametrize("dtype,loss_tol,grad_l2", [(torch.float32, 1e-3, 2e-3), (torch.bfloat16, 2e-3, 0.10), ("fp8", 1e-2, 0.30)])
 def test_r1_iteration_64_vs_oracle(dtype, loss_tol, grad_l2):
-    """One odd+R1 iteration (BASELINE config 2's iteration type) at 64x64, batch 8, against the oracle, both dtypes."""
+    """One odd+R1 iteration (BASELINE config 2's iteration type) at 64x64, batch 8, against the oracle: f32 parity mode, bf16, MX-fp8."""
     from lcgan_amd import config
+    import contextlib
     res, B = 64, 8
-    with config.feature_dtype_as(dtype):
+    operands = "fp8" if dtype == "fp8" else "bf16"
+    dtype = torch.bfloat16 if dtype == "fp8" else dtype
+    with contextlib.ExitStack() as stack:
+        stack.enter_context(config.feature_dtype_as(dtype))
+        stack.enter_context(config.conv_operands_as(operands))
         w = seeded_worker(res, B, DEV)
         feed = FixedFeed(w, B, res, DEV)
         w.g_optimizer.step = lambda: None
@@ -230,14 +243,14 @@ def test_r1_iteration_64_vs_oracle(dtype, loss_tol, grad_l2):
         return (num / den) ** 0.5
     eg, ed = l2(w.generator.module.named_parameters(), g_grads), l2(w.discriminator.module.named_parameters(), d_grads)
     from lcgan_amd import loss
-    with config.feature_dtype_as(dtype):                        # the R1 value alone (it is < 1 % of d_loss)
+    with config.feature_dtype_as(dtype), config.conv_operands_as(operands):     # the R1 value alone (it is < 1 % of d_loss)
         img = feed.real[0].clone().requires_grad_(True)
         r1 = float(loss.cal_r1_reg(w.discriminator(img, False)[0], img))
     r1_rel = abs(r1 - float(parts["r1"])) / abs(float(parts["r1"]))
-    record(f"r1_iteration_64_{'bf16' if dtype == torch.bfloat16 else 'f32'}", g_loss_rel=abs(g_loss - float(g_ref)) / abs(float(g_ref)),
+    record(f"r1_iteration_64_{operands if operands == 'fp8' else 'bf16' if dtype == torch.bfloat16 else 'f32'}", g_loss_rel=abs(g_loss - float(g_ref)) / abs(float(g_ref)),
            d_loss_rel=abs(d_loss - float(d_ref)) / abs(float(d_ref)), g_grad_l2=eg, d_grad_l2=ed, r1_rel=r1_rel)
     assert eg <= grad_l2 and ed <= grad_l2, (eg, ed)
-    assert r1_rel <= (1e-3 if dtype == torch.float32 else 5e-2), (r1, float(parts["r1"]))
+    assert r1_rel <= (1e-3 if dtype == torch.float32 else 0.1 if operands == "fp8" else 1e-2), (r1, float(parts["r1"]))
 
 
 def test_full_size_properties_256():
