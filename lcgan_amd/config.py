@@ -69,7 +69,8 @@ def default_args(res=32, batch=8, **kw):
         app_noise_dim=64, max_flow_scale=0.1, geo_projection_dim=256, app_projection_dim=256, tau=0.05, l_adv=1.0, l_aux=0.5,
         l_r1=10.0, l_s=1e-7, g_lr=0.002, d_lr=0.002, beta1=0.0, beta2=0.99, g_ema_decay=0.9999, g_ema_start=0,
         freezeD_start=100000, freezeD_layer=5, dataset_path="synthetic", model_name="", save_dir="model", sample_dir="samples",
-        best=False, epoch=1, print_interval=100, save_interval=5000, show_interval=1000)
+        best=False, epoch=1, print_interval=100, save_interval=5000, show_interval=1000, psi=2.0, w_psi=1.0, num_fakes=10,
+        ctrl_dim=-1, num_videos=10, img_ch=3)
     for k, v in kw.items():
         setattr(a, k, v)
     return a

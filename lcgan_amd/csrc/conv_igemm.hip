@@ -314,6 +314,10 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
   const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
   const TapTable& tt = a.taps[phase];
   const int hy0 = a.hy0[phase], hx0 = a.hx0[phase], hh = a.hh[phase], hw = a.hw[phase];
+  // LDS pitch of a halo ROW in elements: a multiple of 256 bytes.  A wave's 32 fragment rows are 2 image rows of 16 pixels; with the
+  // second row a whole number of bank rows below the first, the fixed lane groups of ds_read_b128 see the same conflict-free
+  // pattern as 32 consecutive pixels (at the natural pitch hw * 80 B every A read was a 2-way bank conflict)
+  const int rp = (hw * HROW + 127) & ~127;
   const int gy0 = ty * HT * IN_MUL + hy0, gx0 = tx * HT * IN_MUL + hx0;     // input pixel of halo (0,0)
 
   // ---- halo items of this thread (fixed for the whole K loop; only the channel chunk moves) -------------------------
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
     if (hp < hh * hw) {
       const int hy = hp / hw, hx = hp - hy * hw;
       const int gy = gy0 + hy, gx = gx0 + hx;
-      loff[k] = hp * HROW + hvec * 8;
+      loff[k] = hy * rp + hx * HROW + hvec * 8;
       if ((unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win) goff[k] = ((b * a.Hin + gy) * a.Win + gx) * a.Cin + hvec * 8;
     }
   }
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
 #pragma unroll
   for (int mi = 0; mi < NM; ++mi) {
     const int r = wm * 64 + mi * RS + lrow;
-    abase[mi] = (((r >> 4) * IN_MUL) * hw + (r & 15) * IN_MUL) * HROW + lk;
+    abase[mi] = ((r >> 4) * IN_MUL) * rp + (r & 15) * IN_MUL * HROW + lk;
   }
   const int bbase = (wn * 64 + lrow) * HROW + lk;
 
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
   auto step = [&](int q, bf16x8& rs, bf16x8& rl) {
     if (t == 0 && c + 1 < nchunks) halo_load((c + 1) * BK);    // next chunk's halo: in flight during this chunk's taps
     if (q + 2 < total) { rl = b_load(lc, lt); advance(); }
-    const int toff = ((tt.dy[t] - hy0) * hw + (tt.dx[t] - hx0)) * HROW;
+    const int toff = (tt.dy[t] - hy0) * rp + (tt.dx[t] - hx0) * HROW;
     const __bf16* Bc = Bt + (q & 1) * TILE;
     if (M16) {
       bf16x8 af[4], bf[4];
@@ -750,16 +754,22 @@ __global__ __launch_bounds__(512, RW == 2 ? 4 : 2) void conv_halo_narrow_kernel(
 
 // fp32 scratch of the split-K paths ([output pixel][Cout] partial sums met by atomics).  Grow-only, owned by the library,
 // zeroed once when allocated: conv_finalize_kernel re-zeroes what it consumes, so launches need no memset.
-float* g_splitk_ws = nullptr;
-size_t g_splitk_ws_bytes = 0;
+// One scratch per DEVICE (a process drives one GPU in this package, but nothing here assumes it); the split-K protocol -- the
+// finalize kernel re-zeroes what it consumed -- additionally assumes that the convolutions of one device are issued on ONE stream
+// (the launch stream of the training step), which lcgan_amd guarantees.
+constexpr int MAX_DEV = 16;
+float* g_splitk_ws[MAX_DEV] = {};
+size_t g_splitk_ws_bytes[MAX_DEV] = {};
 float* splitk_scratch(size_t bytes, hipStream_t s) {
-  if (bytes > g_splitk_ws_bytes) {
-    if (g_splitk_ws) hipFree(g_splitk_ws);
-    g_splitk_ws_bytes = std::max(bytes, (size_t)8 << 20);
-    if (hipMalloc((void**)&g_splitk_ws, g_splitk_ws_bytes) != hipSuccess) { g_splitk_ws = nullptr; g_splitk_ws_bytes = 0; return nullptr; }
-    hipMemsetAsync(g_splitk_ws, 0, g_splitk_ws_bytes, s);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  if (bytes > g_splitk_ws_bytes[dev]) {
+    if (g_splitk_ws[dev]) hipFree(g_splitk_ws[dev]);
+    g_splitk_ws_bytes[dev] = std::max(bytes, (size_t)8 << 20);
+    if (hipMalloc((void**)&g_splitk_ws[dev], g_splitk_ws_bytes[dev]) != hipSuccess) { g_splitk_ws[dev] = nullptr; g_splitk_ws_bytes[dev] = 0; return nullptr; }
+    hipMemsetAsync(g_splitk_ws[dev], 0, g_splitk_ws_bytes[dev], s);
   }
-  return g_splitk_ws;
+  return g_splitk_ws[dev];
 }
 template <typename T>
 __global__ void conv_finalize_kernel(float* __restrict__ ws, T* __restrict__ y, const float* __restrict__ post,
@@ -835,7 +845,7 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   a.Hm = c.Hm; a.Wm = c.Wm; a.N = c.N; a.Kpad = c.Kpad; a.kc_per_tap = c.kc_per_tap; a.out_mul = c.out_mul;
   a.tiles_x = cdiv(c.Wm, HT); a.tiles_y = cdiv(c.Hm, HT);
   a.bias_scale = c.bias_scale; a.gain = c.gain; a.act = c.act;
-  int max_halo = 0;
+  int max_halo = 0, max_halo_elems = 0;
   for (int p = 0; p < nphase; ++p) {
     a.taps[p] = c.taps[p];
     int ymin = 99, ymax = -99, xmin = 99, xmax = -99;
@@ -846,13 +856,14 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
     a.hy0[p] = ymin; a.hx0[p] = xmin;
     a.hh[p] = (HT - 1) * in_mul + (ymax - ymin) + 1; a.hw[p] = (HT - 1) * in_mul + (xmax - xmin) + 1;
     max_halo = std::max(max_halo, a.hh[p] * a.hw[p]);
+    max_halo_elems = std::max(max_halo_elems, a.hh[p] * ((a.hw[p] * HROW + 127) & ~127));    // rows padded to 256 B (see the kernel)
   }
   if (max_halo * 4 > (in_mul == 1 ? 3 : 9) * 512) return false;
   // a launch that cannot cover half the CUs (small local batch x low resolution: 16..64 tiles, each walking the full K =
   // 9*Cin reduction) goes to the split-K implicit GEMM instead, which spreads the reduction over ~256 workgroups
   const int halo_wgs = c.B * a.tiles_x * a.tiles_y * cdiv(c.Cout, BN) * nphase;
   if (g_use_splitk && halo_wgs < g_halo_min_wgs && c.taps[0].n * c.kc_per_tap >= 8) return false;
-  a.halo_elems = max_halo * HROW;
+  a.halo_elems = max_halo_elems;
   const size_t smem = std::max(((size_t)a.halo_elems + 2 * TILE) * sizeof(__bf16) + (size_t)c.Kpad * sizeof(float),
                                (size_t)256 * (BN + 8) * sizeof(__bf16) + BN * sizeof(float));
   dim3 grid(c.B * a.tiles_x * a.tiles_y, cdiv(c.Cout, BN), nphase);
@@ -1210,15 +1221,17 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
   gwp[i] = acc;
 }
 
-float* g_slab = nullptr;
-size_t g_slab_bytes = 0;
-float* wgrad_slab_scratch(size_t bytes) {          // grow-only, owned by the library; every element is written before it is read
-  if (bytes > g_slab_bytes) {
-    if (g_slab) hipFree(g_slab);
-    g_slab_bytes = std::max(bytes, (size_t)64 << 20);
-    if (hipMalloc((void**)&g_slab, g_slab_bytes) != hipSuccess) { g_slab = nullptr; g_slab_bytes = 0; return nullptr; }
+float* g_slab[MAX_DEV] = {};
+size_t g_slab_bytes[MAX_DEV] = {};
+float* wgrad_slab_scratch(size_t bytes) {          // grow-only, per device, owned by the library; every element is written before it is read
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  if (bytes > g_slab_bytes[dev]) {
+    if (g_slab[dev]) hipFree(g_slab[dev]);
+    g_slab_bytes[dev] = std::max(bytes, (size_t)64 << 20);
+    if (hipMalloc((void**)&g_slab[dev], g_slab_bytes[dev]) != hipSuccess) { g_slab[dev] = nullptr; g_slab_bytes[dev] = 0; return nullptr; }
   }
-  return g_slab;
+  return g_slab[dev];
 }
 
 // =========================================================================================================

@@ -278,6 +278,29 @@ class WORKER(object):
         no activation is kept beyond its consumer."""
         return self.generator_ema(geometry_code, appearance_code, float(self.args.w_psi if w_psi is None else w_psi))
 
+    def fid_evaluate(self, feature_extractor, num_batches=None):
+        """worker.py:381-425 with the feature network passed in (lcgan_amd/fid.py): features of `num_batches` real batches vs as many
+        batches of generator_ema(randn, randn, w_psi); returns the FID and tracks best_fid in the train phase."""
+        import numpy as np
+        from . import fid
+        if num_batches is None:
+            n = min(len(getattr(self.data, "files", ())) or 50000, 50000)
+            num_batches = max(n // self.local_batch_size, 1)
+        real, fake = [], []
+        with torch.no_grad():
+            for _ in range(num_batches):
+                image = self.sample_data_basket()[0]
+                real.append(feature_extractor(image).reshape(image.shape[0], -1).float().cpu())
+            for _ in range(num_batches):
+                img = self.generate(self._randn(self.args.geo_noise_dim), self._randn(self.args.app_noise_dim))
+                fake.append(feature_extractor(img).reshape(img.shape[0], -1).float().cpu())
+        sm, sc = fid.feature_statistics(torch.cat(fake, 0).numpy())
+        rm, rc = fid.feature_statistics(torch.cat(real, 0).numpy())
+        value = fid.calc_fid(sm, sc, rm, rc)
+        if value < self.best_fid and getattr(self.args, "phase", "train") == "train":
+            self.best_fid = value
+        return value
+
     def fake_image_generation(self, num_images=50):
         """worker.py:427-441: `num_images` files, each the local batch stacked in one column (save_image(nrow=1, padding=0))."""
         from .data import save_image_column

@@ -354,6 +354,23 @@ def freeze_fixtures(CNN, LOSS):
     np.savez_compressed(os.path.join(OUT, "freeze_sets.npz"), **d)
 
 
+def fid_fixture():
+    """eval/fid.py:4-27 on seeded feature sets (incl. a rank-deficient one that takes the eps branch or a complex root)."""
+    sys.path.insert(0, REF)
+    from eval import fid as RF
+    d = {}
+    for name, (n, f, shift) in {"a": (400, 24, 0.3), "b": (64, 24, 1.0), "c": (12, 24, 0.0)}.items():
+        x = seeded_tensor((n, f), 4000 + n).double().numpy()
+        y = (seeded_tensor((n, f), 4100 + n).double() * 1.3 + shift).numpy()
+        try:
+            v = float(RF.calc_fid(x.mean(0), np.cov(x, rowvar=False), y.mean(0), np.cov(y, rowvar=False)))
+        except ValueError:
+            v = float("nan")
+        d[f"{name}/n"], d[f"{name}/f"], d[f"{name}/shift"], d[f"{name}/fid"] = np.int64(n), np.int64(f), np.float64(shift), np.float64(v)
+        print("fid", name, v)
+    np.savez_compressed(os.path.join(OUT, "fid.npz"), **d)
+
+
 def main():
     assert os.path.isdir(REF), "the reference only exists in the build container"
     os.makedirs(OUT, exist_ok=True)
@@ -365,6 +382,7 @@ def main():
     forward_fixtures(CNN, res=512, B=1, stride=32)
     forward_fixtures(CNN, res=1024, B=1, stride=64)
     freeze_fixtures(CNN, LOSS)
+    fid_fixture()
 
 
 if __name__ == "__main__":

@@ -307,3 +307,28 @@ def test_prepared_weights_are_rebuilt_in_groups_after_an_optimiser_step():
         assert torch.equal(pw.P4, ref.P4)
     finally:
         be.prep_weight, be.prep_weight_group = single, group
+
+
+def test_fid_statistics_vs_reference():
+    """lcgan_amd.fid.calc_fid against values computed by the reference's eval/fid.py (tests/golden/fid.npz, oracle/make_golden.py)."""
+    from lcgan_amd import fid
+    Fz = np.load(os.path.join(GOLD, "fid.npz"))
+    for name in ("a", "b", "c"):
+        n, f, shift = int(Fz[f"{name}/n"]), int(Fz[f"{name}/f"]), float(Fz[f"{name}/shift"])
+        x = seeded_tensor((n, f), 4000 + n).double().numpy()
+        y = (seeded_tensor((n, f), 4100 + n).double() * 1.3 + shift).numpy()
+        ref = float(Fz[f"{name}/fid"])
+        if np.isnan(ref):
+            with pytest.raises(ValueError):
+                fid.calc_fid(*fid.feature_statistics(x), *fid.feature_statistics(y))
+        else:
+            got = fid.calc_fid(*fid.feature_statistics(x), *fid.feature_statistics(y))
+            assert abs(got - ref) <= 1e-6 * max(abs(ref), 1.0), (name, got, ref)
+
+
+def test_fid_evaluate_with_a_pluggable_feature_network(tmp_path):
+    """WORKER.fid_evaluate (worker.py:381-425) with a stand-in feature extractor (mean-pooled image patches)."""
+    w = seeded_worker(16, 4, "cpu")
+    extractor = lambda img: torch.nn.functional.avg_pool2d(img.float(), 4).flatten(1)[:, :12]
+    v = w.fid_evaluate(extractor, num_batches=6)
+    assert np.isfinite(v) and v > 0 and w.best_fid == v
