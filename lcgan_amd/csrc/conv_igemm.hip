@@ -291,6 +291,18 @@ struct HaloArgs {
   int dbg;                                   // option 3, bit 8: linear instead of XCD-contiguous tile order
 };
 
+#ifdef HALO_STAMPS
+// diagnostic build (scripts/halo_stamps.py; never the shipped library): per wave of the first 2048 workgroups, cycle sums of the four
+// segments of a main-loop step -- [barrier exit -> fragments landed] [MFMA issue] [tile store -> barrier arrival] [barrier wait]
+__device__ unsigned long long g_halo_stamps[2048 * 8 * 5];
+#define STAMP(var)                                                                                                  \
+  __builtin_amdgcn_sched_barrier(0);                                                                                \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                                       \
+  __builtin_amdgcn_sched_barrier(0);
+#else
+#define STAMP(var)
+#endif
+
 // EPI selects the epilogue at compile time: 0 = plain, 1 = + residual, 2 = + 0.25 * half-resolution residual, 3 = style-gradient
 // reduction (gs += sum xs * acc).  As run-time branches the last two cost every launch 5-7 % on the short-K top layer (measured
 // with scripts/ab_raw.py against the builds that preceded them).
@@ -301,7 +313,8 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
   constexpr int NI = IN_MUL == 1 ? 3 : 9;     // halo (pixel, 8-channel vector) items per thread: ceil(hh*hw*4 / 512)
   __bf16* halo = (__bf16*)smem;
   __bf16* Bt = halo + a.halo_elems;           // 2 x [128][HROW]
-  float* psc = (float*)(Bt + 2 * TILE);       // [Kpad] style scales of this workgroup's sample (modulated convs; zero beyond Cin)
+  constexpr bool PAIR = IN_MUL == 2 && !M16;   // two taps per step (below): where one workgroup fits per CU
+  float* psc = (float*)(Bt + (PAIR ? 4 : 2) * TILE);       // [Kpad] style scales of this workgroup's sample (modulated convs; zero beyond Cin)
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -322,16 +335,22 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
 
   // ---- halo items of this thread (fixed for the whole K loop; only the channel chunk moves) -------------------------
   const int hvec = tid & 3;
-  int goff[NI], loff[NI];
+  // (global loads are raw buffer loads: resource in scalar registers, a 32-bit BYTE offset per lane, the moving part -- channel
+  //  chunk, tap -- as the scalar offset; no 64-bit address lives in vector registers and a lane outside the image / the weight
+  //  rows reads zeros by the range check instead of a branch.  Tensors are < 2^31 elements, checked by the caller)
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(2u * (unsigned)(a.B * a.Hin * a.Win * a.Cin)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
+  unsigned goff[NI];
+  int loff[NI];
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
     const int hp = (tid >> 2) + k * 128;
-    loff[k] = -1; goff[k] = -1;
+    loff[k] = -1; goff[k] = 0xffffffffu;
     if (hp < hh * hw) {
       const int hy = hp / hw, hx = hp - hy * hw;
       const int gy = gy0 + hy, gx = gx0 + hx;
       loff[k] = hy * rp + hx * HROW + hvec * 8;
-      if ((unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win) goff[k] = ((b * a.Hin + gy) * a.Win + gx) * a.Cin + hvec * 8;
+      if ((unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win) goff[k] = 2u * (unsigned)(((b * a.Hin + gy) * a.Win + gx) * a.Cin + hvec * 8);
     }
   }
   bf16x8 hreg[NI];
@@ -344,8 +363,8 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
     h_c0 = c0;
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
-      const bool ok = goff[k] >= 0 && c0 + hvec * 8 < a.Cin;
-      hreg[k] = ok ? *(const bf16x8*)(a.x + (size_t)goff[k] + c0) : zero_bf16x8();
+      const unsigned go = c0 + hvec * 8 < a.Cin ? goff[k] : 0xffffffffu;       // out of range -> the buffer load returns zeros
+      hreg[k] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xres, go, __builtin_amdgcn_readfirstlane(c0 * 2), 0));
     }
   };
   auto halo_store = [&]() {
@@ -361,15 +380,11 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
       if (loff[k] >= 0) *(bf16x8*)(halo + loff[k]) = hreg[k];
   };
 
-  // ---- weight tile: 128 rows x 4 vectors = 512 items, one per thread; prefetched TWO taps ahead in two named registers ----
+  // ---- weight tiles: 128 rows x 4 vectors = 512 items per tap, one per thread ------------------------------------------------
   const int brow = tid >> 2;
-  const int ntaps = tt.n, nchunks = a.kc_per_tap, total = ntaps * nchunks;
-  const size_t wrow = (size_t)(n0 + brow) * a.Kpad + hvec * 8;
+  const int ntaps = tt.n, nchunks = a.kc_per_tap;
+  const unsigned wrow = 2u * (unsigned)((n0 + brow) * a.Kpad + hvec * 8);
   const bool bvalid = n0 + brow < a.N;
-  auto b_load = [&](int c, int t) -> bf16x8 {
-    return bvalid ? *(const bf16x8*)(a.w + (size_t)tt.wt[t] * a.N * a.Kpad + wrow + c * BK) : zero_bf16x8();
-  };
-  auto b_store = [&](int buf, const bf16x8& r) { *(bf16x8*)(Bt + buf * TILE + brow * HROW + hvec * 8) = r; };
 
   // ---- per-lane fragment bases ---------------------------------------------------------------------------------------
   // M16 == false: v_mfma_f32_32x32x16_bf16, wave tile 2 x 2 (lane row = lane & 31, k half = lane >> 5, two k-steps per chunk)
@@ -401,49 +416,73 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
 
-  // (c, t) of the tile two steps ahead of the one being computed
-  int lc = 0, lt = 0;
-  auto advance = [&]() { if (++lt == ntaps) { lt = 0; ++lc; } };
-
-  if (a.pre) {
-    for (int i = tid; i < a.Kpad; i += 512) psc[i] = i < a.Cin ? a.pre[(size_t)b * a.Cin + i] : 0.f;
+  if constexpr (PAIR) {
+    // ---- weight tiles of TWO taps per step (one barrier per tap pair): 2 x 128 rows x 4 vectors, two items per thread ----
+    const int ngroups = (ntaps + 1) >> 1, total = ngroups * nchunks;
+    struct BR { bf16x8 v[2]; };
+    auto b_load = [&](int c, int g) -> BR {
+      BR r;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int t = 2 * g + j;
+        const bool ok = t < ntaps;
+        r.v[j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wres, (bvalid && ok) ? wrow : 0xffffffffu,
+                                                                                 __builtin_amdgcn_readfirstlane(2 * (tt.wt[ok ? t : 0] * a.N * a.Kpad + c * BK)), 0));
+      }
+      return r;
+    };
+    auto b_store = [&](int buf, const BR& r) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) *(bf16x8*)(Bt + (buf * 2 + j) * TILE + brow * HROW + hvec * 8) = r.v[j];
+    };
+    int lc = 0, lg = 0;
+    auto advance = [&]() { if (++lg == ngroups) { lg = 0; ++lc; } };
+    if (a.pre) {
+      for (int i = tid; i < a.Kpad; i += 512) psc[i] = i < a.Cin ? a.pre[(size_t)b * a.Cin + i] : 0.f;
+      __syncthreads();
+    }
+    halo_load(0);
+    halo_store();
+    b_store(0, b_load(0, 0));
+    advance();
+    BR r0;                                                       // weight tiles ONE step ahead (a step is 16 MFMAs per wave deep)
+    r0.v[0] = zero_bf16x8(); r0.v[1] = zero_bf16x8();
     __syncthreads();
-  }
-  halo_load(0);
-  halo_store();
-  b_store(0, b_load(0, 0));
-  advance();                                                   // -> tile 1
-  bf16x8 r0 = (1 < total) ? b_load(lc, lt) : zero_bf16x8();    // tile 1 in flight
-  advance();                                                   // -> tile 2
-  bf16x8 r1 = zero_bf16x8();
-  __syncthreads();
 
-  int c = 0, t = 0;
-  // one step: compute tile q from buffer (q & 1); `rs` holds tile q+1 (loaded one step ago), `rl` receives tile q+2
-  auto step = [&](int q, bf16x8& rs, bf16x8& rl) {
-    if (t == 0 && c + 1 < nchunks) halo_load((c + 1) * BK);    // next chunk's halo: in flight during this chunk's taps
-    if (q + 2 < total) { rl = b_load(lc, lt); advance(); }
-    const int toff = (tt.dy[t] - hy0) * rp + (tt.dx[t] - hx0) * HROW;
-    const __bf16* Bc = Bt + (q & 1) * TILE;
-    if (M16) {
-      bf16x8 af[4], bf[4];
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) af[mi] = *(const bf16x8*)(halo + abase[mi] + toff);
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) bf[ni] = *(const bf16x8*)(Bc + bbase + ni * 16 * HROW);
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bf[ni], acc16[mi][ni], 0, 0, 0);
-    } else {
+    int c = 0, g = 0;
+    // one step: the (up to) two taps of group q from buffer pair (q & 1); the second tap's fragments are fetched into the registers
+    // the first tap's MFMAs release, so its LDS reads run under those MFMAs
+    auto step = [&](int q, BR& rs) {
+      if (g == 0 && c + 1 < nchunks) halo_load((c + 1) * BK);
+      if (q + 1 < total) { rs = b_load(lc, lg); advance(); }
+      const int t0 = 2 * g;
+      const bool two = t0 + 1 < ntaps;
+      const int toff0 = (tt.dy[t0] - hy0) * rp + (tt.dx[t0] - hx0) * HROW;
+      const int toff1 = two ? (tt.dy[t0 + 1] - hy0) * rp + (tt.dx[t0 + 1] - hx0) * HROW : 0;
+      const __bf16* Bc = Bt + (q & 1) * 2 * TILE;
       bf16x8 af[2][2], bf[2][2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) af[ks][mi] = *(const bf16x8*)(halo + abase[mi] + toff + ks * 16);
+        for (int mi = 0; mi < 2; ++mi) af[ks][mi] = *(const bf16x8*)(halo + abase[mi] + toff0 + ks * 16);
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) bf[ks][ni] = *(const bf16x8*)(Bc + bbase + ni * 32 * HROW + ks * 16);
+      }
+      if (two) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mi], bf[ks][ni], acc[mi][ni], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);                     // (pins the register reuse: the reads below overwrite the operands above)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) af[ks][mi] = *(const bf16x8*)(halo + abase[mi] + toff1 + ks * 16);
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) bf[ks][ni] = *(const bf16x8*)(Bc + TILE + bbase + ni * 32 * HROW + ks * 16);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -452,20 +491,106 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mi], bf[ks][ni], acc[mi][ni], 0, 0, 0);
-    }
-    if (t == ntaps - 1 && c + 1 < nchunks) {
-      __syncthreads();                                         // every wave is done reading this chunk's halo
-      halo_store();
-    }
-    if (q + 1 < total) b_store((q + 1) & 1, rs);
-    __syncthreads();
-    if (++t == ntaps) { t = 0; ++c; }
-  };
-  for (int q = 0; q < total; q += 2) {
-    step(q, r0, r1);
-    if (q + 1 < total) step(q + 1, r1, r0);
-  }
+      if (g == ngroups - 1 && c + 1 < nchunks) {
+        __syncthreads();
+        halo_store();
+      }
+      if (q + 1 < total) b_store((q + 1) & 1, rs);
+      __syncthreads();
+      if (++g == ngroups) { g = 0; ++c; }
+    };
+    for (int q = 0; q < total; ++q) step(q, r0);
+  } else {
+    // ---- weight tile: 128 rows x 4 vectors = 512 items, one per thread; prefetched TWO taps ahead in two named registers ----
+    const int total = ntaps * nchunks;
+    auto b_load = [&](int c, int t) -> bf16x8 {
+      return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wres, bvalid ? wrow : 0xffffffffu, __builtin_amdgcn_readfirstlane(2 * (tt.wt[t] * a.N * a.Kpad + c * BK)), 0));
+    };
+    auto b_store = [&](int buf, const bf16x8& r) { *(bf16x8*)(Bt + buf * TILE + brow * HROW + hvec * 8) = r; };
 
+    // (c, t) of the tile two steps ahead of the one being computed
+    int lc = 0, lt = 0;
+    auto advance = [&]() { if (++lt == ntaps) { lt = 0; ++lc; } };
+
+    if (a.pre) {
+      for (int i = tid; i < a.Kpad; i += 512) psc[i] = i < a.Cin ? a.pre[(size_t)b * a.Cin + i] : 0.f;
+      __syncthreads();
+    }
+    halo_load(0);
+    halo_store();
+    b_store(0, b_load(0, 0));
+    advance();                                                   // -> tile 1
+    bf16x8 r0 = (1 < total) ? b_load(lc, lt) : zero_bf16x8();    // tile 1 in flight
+    advance();                                                   // -> tile 2
+    bf16x8 r1 = zero_bf16x8();
+    __syncthreads();
+
+    int c = 0, t = 0;
+#ifdef HALO_STAMPS
+    unsigned long long sA = 0, sB = 0, sC = 0, sD = 0, st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;
+    STAMP(st0)
+#endif
+    // one step: compute tile q from buffer (q & 1); `rs` holds tile q+1 (loaded one step ago), `rl` receives tile q+2
+    auto step = [&](int q, bf16x8& rs, bf16x8& rl) {
+      if (t == 0 && c + 1 < nchunks) halo_load((c + 1) * BK);    // next chunk's halo: in flight during this chunk's taps
+      if (q + 2 < total) { rl = b_load(lc, lt); advance(); }
+      const int toff = (tt.dy[t] - hy0) * rp + (tt.dx[t] - hx0) * HROW;
+      const __bf16* Bc = Bt + (q & 1) * TILE;
+      if (M16) {
+        bf16x8 af[4], bf[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) af[mi] = *(const bf16x8*)(halo + abase[mi] + toff);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bf[ni] = *(const bf16x8*)(Bc + bbase + ni * 16 * HROW);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bf[ni], acc16[mi][ni], 0, 0, 0);
+      } else {
+        bf16x8 af[2][2], bf[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) af[ks][mi] = *(const bf16x8*)(halo + abase[mi] + toff + ks * 16);
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) bf[ks][ni] = *(const bf16x8*)(Bc + bbase + ni * 32 * HROW + ks * 16);
+        }
+        STAMP(st1)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mi], bf[ks][ni], acc[mi][ni], 0, 0, 0);
+        STAMP(st2)
+      }
+      if (t == ntaps - 1 && c + 1 < nchunks) {
+        __syncthreads();                                         // every wave is done reading this chunk's halo
+        halo_store();
+      }
+      if (q + 1 < total) b_store((q + 1) & 1, rs);
+      STAMP(st3)
+      __syncthreads();
+      STAMP(st4)
+#ifdef HALO_STAMPS
+      sA += st1 - st0; sB += st2 - st1; sC += st3 - st2; sD += st4 - st3; st0 = st4;
+#endif
+      if (++t == ntaps) { t = 0; ++c; }
+    };
+    for (int q = 0; q < total; q += 2) {
+      step(q, r0, r1);
+      if (q + 1 < total) step(q + 1, r1, r0);
+    }
+
+#ifdef HALO_STAMPS
+  if (!M16 && lane == 0 && blockIdx.x < 2048 && blockIdx.y == 0 && blockIdx.z == 0) {
+    unsigned long long* o = g_halo_stamps + ((size_t)blockIdx.x * 8 + wid) * 5;
+    o[0] = sA; o[1] = sB; o[2] = sC; o[3] = sD; o[4] = total;
+  }
+#endif
+  }
   // ---- epilogue: demod/bias/act in registers -> bf16 tile in LDS -> 16-byte coalesced stores (+ residual) ----------------
   // (the main loop ended with a barrier, so the staging buffers are free)
   constexpr int OROW = BN + 8;                                     // bf16 per output row in LDS (272 B: conflict-light)
@@ -864,7 +989,8 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   const int halo_wgs = c.B * a.tiles_x * a.tiles_y * cdiv(c.Cout, BN) * nphase;
   if (g_use_splitk && halo_wgs < g_halo_min_wgs && c.taps[0].n * c.kc_per_tap >= 8) return false;
   a.halo_elems = max_halo_elems;
-  const size_t smem = std::max(((size_t)a.halo_elems + 2 * TILE) * sizeof(__bf16) + (size_t)c.Kpad * sizeof(float),
+  const int NBT = (in_mul == 2 && !g_mfma16) ? 4 : 2;             // stride-2 forward stages the weight tiles of two taps per step
+  const size_t smem = std::max(((size_t)a.halo_elems + NBT * TILE) * sizeof(__bf16) + (size_t)c.Kpad * sizeof(float),
                                (size_t)256 * (BN + 8) * sizeof(__bf16) + BN * sizeof(float));
   dim3 grid(c.B * a.tiles_x * a.tiles_y, cdiv(c.Cout, BN), nphase);
 #define LAUNCH_HALO(IM, MM, EP)                                                                                         \
@@ -1428,6 +1554,12 @@ int lcgan_set_option(int option, int value) {
   if (option == 9) { const int old = g_wgrad3_pack; g_wgrad3_pack = value; return old; }
   return LCGAN_EINVAL;
 }
+
+#ifdef HALO_STAMPS
+int lcgan_halo_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_stamps), sizeof(unsigned long long) * 2048 * 8 * 5) == hipSuccess ? LCGAN_OK : LCGAN_ELAUNCH;
+}
+#endif
 
 int lcgan_conv_weight_prep(const float* w, int A, int Bc, int k, float scale, int transpose,
                            void* wp, int parts, float* wsq, void* stream) {

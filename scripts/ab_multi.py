@@ -9,11 +9,16 @@ variants = sys.argv[1:]
 Ks = []
 for i, v in enumerate(variants):
     path = f"/tmp/libv{i}.so"
-    shutil.copy(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lcgan_amd", "liblcgan_hip.so"), path)
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lcgan_amd", "liblcgan_hip.so")
+    kvs = [kv.split("=") for kv in filter(None, v.split(","))]
+    for o, val in kvs:
+        if o == "lib":                                   # "lib=ab/libX.so,4=1": another build as this variant
+            src = val
+    shutil.copy(src, path)
     K = kernels_for(path)
-    for kv in filter(None, v.split(",")):
-        o, val = kv.split("=")
-        K.lib.lcgan_set_option(int(o), int(val))
+    for o, val in kvs:
+        if o != "lib":
+            K.lib.lcgan_set_option(int(o), int(val))
     Ks.append(K)
 B = 32
 shapes = [(256, 128, 128, 1), (128, 256, 256, 1), (64, 512, 512, 1), (32, 512, 512, 1), (256, 128, 256, 2), (128, 256, 512, 2)]

@@ -1,0 +1,27 @@
+"""In-kernel stamps of conv_halo_kernel's main loop (diagnostic build with -DHALO_STAMPS, never the shipped library):
+where a step's cycles go, per wave.   bash: see scripts/gpu_r2.sh `stamps`."""
+import ctypes as C, math, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from scripts.ab_conv import kernels_for
+K = kernels_for(sys.argv[1])
+K.lib.lcgan_halo_stamps.argtypes = [C.c_void_p]
+B = 32
+for (Hh, Ci, Co, st) in [(256, 128, 128, 1), (128, 256, 256, 1), (64, 512, 512, 1)]:
+    x = torch.randn(B, Hh, Hh, Ci, device="cuda").bfloat16()
+    w = torch.randn(Co, Ci, 3, 3, device="cuda")
+    pw, _ = K.prep_weight(w, 1 / math.sqrt(Ci * 9), False, False)
+    for _ in range(3):
+        K.conv_fwd(x, pw, Co, 3, st, act=1, gain=1.4)
+    torch.cuda.synchronize()
+    buf = (C.c_ulonglong * (2048 * 8 * 5))()
+    assert K.lib.lcgan_halo_stamps(buf) == 0
+    a = np.array(buf[:], dtype=np.float64).reshape(2048, 8, 5)
+    steps = a[0, 0, 4]
+    ntiles = B * ((Hh // st + 15) // 16) ** 2
+    a = a[:min(ntiles, 2048)]                                  # (rows beyond this launch's grid hold an earlier launch)
+    per = a[:, :, :4] / steps                                  # cycles per step and segment, per (workgroup, wave)
+    med = np.median(per.reshape(-1, 4), axis=0)
+    early, late = np.median(per[:, :4].reshape(-1, 4), axis=0), np.median(per[:, 4:].reshape(-1, 4), axis=0)
+    print(f"{Hh}^2 {Ci}->{Co}: steps {steps:.0f}; cycles/step  reads-landed {med[0]:.0f}  mfma-issue {med[1]:.0f}  store->barrier {med[2]:.0f}  barrier-wait {med[3]:.0f}  total {med.sum():.0f}")
+    print(f"      waves 0-3: {early.round()}   waves 4-7: {late.round()}")
