@@ -1231,23 +1231,39 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
 
   struct Stage { bf16x8 g[NG]; bf16x8 x[NX]; };
 
+  // Global loads are raw buffer loads (resource in scalar registers, one 32-bit byte offset per lane): the part of an item's
+  // offset that belongs to the thread is computed once, the chunk adds one uniform base, and a lane outside the image (padding
+  // rows / columns) or beyond the channels gets offset 0xffffffff, which the range check turns into zeros -- no branch and no
+  // 64-bit address per load.  Tensors are < 2^31 elements (checked by the caller).
+  const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, (int)(2u * (unsigned)(a.B * a.Hm * a.Wm * a.Cg)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)(2u * (unsigned)(a.B * a.Hx * a.Wx * a.Cx)), 0x00020000);
+  int goffs[NG], xoffs[NX], xhr[NX], xhc[NX];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const int p = lpos + 32 * i, pr = p / SEGW, pc = p - pr * SEGW;
+    goffs[i] = 2 * (((lgrp + pr) * a.Wm + pc) * a.Cg + a0 + cvec * 8);
+  }
+#pragma unroll
+  for (int k = 0; k < NX; ++k) {
+    const int r = lpos + 32 * k, hr = r / XW, hc = r - hr * XW;
+    xhr[k] = r < XR && xc_ok ? (lgrp + hr) * STRIDE + ky - PAD : -0x40000000;      // row / column relative to the chunk origin
+    xhc[k] = hc - PAD;
+    xoffs[k] = 2 * ((xhr[k] * a.Wx + xhc[k]) * a.Cx + c0 + cvec * 8);
+  }
+
   auto gload = [&](int q, Stage& st) {
     const int seg = q % segs, t = q / segs;
-    const int row0 = (t % rgroups) * ROWS * PK + lgrp, b = t / rgroups, j0 = seg * SEGW;
+    const int row0 = (t % rgroups) * ROWS * PK, b = t / rgroups, j0 = seg * SEGW;
+    const int gbase = 2 * (((b * a.Hm + row0) * a.Wm + j0) * a.Cg);
 #pragma unroll
-    for (int i = 0; i < NG; ++i) {
-      const int p = lpos + 32 * i;                           // position in the chunk
-      const int pr = p / SEGW, pc = p - pr * SEGW;
-      st.g[i] = ga_ok ? *(const bf16x8*)(g + ((size_t)(b * a.Hm + row0 + pr) * a.Wm + j0 + pc) * a.Cg + a0 + cvec * 8) : zero_bf16x8();
-    }
-    const int xx0 = j0 * STRIDE - PAD;
+    for (int i = 0; i < NG; ++i)
+      st.g[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(gres, ga_ok ? (unsigned)(gbase + goffs[i]) : 0xffffffffu, 0, 0));
+    const int y0 = row0 * STRIDE, x0 = j0 * STRIDE;
+    const int xbase = 2 * (((b * a.Hx + y0) * a.Wx + x0) * a.Cx);
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
-      const int r = lpos + 32 * k;                           // halo pixel index
-      const int hr = r / XW, hc = r - hr * XW;
-      const int yy = (row0 + hr) * STRIDE + ky - PAD, xx = xx0 + hc;
-      const bool ok = r < XR && xc_ok && (unsigned)yy < (unsigned)a.Hx && (unsigned)xx < (unsigned)a.Wx;
-      st.x[k] = ok ? *(const bf16x8*)(x + ((size_t)(b * a.Hx + yy) * a.Wx + xx) * a.Cx + c0 + cvec * 8) : zero_bf16x8();
+      const bool ok = (unsigned)(y0 + xhr[k]) < (unsigned)a.Hx && (unsigned)(x0 + xhc[k]) < (unsigned)a.Wx;
+      st.x[k] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xres, ok ? (unsigned)(xbase + xoffs[k]) : 0xffffffffu, 0, 0));
     }
   };
   auto sstore = [&](int buf, const Stage& st) {

@@ -41,13 +41,14 @@ for (Hh, Ci, Co, st) in shapes:
     g = torch.randn(B, Hh // st, Hh // st, Co, device="cuda").bfloat16()
     bias = torch.randn(Co, device="cuda")
     sc = 1 / math.sqrt(Ci * 9)
-    res = [dict(f=[], d=[]) for _ in Ks]
+    res = [dict(f=[], d=[], w=[]) for _ in Ks]
     pws = [(K.prep_weight(w, sc, False, False)[0], K.prep_weight(w, sc, True, False)[0]) for K in Ks]
     n = 6 if Hh >= 64 else 20
     for rnd in range(3):
         for i, K in enumerate(Ks):
             res[i]["f"].append(timeit(lambda: K.conv_fwd(x, pws[i][0], Co, 3, st, bias=bias, act=1, gain=1.4), n))
             res[i]["d"].append(timeit(lambda: K.conv_bwd_data(g, pws[i][1], Ci, 3, st), n))
+            res[i]["w"].append(timeit(lambda: K.conv_wgrad(x, g, Co, Ci, 3, st), n))
     # agreement of every variant with variant 0 on the same inputs (bf16 outputs: differences beyond ~1 ulp mean a bug)
     pre, post = torch.rand(B, Ci, device="cuda") + 0.5, torch.rand(B, Co, device="cuda") + 0.5
     resid = torch.randn(B, Hh // st, Hh // st, Co, device="cuda").bfloat16()
@@ -60,9 +61,11 @@ for (Hh, Ci, Co, st) in shapes:
              K.conv_bwd_data(g, pws[i][1], Ci, 3, st).float()]
         if rhalf is not None:
             o.append(K.conv_bwd_data(g, pws[i][1], Ci, 3, st, residual=rhalf, residual_half=True).float())
+        o.append(K.conv_wgrad(x, g, Co, Ci, 3, st).float().clone())               # (fp32 atomics / slabs: agreement to ~1e-6)
+        o.append(K.conv_wgrad(x, g, Co, Ci, 3, st, pre_x=pre, pre_g=post).float().clone())
         outs.append(o)
     errs = [max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(o, outs[0])) for o in outs]
     line = f"{Hh:4d}^2 {Ci:3d}->{Co:3d} s{st}: maxrel-vs-v0 " + " ".join(f"{e:.1e}" for e in errs)
-    for kind in ("f", "d"):
+    for kind in ("f", "d", "w"):
         line += f" {kind}:" + " ".join(f"{min(r[kind]) * 1e3:7.1f}" for r in res)
     print(line, flush=True)
