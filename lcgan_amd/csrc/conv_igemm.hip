@@ -19,6 +19,7 @@
 //  * conv_wgrad_kernel reduces over positions: operands are staged row-major ([position][channel]) and read
 //    with ds_read_b64_tr_b16 so no transpose pass is needed; split-K partials are combined with fp32 atomics.
 #include "common.h"
+#include <type_traits>
 
 #include <algorithm>
 #include <cstdio>
@@ -38,6 +39,7 @@ int g_halo_min_wgs = 128;                 // lcgan_set_option(6, ...): halo laun
 int g_wgrad_slab_min = 4;                 // lcgan_set_option(8, ...): row-segment wgrad launches with at least this many splits reduce through a slab instead of atomics (0 = never)
 int g_halo_narrow_min_wgs = 256;          // lcgan_set_option(7, ...): narrow-layer halo kernel (Cout <= 64, 16 x 32 tiles) from this many workgroups; 0 = never
 int g_wgrad3_pack = 1;                    // lcgan_set_option(9, ...): packed channel groups in the row-segment wgrad kernel for layers with <= 64 channels
+int g_halo_dma = 0;                       // lcgan_set_option(10, ...): LDS-DMA staging in the halo kernel (stride-1 geometries without input scales)
 int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): experiments, bit mask (the wgrad3 no-atomics switch is gone: it sat in the epilogue);
                                           // halo kernel: 8 = linear tile order (the store / emit / main-loop skipping switches used for the
                                           // fixed-cost analysis in DESIGN.md were removed again: they sat in the hot epilogue)
@@ -306,8 +308,19 @@ __device__ unsigned long long g_halo_stamps[2048 * 8 * 5];
 // EPI selects the epilogue at compile time: 0 = plain, 1 = + residual, 2 = + 0.25 * half-resolution residual, 3 = style-gradient
 // reduction (gs += sum xs * acc).  As run-time branches the last two cost every launch 5-7 % on the short-K top layer (measured
 // with scripts/ab_raw.py against the builds that preceded them).
-template <int IN_MUL, bool M16, int EPI>
+// DMA (stride-1 geometries without per-sample input scales, Cin % 32 == 0): both operand tiles go global -> LDS by
+// `buffer_load ... lds` (no staging registers, no ds_write, no per-step vector-memory wait before an LDS store).  An LDS-DMA
+// instruction writes lane l's 16 bytes at base + 16 l, so the images are unpadded 64-byte records (pixel / weight row x 32
+// channels) whose four 16-byte slots are XOR-swizzled through the SOURCE address: slot = chunk ^ ((x >> 2) & 3), which makes the
+// fixed 16-lane groups of ds_read_b128 conflict-free for every tap shift (halo row pitch 20 pixels, a multiple of 4).
+constexpr int DMA_HP = 20, DMA_HROWS = 18;                       // halo image: <= 18 rows of 20 pixels
+constexpr int DMA_HBUF = (DMA_HROWS * DMA_HP * 64 + 1023) & ~1023; // bytes per halo image, whole 1-KB DMA pieces (two images: the next chunk lands during this one's taps)
+constexpr int DMA_BBUF = 128 * 64;                               // bytes per weight tile (two)
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int IN_MUL, bool M16, int EPI, bool DMA = false>
 __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_kernel(HaloArgs a) {
+  static_assert(!DMA || (IN_MUL == 1 && !M16 && EPI != 3), "LDS-DMA staging: stride-1 geometries, 32x32x16 tiles, no input scales");
   constexpr bool SR = EPI == 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NI = IN_MUL == 1 ? 3 : 9;     // halo (pixel, 8-channel vector) items per thread: ceil(hh*hw*4 / 512)
@@ -416,7 +429,85 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
 
-  if constexpr (PAIR) {
+  if constexpr (DMA) {
+    char* Hb = smem;                                             // 2 halo images
+    char* Bb = smem + 2 * DMA_HBUF;                              // 2 weight tiles
+    const int total = ntaps * nchunks;
+    const int dslot = lane & 3, widu = __builtin_amdgcn_readfirstlane(wid);
+    // halo: wave-instruction i = wid + 8 k moves pixels 16 i .. 16 i + 15 (linear over [hh][20]) x 4 slots
+    unsigned hvo[3];
+    bool hdo[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int i = widu + 8 * k, pi = 16 * i + (lane >> 2);
+      const int hy = pi / DMA_HP, hx = pi - hy * DMA_HP;
+      const int ch = dslot ^ ((hx >> 2) & 3);
+      const int gy = gy0 + hy, gx = gx0 + hx;
+      hdo[k] = 16 * i < hh * DMA_HP;
+      const bool ok = hy < hh && hx < hw && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
+      hvo[k] = ok ? 2u * (unsigned)(((b * a.Hin + gy) * a.Win + gx) * a.Cin + ch * 8) : 0xffffffffu;
+    }
+    auto dma_halo = [&](int c0, int buf) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (hdo[k])
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(Hb + buf * DMA_HBUF + (widu + 8 * k) * 1024), 16, hvo[k],
+                                                   __builtin_amdgcn_readfirstlane(c0 * 2), 0, 0);
+    };
+    // weights: wave `wid` moves rows 16 wid .. 16 wid + 15 x 4 slots
+    const int drow = 16 * widu + (lane >> 2);
+    const unsigned wvo = n0 + drow < a.N ? 2u * (unsigned)((n0 + drow) * a.Kpad + (dslot ^ ((drow >> 2) & 3)) * 8) : 0xffffffffu;
+    auto dma_b = [&](int cc, int t, int buf) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void*)(Bb + buf * DMA_BBUF + widu * 1024), 16, wvo,
+                                               __builtin_amdgcn_readfirstlane(2 * (tt.wt[t] * a.N * a.Kpad + cc * BK)), 0, 0);
+    };
+    // fragment byte addresses: A = row part + column part of the tap's x shift (0..2) ; k-step 1 is the same address ^ 32
+    const int half = lane >> 5, txl = lane & 15, halfs = half << 4;
+    const int rowofs = (wm * 4 + ((lane & 31) >> 4)) * (DMA_HP * 64);          // mi = 1: + 2 image rows
+    const int brow_l = wn * 64 + (lane & 31);
+    const int baddr0 = 2 * DMA_HBUF + brow_l * 64 + ((half ^ ((brow_l >> 2) & 3)) << 4);   // ni = 1: + 32 rows (same swizzle)
+    const int baddr1 = baddr0 ^ 32;
+
+    int lc = 0, lt = 0;
+    auto advance = [&]() { if (++lt == ntaps) { lt = 0; ++lc; } };
+    dma_halo(0, 0);
+    dma_b(0, 0, 0);
+    advance();
+    __syncthreads();
+    int c = 0, t = 0;
+    auto step = [&](int q, auto bufc) {
+      constexpr int buf = decltype(bufc)::value;
+      if (q + 1 < total) { dma_b(lc, lt, buf ^ 1); advance(); }
+      if (t == 0 && c + 1 < nchunks) dma_halo((c + 1) * BK, (c + 1) & 1);
+      const int ddx = tt.dx[t] - hx0;
+      const int ua = (c & 1) * DMA_HBUF + (tt.dy[t] - hy0) * (DMA_HP * 64);
+      const int hxl = txl + ddx;                                 // this lane's halo column under the tap: record hxl, slot (chunk ^ swizzle)
+      const int a0 = rowofs + ua + ((hxl << 6) | (halfs ^ ((hxl << 2) & 0x30)));
+      const int a1 = a0 ^ 32;
+      bf16x8 af[2][2], bf[2][2];
+      af[0][0] = *(const bf16x8*)(smem + a0);
+      af[0][1] = *(const bf16x8*)(smem + a0 + 2 * DMA_HP * 64);
+      bf[0][0] = *(const bf16x8*)(smem + baddr0 + buf * DMA_BBUF);
+      bf[0][1] = *(const bf16x8*)(smem + baddr0 + buf * DMA_BBUF + 32 * 64);
+      af[1][0] = *(const bf16x8*)(smem + a1);
+      af[1][1] = *(const bf16x8*)(smem + a1 + 2 * DMA_HP * 64);
+      bf[1][0] = *(const bf16x8*)(smem + baddr1 + buf * DMA_BBUF);
+      bf[1][1] = *(const bf16x8*)(smem + baddr1 + buf * DMA_BBUF + 32 * 64);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mi], bf[ks][ni], acc[mi][ni], 0, 0, 0);
+      __syncthreads();                                           // (waits for this step's DMA: vmcnt(0), then the barrier)
+      if (++t == ntaps) { t = 0; ++c; }
+    };
+    for (int q = 0; q < total; q += 2) {
+      step(q, std::integral_constant<int, 0>{});
+      if (q + 1 < total) step(q + 1, std::integral_constant<int, 1>{});
+    }
+  } else if constexpr (PAIR) {
     // ---- weight tiles of TWO taps per step (one barrier per tap pair): 2 x 128 rows x 4 vectors, two items per thread ----
     const int ngroups = (ntaps + 1) >> 1, total = ngroups * nchunks;
     struct BR { bf16x8 v[2]; };
@@ -1004,6 +1095,20 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
     if (a.xs) LAUNCH_HALO(IM, MM, 3) else if (a.residual && a.res_half) LAUNCH_HALO(IM, MM, 2)                          \
     else if (a.residual) LAUNCH_HALO(IM, MM, 1) else LAUNCH_HALO(IM, MM, 0)                                             \
   }
+  bool dma_ok = g_halo_dma && in_mul == 1 && !g_mfma16 && !a.pre && !a.xs && c.Cin % 32 == 0 && c.Kpad == c.Cin;
+  for (int p = 0; p < nphase; ++p) dma_ok = dma_ok && a.hh[p] <= DMA_HROWS && a.hw[p] <= DMA_HP && a.hw[p] - HT <= 2;
+  if (dma_ok) {
+    const size_t dsmem = std::max((size_t)(2 * DMA_HBUF + 2 * DMA_BBUF), (size_t)256 * (BN + 8) * sizeof(__bf16) + BN * sizeof(float));
+#define LAUNCH_DMA(EP)                                                                                                  \
+  {                                                                                                                     \
+    static bool set = false;                                                                                            \
+    if (!set) { hipFuncSetAttribute((const void*)conv_halo_kernel<1, false, EP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
+    hipLaunchKernelGGL((conv_halo_kernel<1, false, EP, true>), grid, dim3(512), dsmem, s, a);                           \
+  }
+    if (a.residual && a.res_half) LAUNCH_DMA(2) else if (a.residual) LAUNCH_DMA(1) else LAUNCH_DMA(0)
+#undef LAUNCH_DMA
+    return true;
+  }
   if (in_mul == 1 && g_mfma16 && !a.xs && !a.residual) LAUNCH_HALO(1, true, 0)
   else if (in_mul == 1) LAUNCH_HALO_EPI(1, false)
   else if (g_mfma16 && !a.xs && !a.residual) LAUNCH_HALO(2, true, 0)
@@ -1568,6 +1673,7 @@ int lcgan_set_option(int option, int value) {
   if (option == 7) { const int old = g_halo_narrow_min_wgs; g_halo_narrow_min_wgs = value; return old; }
   if (option == 8) { const int old = g_wgrad_slab_min; g_wgrad_slab_min = value; return old; }
   if (option == 9) { const int old = g_wgrad3_pack; g_wgrad3_pack = value; return old; }
+  if (option == 10) { const int old = g_halo_dma; g_halo_dma = value; return old; }
   return LCGAN_EINVAL;
 }
 
