@@ -39,7 +39,7 @@ int g_halo_min_wgs = 128;                 // lcgan_set_option(6, ...): halo laun
 int g_wgrad_slab_min = 4;                 // lcgan_set_option(8, ...): row-segment wgrad launches with at least this many splits reduce through a slab instead of atomics (0 = never)
 int g_halo_narrow_min_wgs = 256;          // lcgan_set_option(7, ...): narrow-layer halo kernel (Cout <= 64, 16 x 32 tiles) from this many workgroups; 0 = never
 int g_wgrad3_pack = 1;                    // lcgan_set_option(9, ...): packed channel groups in the row-segment wgrad kernel for layers with <= 64 channels
-int g_halo_dma = 0;                       // lcgan_set_option(10, ...): LDS-DMA staging in the halo kernel (stride-1 geometries without input scales)
+int g_halo_dma = 2;                       // lcgan_set_option(10, ...): LDS-DMA staging in the halo kernel (stride-1 geometries without input scales)
 int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): experiments, bit mask (the wgrad3 no-atomics switch is gone: it sat in the epilogue);
                                           // halo kernel: 8 = linear tile order (the store / emit / main-loop skipping switches used for the
                                           // fixed-cost analysis in DESIGN.md were removed again: they sat in the hot epilogue)
@@ -318,9 +318,9 @@ constexpr int DMA_HBUF = (DMA_HROWS * DMA_HP * 64 + 1023) & ~1023; // bytes per 
 constexpr int DMA_BBUF = 128 * 64;                               // bytes per weight tile (two)
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int IN_MUL, bool M16, int EPI, bool DMA = false>
+template <int IN_MUL, bool M16, int EPI, int DMA = 0>
 __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_kernel(HaloArgs a) {
-  static_assert(!DMA || (IN_MUL == 1 && !M16 && EPI != 3), "LDS-DMA staging: stride-1 geometries, 32x32x16 tiles, no input scales");
+  static_assert(DMA == 0 || (IN_MUL == 1 && !M16 && EPI != 3), "LDS-DMA staging: stride-1 geometries, 32x32x16 tiles, no input scales");
   constexpr bool SR = EPI == 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NI = IN_MUL == 1 ? 3 : 9;     // halo (pixel, 8-channel vector) items per thread: ceil(hh*hw*4 / 512)
@@ -429,10 +429,9 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
 
-  if constexpr (DMA) {
+  if constexpr (DMA != 0) {
     char* Hb = smem;                                             // 2 halo images
-    char* Bb = smem + 2 * DMA_HBUF;                              // 2 weight tiles
-    const int total = ntaps * nchunks;
+    char* Bb = smem + 2 * DMA_HBUF;                              // 2 (x TP) weight tiles
     const int dslot = lane & 3, widu = __builtin_amdgcn_readfirstlane(wid);
     // halo: wave-instruction i = wid + 8 k moves pixels 16 i .. 16 i + 15 (linear over [hh][20]) x 4 slots
     unsigned hvo[3];
@@ -457,9 +456,18 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
     // weights: wave `wid` moves rows 16 wid .. 16 wid + 15 x 4 slots
     const int drow = 16 * widu + (lane >> 2);
     const unsigned wvo = n0 + drow < a.N ? 2u * (unsigned)((n0 + drow) * a.Kpad + (dslot ^ ((drow >> 2) & 3)) * 8) : 0xffffffffu;
-    auto dma_b = [&](int cc, int t, int buf) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void*)(Bb + buf * DMA_BBUF + widu * 1024), 16, wvo,
-                                               __builtin_amdgcn_readfirstlane(2 * (tt.wt[t] * a.N * a.Kpad + cc * BK)), 0, 0);
+    // TP taps per step (one barrier per step): DMA == 2 moves two weight tiles per step and runs the second tap's fragment reads
+    // under the first tap's MFMAs (16 MFMAs per wave between barriers)
+    constexpr int TP = DMA;
+    const int ngroups = (ntaps + TP - 1) / TP, total = ngroups * nchunks;
+    auto dma_b = [&](int cc, int g, int buf) {
+#pragma unroll
+      for (int j = 0; j < TP; ++j) {
+        const int t = g * TP + j;
+        if (t < ntaps)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void*)(Bb + (buf * TP + j) * DMA_BBUF + widu * 1024), 16, wvo,
+                                                   __builtin_amdgcn_readfirstlane(2 * (tt.wt[t] * a.N * a.Kpad + cc * BK)), 0, 0);
+      }
     };
     // fragment byte addresses: A = row part + column part of the tap's x shift (0..2) ; k-step 1 is the same address ^ 32
     const int half = lane >> 5, txl = lane & 15, halfs = half << 4;
@@ -468,40 +476,52 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
     const int baddr0 = 2 * DMA_HBUF + brow_l * 64 + ((half ^ ((brow_l >> 2) & 3)) << 4);   // ni = 1: + 32 rows (same swizzle)
     const int baddr1 = baddr0 ^ 32;
 
-    int lc = 0, lt = 0;
-    auto advance = [&]() { if (++lt == ntaps) { lt = 0; ++lc; } };
+    int lc = 0, lg = 0;
+    auto advance = [&]() { if (++lg == ngroups) { lg = 0; ++lc; } };
     dma_halo(0, 0);
     dma_b(0, 0, 0);
     advance();
     __syncthreads();
-    int c = 0, t = 0;
+    int c = 0, g = 0;
+    bf16x8 af[2][2], bf[2][2];
+    auto frag_reads = [&](int t, int tilebase, int ks) {         // k-step ks of tap t: 2 A + 2 B fragments
+      const int hxl = txl + tt.dx[t] - hx0;                      // this lane's halo column under the tap: record hxl, slot (chunk ^ swizzle)
+      const int a0 = (rowofs + (c & 1) * DMA_HBUF + (tt.dy[t] - hy0) * (DMA_HP * 64) + ((hxl << 6) | (halfs ^ ((hxl << 2) & 0x30)))) ^ (ks * 32);
+      af[ks][0] = *(const bf16x8*)(smem + a0);
+      af[ks][1] = *(const bf16x8*)(smem + a0 + 2 * DMA_HP * 64);
+      const int b0 = (ks ? baddr1 : baddr0) + tilebase;
+      bf[ks][0] = *(const bf16x8*)(smem + b0);
+      bf[ks][1] = *(const bf16x8*)(smem + b0 + 32 * 64);
+    };
+    auto mfmas = [&](int ks) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mi], bf[ks][ni], acc[mi][ni], 0, 0, 0);
+    };
     auto step = [&](int q, auto bufc) {
       constexpr int buf = decltype(bufc)::value;
-      if (q + 1 < total) { dma_b(lc, lt, buf ^ 1); advance(); }
-      if (t == 0 && c + 1 < nchunks) dma_halo((c + 1) * BK, (c + 1) & 1);
-      const int ddx = tt.dx[t] - hx0;
-      const int ua = (c & 1) * DMA_HBUF + (tt.dy[t] - hy0) * (DMA_HP * 64);
-      const int hxl = txl + ddx;                                 // this lane's halo column under the tap: record hxl, slot (chunk ^ swizzle)
-      const int a0 = rowofs + ua + ((hxl << 6) | (halfs ^ ((hxl << 2) & 0x30)));
-      const int a1 = a0 ^ 32;
-      bf16x8 af[2][2], bf[2][2];
-      af[0][0] = *(const bf16x8*)(smem + a0);
-      af[0][1] = *(const bf16x8*)(smem + a0 + 2 * DMA_HP * 64);
-      bf[0][0] = *(const bf16x8*)(smem + baddr0 + buf * DMA_BBUF);
-      bf[0][1] = *(const bf16x8*)(smem + baddr0 + buf * DMA_BBUF + 32 * 64);
-      af[1][0] = *(const bf16x8*)(smem + a1);
-      af[1][1] = *(const bf16x8*)(smem + a1 + 2 * DMA_HP * 64);
-      bf[1][0] = *(const bf16x8*)(smem + baddr1 + buf * DMA_BBUF);
-      bf[1][1] = *(const bf16x8*)(smem + baddr1 + buf * DMA_BBUF + 32 * 64);
+      if (q + 1 < total) { dma_b(lc, lg, buf ^ 1); advance(); }
+      if (g == 0 && c + 1 < nchunks) dma_halo((c + 1) * BK, (c + 1) & 1);
+      const int t0 = g * TP;
+      frag_reads(t0, buf * TP * DMA_BBUF, 0);
+      frag_reads(t0, buf * TP * DMA_BBUF, 1);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int j = 1; j < TP; ++j)
+        if (t0 + j < ntaps) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mi], bf[ks][ni], acc[mi][ni], 0, 0, 0);
+          for (int ks = 0; ks < 2; ++ks) {
+            mfmas(ks);
+            __builtin_amdgcn_sched_barrier(0);                   // (pins the register reuse: the reads below overwrite the operands above)
+            frag_reads(t0 + j, (buf * TP + j) * DMA_BBUF, ks);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      mfmas(0);
+      mfmas(1);
       __syncthreads();                                           // (waits for this step's DMA: vmcnt(0), then the barrier)
-      if (++t == ntaps) { t = 0; ++c; }
+      if (++g == ngroups) { g = 0; ++c; }
     };
     for (int q = 0; q < total; q += 2) {
       step(q, std::integral_constant<int, 0>{});
@@ -1098,14 +1118,18 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   bool dma_ok = g_halo_dma && in_mul == 1 && !g_mfma16 && !a.pre && !a.xs && c.Cin % 32 == 0 && c.Kpad == c.Cin;
   for (int p = 0; p < nphase; ++p) dma_ok = dma_ok && a.hh[p] <= DMA_HROWS && a.hw[p] <= DMA_HP && a.hw[p] - HT <= 2;
   if (dma_ok) {
-    const size_t dsmem = std::max((size_t)(2 * DMA_HBUF + 2 * DMA_BBUF), (size_t)256 * (BN + 8) * sizeof(__bf16) + BN * sizeof(float));
-#define LAUNCH_DMA(EP)                                                                                                  \
+    const int tp = g_halo_dma == 2 ? 2 : 1;
+    const size_t dsmem = std::max((size_t)(2 * DMA_HBUF + 2 * tp * DMA_BBUF), (size_t)256 * (BN + 8) * sizeof(__bf16) + BN * sizeof(float));
+#define LAUNCH_DMA(EP, TPV)                                                                                             \
   {                                                                                                                     \
     static bool set = false;                                                                                            \
-    if (!set) { hipFuncSetAttribute((const void*)conv_halo_kernel<1, false, EP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
-    hipLaunchKernelGGL((conv_halo_kernel<1, false, EP, true>), grid, dim3(512), dsmem, s, a);                           \
+    if (!set) { hipFuncSetAttribute((const void*)conv_halo_kernel<1, false, EP, TPV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
+    hipLaunchKernelGGL((conv_halo_kernel<1, false, EP, TPV>), grid, dim3(512), dsmem, s, a);                            \
   }
-    if (a.residual && a.res_half) LAUNCH_DMA(2) else if (a.residual) LAUNCH_DMA(1) else LAUNCH_DMA(0)
+#define LAUNCH_DMA_EPI(TPV)                                                                                             \
+  { if (a.residual && a.res_half) LAUNCH_DMA(2, TPV) else if (a.residual) LAUNCH_DMA(1, TPV) else LAUNCH_DMA(0, TPV) }
+    if (tp == 2) LAUNCH_DMA_EPI(2) else LAUNCH_DMA_EPI(1)
+#undef LAUNCH_DMA_EPI
 #undef LAUNCH_DMA
     return true;
   }
