@@ -322,6 +322,10 @@ template <int IN_MUL, bool M16, int EPI, int DMA = 0>
 __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_kernel(HaloArgs a) {
   static_assert(DMA == 0 || (IN_MUL == 1 && !M16 && EPI != 3), "LDS-DMA staging: stride-1 geometries, 32x32x16 tiles, no input scales");
   constexpr bool SR = EPI == 3;
+  // TR: the 32x32 MFMAs run with their operands swapped (weights as the row operand), so a lane's 16 accumulator registers are
+  // 4 groups of 4 CONSECUTIVE CHANNELS of one pixel instead of 16 pixels of one channel: the epilogue moves 8-byte groups
+  // (16 ds_write_b64 per lane) instead of 64 two-byte elements.  The style-gradient epilogue keeps channel-per-lane (its column sums).
+  constexpr bool TR = !M16 && !SR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NI = IN_MUL == 1 ? 3 : 9;     // halo (pixel, 8-channel vector) items per thread: ceil(hh*hw*4 / 512)
   __bf16* halo = (__bf16*)smem;
@@ -498,7 +502,8 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mi], bf[ks][ni], acc[mi][ni], 0, 0, 0);
+          acc[mi][ni] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][ni], af[ks][mi], acc[mi][ni], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mi], bf[ks][ni], acc[mi][ni], 0, 0, 0);
     };
     auto step = [&](int q, auto bufc) {
       constexpr int buf = decltype(bufc)::value;
@@ -586,7 +591,8 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
           for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mi], bf[ks][ni], acc[mi][ni], 0, 0, 0);
+              acc[mi][ni] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][ni], af[ks][mi], acc[mi][ni], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mi], bf[ks][ni], acc[mi][ni], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);                     // (pins the register reuse: the reads below overwrite the operands above)
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi) af[ks][mi] = *(const bf16x8*)(halo + abase[mi] + toff1 + ks * 16);
@@ -601,7 +607,8 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mi], bf[ks][ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][ni], af[ks][mi], acc[mi][ni], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mi], bf[ks][ni], acc[mi][ni], 0, 0, 0);
       if (g == ngroups - 1 && c + 1 < nchunks) {
         __syncthreads();
         halo_store();
@@ -674,7 +681,8 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
           for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mi], bf[ks][ni], acc[mi][ni], 0, 0, 0);
+              acc[mi][ni] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][ni], af[ks][mi], acc[mi][ni], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mi], bf[ks][ni], acc[mi][ni], 0, 0, 0);
         STAMP(st2)
       }
       if (t == ntaps - 1 && c + 1 < nchunks) {
@@ -707,9 +715,19 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
   constexpr int OROW = BN + 8;                                     // bf16 per output row in LDS (272 B: conflict-light)
   __bf16* ot = (__bf16*)smem;                                      // [256][OROW]
   float* colbuf = (float*)(smem + 256 * OROW * sizeof(__bf16));    // [128] column sums of xs * acc (fused style-gradient reduction)
+  float* cbias = colbuf + BN;                                      // [128] bias * bias_scale, [128] demodulation scale of this sample
+  float* cpost = cbias + BN;
   const __bf16* side = SR ? a.xs : a.residual;                     // the tile that meets the accumulators: residual, or xs
   if (SR && tid < BN) colbuf[tid] = 0.f;
-  if (EPI != 0) {                                                  // stage it with coalesced 16-byte loads
+  if (TR && tid < BN) {
+    const int n = n0 + tid;
+    cbias[tid] = (a.bias && n < a.N) ? a.bias[n] * a.bias_scale : 0.f;
+    cpost[tid] = (a.post && n < a.Cout) ? a.post[(size_t)b * a.Cout + n] : 1.f;
+  }
+  // half-resolution residual under a stride-1 geometry (TR layout): the 4 lanes that share a source pixel read its 8-byte channel
+  // groups straight from global memory (L1 hits) in the loop below -- no staging pass, no 4x-redundant 16-byte loads
+  const bool quarter = TR && EPI == 2 && a.out_mul == 1;
+  if (EPI != 0 && !quarter) {                                      // stage it with coalesced 16-byte loads
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int idx = tid + k * 512;
@@ -724,49 +742,91 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
       }
       *(bf16x8*)(ot + row * OROW + vv * 8) = rr;
     }
-    __syncthreads();
   }
-  auto colconst = [&](int nl, float& bv, float& pv) {              // per output column: bias and demodulation scale
-    const int n = n0 + nl;
-    bv = (a.bias && n < a.N) ? a.bias[n] * a.bias_scale : 0.f;
-    pv = (a.post && n < a.Cout) ? a.post[(size_t)b * a.Cout + n] : 1.f;
-  };
+  if (TR || EPI != 0) __syncthreads();
   constexpr float res_scale = EPI == 2 ? 0.25f : 1.f;
-  auto emit = [&](int row, int nl, float accv, float bv, float pv, float& cs) {
-    float v = accv * pv + bv;
-    v = (a.act == ACT_LRELU ? (v > 0.f ? v : v * LRELU_SLOPE) : v) * a.gain;
-    if (SR) cs += accv * (float)ot[row * OROW + nl];               // style-gradient partial: x * (unscaled data gradient)
-    else if (EPI != 0) v += res_scale * (float)ot[row * OROW + nl];     // same thread reads and rewrites this element: one rounding
-    ot[row * OROW + nl] = (__bf16)v;
-  };
-  auto colflush = [&](int nl, float cs, int width) {               // lanes sharing a column -> one LDS add per wave and column
-    if (!SR) return;
-    for (int o = width; o < 64; o <<= 1) cs += __shfl_xor(cs, o, 64);
-    if (lane < width) atomicAdd(&colbuf[nl], cs);
-  };
-  if (M16) {
+  if constexpr (TR) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    // this lane's pixels (mi = 0, 1) and, for the half-resolution residual, their source pixels
+    const __bf16* qsrc[2] = {nullptr, nullptr};
+    if (quarter) {
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int nl = wn * 64 + ni * 16 + (lane & 15);
-      float bv, pv, cs = 0.f;
-      colconst(nl, bv, pv);
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) emit(wm * 64 + mi * 16 + (lane >> 4) * 4 + r, nl, acc16[mi][ni][r], bv, pv, cs);
-      colflush(nl, cs, 16);
+      for (int mi = 0; mi < 2; ++mi) {
+        const int row = wm * 64 + mi * 32 + (lane & 31);
+        const int qy = (ty * HT + (row >> 4)) >> 1, qx = (tx * HT + (row & 15)) >> 1;
+        if (qy < (a.Hout >> 1) && qx < (a.Wout >> 1)) qsrc[mi] = side + ((size_t)(b * (a.Hout >> 1) + qy) * (a.Wout >> 1) + qx) * a.Cout + n0;
+      }
     }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ch = wn * 64 + ni * 32 + 8 * g + 4 * (lane >> 5);            // this lane's 4 channels of accumulator group g
+        const f32x4 bv = *(const f32x4*)(cbias + ch), pv = *(const f32x4*)(cpost + ch);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int row = wm * 64 + mi * 32 + (lane & 31);                     // this lane's pixel
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float t = acc[mi][ni][4 * g + j] * pv[j] + bv[j];
+            v[j] = (a.act == ACT_LRELU ? (t > 0.f ? t : t * LRELU_SLOPE) : t) * a.gain;
+          }
+          if (EPI != 0) {
+            bf16x4 rr = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            if (!quarter) rr = *(const bf16x4*)(ot + row * OROW + ch);
+            else if (qsrc[mi] && n0 + ch < a.Cout) rr = *(const bf16x4*)(qsrc[mi] + ch);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += res_scale * (float)rr[j];
+          }
+          bf16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
+          *(bf16x4*)(ot + row * OROW + ch) = o;
+        }
+      }
   } else {
+    auto colconst = [&](int nl, float& bv, float& pv) {              // per output column: bias and demodulation scale
+      const int n = n0 + nl;
+      bv = (a.bias && n < a.N) ? a.bias[n] * a.bias_scale : 0.f;
+      pv = (a.post && n < a.Cout) ? a.post[(size_t)b * a.Cout + n] : 1.f;
+    };
+    auto emit = [&](int row, int nl, float accv, float bv, float pv, float& cs) {
+      float v = accv * pv + bv;
+      v = (a.act == ACT_LRELU ? (v > 0.f ? v : v * LRELU_SLOPE) : v) * a.gain;
+      if (SR) cs += accv * (float)ot[row * OROW + nl];               // style-gradient partial: x * (unscaled data gradient)
+      else if (EPI != 0) v += res_scale * (float)ot[row * OROW + nl];     // same thread reads and rewrites this element: one rounding
+      ot[row * OROW + nl] = (__bf16)v;
+    };
+    auto colflush = [&](int nl, float cs, int width) {               // lanes sharing a column -> one LDS add per wave and column
+      if (!SR) return;
+      for (int o = width; o < 64; o <<= 1) cs += __shfl_xor(cs, o, 64);
+      if (lane < width) atomicAdd(&colbuf[nl], cs);
+    };
+    if (M16) {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int nl = wn * 64 + ni * 32 + (lane & 31);
-      float bv, pv, cs = 0.f;
-      colconst(nl, bv, pv);
+      for (int ni = 0; ni < 4; ++ni) {
+        const int nl = wn * 64 + ni * 16 + (lane & 15);
+        float bv, pv, cs = 0.f;
+        colconst(nl, bv, pv);
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) emit(wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), nl, acc[mi][ni][r], bv, pv, cs);
-      colflush(nl, cs, 32);
+          for (int r = 0; r < 4; ++r) emit(wm * 64 + mi * 16 + (lane >> 4) * 4 + r, nl, acc16[mi][ni][r], bv, pv, cs);
+        colflush(nl, cs, 16);
+      }
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int nl = wn * 64 + ni * 32 + (lane & 31);
+        float bv, pv, cs = 0.f;
+        colconst(nl, bv, pv);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) emit(wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), nl, acc[mi][ni][r], bv, pv, cs);
+        colflush(nl, cs, 32);
+      }
     }
   }
   __syncthreads();
@@ -1068,6 +1128,9 @@ bool try_launch_halo_narrow(const ConvArgs& c, int nphase, hipStream_t s) {
   return true;
 }
 
+// epilogue staging of conv_halo_kernel: output tile [256][BN + 8] bf16 and three float rows (column sums, bias, demodulation)
+constexpr size_t HALO_EPI_SMEM = (size_t)256 * (BN + 8) * sizeof(__bf16) + 3 * BN * sizeof(float);
+
 // host side: returns true when the halo kernel was launched for this geometry
 bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   if (c.Hm < HT || c.Wm < HT || c.act == ACT_TANH) return false;
@@ -1102,7 +1165,7 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   a.halo_elems = max_halo_elems;
   const int NBT = (in_mul == 2 && !g_mfma16) ? 4 : 2;             // stride-2 forward stages the weight tiles of two taps per step
   const size_t smem = std::max(((size_t)a.halo_elems + NBT * TILE) * sizeof(__bf16) + (size_t)c.Kpad * sizeof(float),
-                               (size_t)256 * (BN + 8) * sizeof(__bf16) + BN * sizeof(float));
+                               HALO_EPI_SMEM);
   dim3 grid(c.B * a.tiles_x * a.tiles_y, cdiv(c.Cout, BN), nphase);
 #define LAUNCH_HALO(IM, MM, EP)                                                                                         \
   {                                                                                                                     \
@@ -1119,7 +1182,7 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   for (int p = 0; p < nphase; ++p) dma_ok = dma_ok && a.hh[p] <= DMA_HROWS && a.hw[p] <= DMA_HP && a.hw[p] - HT <= 2;
   if (dma_ok) {
     const int tp = g_halo_dma == 2 ? 2 : 1;
-    const size_t dsmem = std::max((size_t)(2 * DMA_HBUF + 2 * tp * DMA_BBUF), (size_t)256 * (BN + 8) * sizeof(__bf16) + BN * sizeof(float));
+    const size_t dsmem = std::max((size_t)(2 * DMA_HBUF + 2 * tp * DMA_BBUF), HALO_EPI_SMEM);
 #define LAUNCH_DMA(EP, TPV)                                                                                             \
   {                                                                                                                     \
     static bool set = false;                                                                                            \
