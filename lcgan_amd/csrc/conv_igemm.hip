@@ -40,6 +40,7 @@ int g_wgrad_slab_min = 4;                 // lcgan_set_option(8, ...): row-segme
 int g_halo_narrow_min_wgs = 256;          // lcgan_set_option(7, ...): narrow-layer halo kernel (Cout <= 64, 16 x 32 tiles) from this many workgroups; 0 = never
 int g_wgrad3_pack = 1;                    // lcgan_set_option(9, ...): packed channel groups in the row-segment wgrad kernel for layers with <= 64 channels
 int g_halo_dma = 2;                       // lcgan_set_option(10, ...): LDS-DMA staging in the halo kernel (stride-1 geometries without input scales)
+int g_halo_dma_mod = 1;                   // lcgan_set_option(11, ...): the same structure for convolutions with per-sample input scales (halo through registers): 0 = off, 1 / 2 = taps per step
 int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): experiments, bit mask (the wgrad3 no-atomics switch is gone: it sat in the epilogue);
                                           // halo kernel: 8 = linear tile order (the store / emit / main-loop skipping switches used for the
                                           // fixed-cost analysis in DESIGN.md were removed again: they sat in the hot epilogue)
@@ -318,9 +319,10 @@ constexpr int DMA_HBUF = (DMA_HROWS * DMA_HP * 64 + 1023) & ~1023; // bytes per 
 constexpr int DMA_BBUF = 128 * 64;                               // bytes per weight tile (two)
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int IN_MUL, bool M16, int EPI, int DMA = 0>
+template <int IN_MUL, bool M16, int EPI, int DMA = 0, bool MOD = false>
 __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_kernel(HaloArgs a) {
-  static_assert(DMA == 0 || (IN_MUL == 1 && !M16 && EPI != 3), "LDS-DMA staging: stride-1 geometries, 32x32x16 tiles, no input scales");
+  static_assert(DMA == 0 || (IN_MUL == 1 && !M16 && (MOD || EPI != 3)), "LDS-DMA staging: stride-1 geometries, 32x32x16 tiles");
+  static_assert(!MOD || DMA != 0, "MOD: the swizzled-record structure with the halo staged through registers (per-sample input scales)");
   constexpr bool SR = EPI == 3;
   // TR: the 32x32 MFMAs run with their operands swapped (weights as the row operand), so a lane's 16 accumulator registers are
   // 4 groups of 4 CONSECUTIVE CHANNELS of one pixel instead of 16 pixels of one channel: the epilogue moves 8-byte groups
@@ -450,12 +452,43 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
       const bool ok = hy < hh && hx < hw && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
       hvo[k] = ok ? 2u * (unsigned)(((b * a.Hin + gy) * a.Win + gx) * a.Cin + ch * 8) : 0xffffffffu;
     }
-    auto dma_halo = [&](int c0, int buf) {
+    // MOD (per-sample input scales: modulated convolutions and their data gradients): the halo pieces travel through registers
+    // into the SAME swizzled records -- loaded when a chunk starts, multiplied by the sample's channel scales and written to the
+    // other image in the chunk's last step (two images: no extra barrier); the weight tiles still go by LDS-DMA
+    float* dpsc = (float*)(smem + 2 * DMA_HBUF + 2 * DMA * DMA_BBUF);        // [Cin] scales of this workgroup's sample
+    bf16x8 hreg[MOD ? 3 : 1];
+    int hch[3];                                                  // this lane's channel offset within a chunk, per piece
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
-        if (hdo[k])
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(Hb + buf * DMA_HBUF + (widu + 8 * k) * 1024), 16, hvo[k],
-                                                   __builtin_amdgcn_readfirstlane(c0 * 2), 0, 0);
+    for (int k = 0; k < 3; ++k) {
+      const int pi = 16 * (widu + 8 * k) + (lane >> 2);
+      hch[k] = (dslot ^ (((pi % DMA_HP) >> 2) & 3)) * 8;
+    }
+    int h_c0 = 0;
+    auto dma_halo = [&](int c0, int buf) {
+      if constexpr (MOD) {
+        h_c0 = c0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          hreg[k] = hdo[k] ? __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xres, hvo[k], __builtin_amdgcn_readfirstlane(c0 * 2), 0))
+                           : zero_bf16x8();
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          if (hdo[k])
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(Hb + buf * DMA_HBUF + (widu + 8 * k) * 1024), 16, hvo[k],
+                                                     __builtin_amdgcn_readfirstlane(c0 * 2), 0, 0);
+      }
+    };
+    auto halo_store_mod = [&](int buf) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (!hdo[k]) continue;
+        const f32x4 s0 = *(const f32x4*)(dpsc + h_c0 + hch[k]), s1 = *(const f32x4*)(dpsc + h_c0 + hch[k] + 4);
+        bf16x8 v = hreg[k];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)((float)v[j] * (j < 4 ? s0[j] : s1[j - 4]));
+        *(bf16x8*)(Hb + buf * DMA_HBUF + (widu + 8 * k) * 1024 + lane * 16) = v;
+      }
     };
     // weights: wave `wid` moves rows 16 wid .. 16 wid + 15 x 4 slots
     const int drow = 16 * widu + (lane >> 2);
@@ -482,9 +515,14 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
 
     int lc = 0, lg = 0;
     auto advance = [&]() { if (++lg == ngroups) { lg = 0; ++lc; } };
+    if constexpr (MOD) {
+      for (int i = tid; i < a.Cin; i += 512) dpsc[i] = a.pre[(size_t)b * a.Cin + i];
+      __syncthreads();
+    }
     dma_halo(0, 0);
     dma_b(0, 0, 0);
     advance();
+    if constexpr (MOD) halo_store_mod(0);
     __syncthreads();
     int c = 0, g = 0;
     bf16x8 af[2][2], bf[2][2];
@@ -525,6 +563,9 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
         }
       mfmas(0);
       mfmas(1);
+      if constexpr (MOD) {
+        if (g == ngroups - 1 && c + 1 < nchunks) halo_store_mod((c + 1) & 1);
+      }
       __syncthreads();                                           // (waits for this step's DMA: vmcnt(0), then the barrier)
       if (++g == ngroups) { g = 0; ++c; }
     };
@@ -1178,20 +1219,26 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
     if (a.xs) LAUNCH_HALO(IM, MM, 3) else if (a.residual && a.res_half) LAUNCH_HALO(IM, MM, 2)                          \
     else if (a.residual) LAUNCH_HALO(IM, MM, 1) else LAUNCH_HALO(IM, MM, 0)                                             \
   }
-  bool dma_ok = g_halo_dma && in_mul == 1 && !g_mfma16 && !a.pre && !a.xs && c.Cin % 32 == 0 && c.Kpad == c.Cin;
+  const bool mod = a.pre != nullptr;
+  bool dma_ok = g_halo_dma && in_mul == 1 && !g_mfma16 && (mod ? g_halo_dma_mod != 0 : !a.xs) && c.Cin % 32 == 0 && c.Kpad == c.Cin;
   for (int p = 0; p < nphase; ++p) dma_ok = dma_ok && a.hh[p] <= DMA_HROWS && a.hw[p] <= DMA_HP && a.hw[p] - HT <= 2;
   if (dma_ok) {
-    const int tp = g_halo_dma == 2 ? 2 : 1;
-    const size_t dsmem = std::max((size_t)(2 * DMA_HBUF + 2 * tp * DMA_BBUF), HALO_EPI_SMEM);
-#define LAUNCH_DMA(EP, TPV)                                                                                             \
+    const int tp = mod ? (g_halo_dma_mod == 2 ? 2 : 1) : (g_halo_dma == 2 ? 2 : 1);
+    const size_t dsmem = std::max((size_t)(2 * DMA_HBUF + 2 * tp * DMA_BBUF) + (mod ? (size_t)c.Cin * sizeof(float) : 0), HALO_EPI_SMEM);
+#define LAUNCH_DMA(EP, TPV, MD)                                                                                         \
   {                                                                                                                     \
     static bool set = false;                                                                                            \
-    if (!set) { hipFuncSetAttribute((const void*)conv_halo_kernel<1, false, EP, TPV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
-    hipLaunchKernelGGL((conv_halo_kernel<1, false, EP, TPV>), grid, dim3(512), dsmem, s, a);                            \
+    if (!set) { hipFuncSetAttribute((const void*)conv_halo_kernel<1, false, EP, TPV, MD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
+    hipLaunchKernelGGL((conv_halo_kernel<1, false, EP, TPV, MD>), grid, dim3(512), dsmem, s, a);                        \
   }
 #define LAUNCH_DMA_EPI(TPV)                                                                                             \
-  { if (a.residual && a.res_half) LAUNCH_DMA(2, TPV) else if (a.residual) LAUNCH_DMA(1, TPV) else LAUNCH_DMA(0, TPV) }
-    if (tp == 2) LAUNCH_DMA_EPI(2) else LAUNCH_DMA_EPI(1)
+  { if (a.residual && a.res_half) LAUNCH_DMA(2, TPV, false) else if (a.residual) LAUNCH_DMA(1, TPV, false) else LAUNCH_DMA(0, TPV, false) }
+#define LAUNCH_DMA_MOD(TPV)                                                                                             \
+  { if (a.xs) LAUNCH_DMA(3, TPV, true) else if (a.residual && a.res_half) LAUNCH_DMA(2, TPV, true)                      \
+    else if (a.residual) LAUNCH_DMA(1, TPV, true) else LAUNCH_DMA(0, TPV, true) }
+    if (mod) { if (tp == 2) LAUNCH_DMA_MOD(2) else LAUNCH_DMA_MOD(1) }
+    else if (tp == 2) LAUNCH_DMA_EPI(2) else LAUNCH_DMA_EPI(1)
+#undef LAUNCH_DMA_MOD
 #undef LAUNCH_DMA_EPI
 #undef LAUNCH_DMA
     return true;
@@ -1761,6 +1808,7 @@ int lcgan_set_option(int option, int value) {
   if (option == 8) { const int old = g_wgrad_slab_min; g_wgrad_slab_min = value; return old; }
   if (option == 9) { const int old = g_wgrad3_pack; g_wgrad3_pack = value; return old; }
   if (option == 10) { const int old = g_halo_dma; g_halo_dma = value; return old; }
+  if (option == 11) { const int old = g_halo_dma_mod; g_halo_dma_mod = value; return old; }
   return LCGAN_EINVAL;
 }
 

@@ -41,7 +41,8 @@ for (Hh, Ci, Co, st) in shapes:
     g = torch.randn(B, Hh // st, Hh // st, Co, device="cuda").bfloat16()
     bias = torch.randn(Co, device="cuda")
     sc = 1 / math.sqrt(Ci * 9)
-    res = [dict(f=[], d=[], w=[]) for _ in Ks]
+    res = [dict(f=[], d=[], w=[], m=[]) for _ in Ks]
+    pre, post = torch.rand(B, Ci, device="cuda") + 0.5, torch.rand(B, Co, device="cuda") + 0.5
     pws = [(K.prep_weight(w, sc, False, False)[0], K.prep_weight(w, sc, True, False)[0]) for K in Ks]
     n = 6 if Hh >= 64 else 20
     for rnd in range(3):
@@ -49,8 +50,8 @@ for (Hh, Ci, Co, st) in shapes:
             res[i]["f"].append(timeit(lambda: K.conv_fwd(x, pws[i][0], Co, 3, st, bias=bias, act=1, gain=1.4), n))
             res[i]["d"].append(timeit(lambda: K.conv_bwd_data(g, pws[i][1], Ci, 3, st), n))
             res[i]["w"].append(timeit(lambda: K.conv_wgrad(x, g, Co, Ci, 3, st), n))
+            res[i]["m"].append(timeit(lambda: K.conv_fwd(x, pws[i][0], Co, 3, st, pre=pre, post=post, bias=bias, act=1, gain=1.0), n))
     # agreement of every variant with variant 0 on the same inputs (bf16 outputs: differences beyond ~1 ulp mean a bug)
-    pre, post = torch.rand(B, Ci, device="cuda") + 0.5, torch.rand(B, Co, device="cuda") + 0.5
     resid = torch.randn(B, Hh // st, Hh // st, Co, device="cuda").bfloat16()
     rhalf = torch.randn(B, Hh // 2, Hh // 2, Ci, device="cuda").bfloat16() if st == 1 else None
     outs = []
@@ -66,6 +67,6 @@ for (Hh, Ci, Co, st) in shapes:
         outs.append(o)
     errs = [max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(o, outs[0])) for o in outs]
     line = f"{Hh:4d}^2 {Ci:3d}->{Co:3d} s{st}: maxrel-vs-v0 " + " ".join(f"{e:.1e}" for e in errs)
-    for kind in ("f", "d", "w"):
+    for kind in ("f", "d", "w", "m"):
         line += f" {kind}:" + " ".join(f"{min(r[kind]) * 1e3:7.1f}" for r in res)
     print(line, flush=True)
