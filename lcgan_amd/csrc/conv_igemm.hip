@@ -41,6 +41,7 @@ int g_halo_narrow_min_wgs = 256;          // lcgan_set_option(7, ...): narrow-la
 int g_wgrad3_pack = 1;                    // lcgan_set_option(9, ...): packed channel groups in the row-segment wgrad kernel for layers with <= 64 channels
 int g_halo_dma = 2;                       // lcgan_set_option(10, ...): LDS-DMA staging in the halo kernel (stride-1 geometries without input scales)
 int g_halo_dma_mod = 1;                   // lcgan_set_option(11, ...): the same structure for convolutions with per-sample input scales (halo through registers): 0 = off, 1 / 2 = taps per step
+int g_wgrad_dma = 2;                      // lcgan_set_option(12, ...): LDS-DMA staging in the row-segment weight-gradient kernel (3x3, 64-wide segments, stride 1): 0 = off, 1 = on with the one-workgroup-per-CU split, 2 = on, split for two workgroups per CU; 3 = also stride 2 (measured slower: one workgroup per CU, one chunk of prefetch)
 int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): experiments, bit mask (the wgrad3 no-atomics switch is gone: it sat in the epilogue);
                                           // halo kernel: 8 = linear tile order (the store / emit / main-loop skipping switches used for the
                                           // fixed-cost analysis in DESIGN.md were removed again: they sat in the hot epilogue)
@@ -1591,6 +1592,150 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
     }
 }
 
+// =========================================================================================================
+// conv_wgrad3_dma_kernel: the row-segment weight-gradient kernel for its main case (3x3, 64-position row segments, no packed
+// groups) with both operand tiles staged by LDS-DMA (`buffer_load ... lds`): no staging registers (the register-staged kernel
+// holds two stages = 40 VGPRs and sits at 200+), so at stride 1 TWO workgroups share a CU (<= 128 VGPRs, 2 x 33 KB of LDS each).
+// LDS image: one 256-byte record per position / halo pixel (128 channels), unpadded because a DMA piece is 64 lanes x 16 B =
+// 4 records; the sixteen 16-byte slots of record r hold channel chunk  slot ^ (4 * f(r))  (swizzle through the SOURCE address),
+// f(r) = r & 3 for G and (r >> (STRIDE - 1)) & 3 for X, so the four rows a transposed 4 x 16 block read touches sit in four
+// different bank groups, exactly as the 320-byte padded pitch of the register-staged kernel arranged.
+// =========================================================================================================
+template <int STRIDE>
+__global__ __launch_bounds__(512, STRIDE == 1 ? 4 : 2) void conv_wgrad3_dma_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int SEG = 64, NKX = 3;
+  constexpr int XW = SEG * STRIDE + 2;                       // halo pixels of a row segment
+  constexpr int GP = SEG / 4, XP = (XW + 3) / 4;             // 1-KB DMA pieces (4 records each) of G and X
+  constexpr int NXI = (XP + 7) / 8;                          // X pieces per wave
+  constexpr int STAGE_B = (GP + XP) * 1024;                  // bytes per stage
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, widu = __builtin_amdgcn_readfirstlane(wid);
+  const int wm = wid >> 2, wn = wid & 3;                    // 8 waves: 2 (a) x 4 (c), wave tile 64 x 32
+  const int a0 = blockIdx.x * 128, c0 = blockIdx.y * 128;
+  const int split = blockIdx.z / NKX, ky = blockIdx.z - split * NKX;
+  const int segs = a.Wm / SEG, rgroups = a.Hm;
+  const int bsmp = split / a.parts, part = split - bsmp * a.parts;
+  const int cps = a.cps_group;
+  const int q_begin = bsmp * cps + part * a.chunks_per_split;
+  const int q_end = min(q_begin + a.chunks_per_split, (bsmp + 1) * cps);
+  if (q_begin >= q_end) return;
+  const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc((void*)a.g, 0, (int)(2u * (unsigned)(a.B * a.Hm * a.Wm * a.Cg)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(2u * (unsigned)(a.B * a.Hx * a.Wx * a.Cx)), 0x00020000);
+
+  // ---- DMA items of this lane: record lrec = lane >> 4 of a piece, slot = lane & 15 ----------------------------------------
+  const int lrec = lane >> 4, slot = lane & 15;
+  unsigned goffs[2];                                         // G piece i = widu + 8 k : positions 4 i .. 4 i + 3
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int pos = 4 * (widu + 8 * k) + lrec;
+    const int ch = (slot ^ ((pos & 3) << 2)) * 8;
+    goffs[k] = a0 + ch < a.Cg ? 2u * (unsigned)(pos * a.Cg + a0 + ch) : 0xffffffffu;
+  }
+  int xoffs[NXI], xhc[NXI];                                  // X piece i = widu + 8 k : halo pixels 4 i .. 4 i + 3
+#pragma unroll
+  for (int k = 0; k < NXI; ++k) {
+    const int hc = 4 * (widu + 8 * k) + lrec;
+    const int ch = (slot ^ (((hc >> (STRIDE - 1)) & 3) << 2)) * 8;
+    xhc[k] = (hc < XW && c0 + ch < a.Cx) ? hc - 1 : -0x40000000;     // column relative to the segment origin (padding: -1)
+    xoffs[k] = 2 * ((hc - 1) * a.Cx + c0 + ch);
+  }
+  auto dma = [&](int q, int buf) {
+    const int seg = q % segs, t = q / segs;
+    const int row0 = t % rgroups, b = t / rgroups, j0 = seg * SEG;
+    char* G = smem + buf * STAGE_B;
+    const int gbase = 2 * (((b * a.Hm + row0) * a.Wm + j0) * a.Cg);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(gres, (lds_void*)(G + (widu + 8 * k) * 1024), 16, goffs[k], __builtin_amdgcn_readfirstlane(gbase), 0, 0);
+    const int yy = row0 * STRIDE + ky - 1, x0 = j0 * STRIDE;
+    const bool yok = (unsigned)yy < (unsigned)a.Hx;
+    const int xbase = 2 * (((b * a.Hx + yy) * a.Wx + x0) * a.Cx);
+#pragma unroll
+    for (int k = 0; k < NXI; ++k) {
+      if (widu + 8 * k >= XP) continue;
+      const bool ok = yok && (unsigned)(x0 + xhc[k]) < (unsigned)a.Wx;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(G + (GP + widu + 8 * k) * 1024), 16, ok ? (unsigned)(xbase + xoffs[k]) : 0xffffffffu, 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[NKX][2];
+#pragma unroll
+  for (int t = 0; t < NKX; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.f;
+
+  // ---- fragment byte addresses (transposed 4 x 16 block reads; see tr_frag_rows) ------------------------------------------
+  const int g16 = lane >> 4, i16 = lane & 15;
+  const int trow = 8 * (g16 >> 1) + (i16 >> 2);
+  const int tcol = 16 * (g16 & 1) + 4 * (i16 & 3);
+  const int rsw = i16 >> 2;                                  // (row & 3) of this lane's G rows: trow + 16 ks (+ 4)
+  int gaddr[2], xaddr[NKX];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) gaddr[mi] = trow * 256 + 2 * ((wm * 64 + mi * 32 + tcol) ^ (rsw << 5));
+#pragma unroll
+  for (int kx = 0; kx < NKX; ++kx) {
+    const int r = trow * STRIDE + kx;                        // + 16 STRIDE ks (+ 4 STRIDE): the swizzle term does not change
+    xaddr[kx] = GP * 1024 + r * 256 + 2 * ((wn * 32 + tcol) ^ (((r >> (STRIDE - 1)) & 3) << 5));
+  }
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto tr_pair = [&](const char* base, int addr, int rowb_bytes) -> bf16x8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + addr));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + addr + rowb_bytes));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  auto compute = [&](auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+    const char* S = smem + buf * STAGE_B;
+#pragma unroll
+    for (int ks = 0; ks < SEG / 16; ++ks) {
+      bf16x8 af[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) af[mi] = tr_pair(S, gaddr[mi] + ks * 16 * 256, 4 * 256);
+#pragma unroll
+      for (int kx = 0; kx < NKX; ++kx) {
+        const bf16x8 bf = tr_pair(S, xaddr[kx] + ks * 16 * STRIDE * 256, 4 * STRIDE * 256);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[kx][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf, acc[kx][mi], 0, 0, 0);
+      }
+    }
+  };
+
+  dma(q_begin, 0);
+  __syncthreads();
+  for (int q = q_begin; q < q_end; q += 2) {
+    if (q + 1 < q_end) dma(q + 1, 1);
+    compute(std::integral_constant<int, 0>{});
+    __syncthreads();                                         // (vmcnt(0): the next chunk has landed; then the barrier)
+    if (q + 1 < q_end) {
+      if (q + 2 < q_end) dma(q + 2, 0);
+      compute(std::integral_constant<int, 1>{});
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int kx = 0; kx < NKX; ++kx)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int cc = c0 + wn * 32 + (lane & 31);
+      const float sxv = (a.pre_x && cc < a.Cx) ? a.pre_x[(size_t)bsmp * a.Cx + cc] : 1.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int aa = a0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (aa < a.A && cc < a.Bc) {
+          const float sgv = a.pre_g ? a.pre_g[(size_t)bsmp * a.Cg + aa] : 1.f;
+          const size_t off = ((size_t)(ky * NKX + kx) * a.A + aa) * a.Bc + cc;
+          if (a.slab) a.slab[(size_t)split * (NKX * NKX) * a.A * a.Bc + off] = acc[kx][mi][r] * sxv * sgv;
+          else atomicAdd(a.gwp + off, acc[kx][mi][r] * sxv * sgv);
+        }
+      }
+    }
+}
+
 // gwp[i] = sum_s slab[s][i]: the partial weight-gradient tiles of the row-segment kernel meet here instead of through fp32
 // atomics (12.5 M atomic adds onto 147 K addresses for the 128x128 top layer: ~20 % of that kernel)
 __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ gwp, int total, int nsplit) {
@@ -1809,6 +1954,7 @@ int lcgan_set_option(int option, int value) {
   if (option == 9) { const int old = g_wgrad3_pack; g_wgrad3_pack = value; return old; }
   if (option == 10) { const int old = g_halo_dma; g_halo_dma = value; return old; }
   if (option == 11) { const int old = g_halo_dma_mod; g_halo_dma_mod = value; return old; }
+  if (option == 12) { const int old = g_wgrad_dma; g_wgrad_dma = value; return old; }
   return LCGAN_EINVAL;
 }
 
@@ -1997,7 +2143,9 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
       const int min_chunks = 2048 / seg;
       parts = max(1, min(parts, cps / min_chunks > 0 ? cps / min_chunks : 1));
     } else {
-      const int occ = 1;                                          // 166-236 VGPRs: one 512-thread workgroup per CU whatever the LDS size
+      // register-staged kernel: 166-236 VGPRs, one 512-thread workgroup per CU whatever the LDS size; the LDS-DMA kernel at
+      // stride 1 keeps two (128 VGPRs, 66 KB of LDS each)
+      const int occ = (g_wgrad_dma >= 2 && segw == 64 && k == 3 && pk == 1 && stride == 1) ? 2 : 1;
       const int max_parts = max(1, cps / (1024 / seg));
       double best = 1e30;
       for (int pt = 1; pt <= max_parts; ++pt) {
@@ -2033,6 +2181,18 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
 #define LAUNCH_WG3_K(ST, SG, SW) { if (k == 3) LAUNCH_WG3(ST, SG, SW, 3) else LAUNCH_WG3(ST, SG, SW, 1) }
     if (pk == 4) { if (stride == 1) LAUNCH_WG3_PK(1, 4) else LAUNCH_WG3_PK(2, 4) }
     else if (pk == 2) { if (stride == 1) LAUNCH_WG3_PK(1, 2) else LAUNCH_WG3_PK(2, 2) }
+    else if (g_wgrad_dma && (stride == 1 || g_wgrad_dma == 3) && segw == 64 && k == 3 && Cg % 8 == 0 && Cx % 8 == 0) {
+      const size_t dsm = 2 * (size_t)(16 + (64 * stride + 2 + 3) / 4) * 1024;
+      if (stride == 1) {
+        static bool set = false;
+        if (!set) { hipFuncSetAttribute((const void*)conv_wgrad3_dma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+        hipLaunchKernelGGL((conv_wgrad3_dma_kernel<1>), grid3, dim3(512), dsm, s, a);
+      } else {
+        static bool set = false;
+        if (!set) { hipFuncSetAttribute((const void*)conv_wgrad3_dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+        hipLaunchKernelGGL((conv_wgrad3_dma_kernel<2>), grid3, dim3(512), dsm, s, a);
+      }
+    }
     else if (stride == 1) {
       if (segw == 64) LAUNCH_WG3_K(1, 64, 64) else if (segw == 32) LAUNCH_WG3_K(1, 32, 32)
       else if (segw == 16) LAUNCH_WG3_K(1, 32, 16) else LAUNCH_WG3_K(1, 32, 8)
