@@ -155,6 +155,80 @@ def test_conv_bwd_data(H, dtype, case):
               E.conv_bwd_data(g, pw_e, Ci, k, stride, residual=rh, residual_half=True), dtype, "half-res residual")
 
 
+# ---- staging variants of the halo-tile kernel and the row-segment weight-gradient kernel ------------------------------------------
+# (lcgan_set_option: 6 = 0 sends every eligible launch to the halo kernel whatever its grid size; 10 = LDS-DMA staging of the
+#  unmodulated stride-1 / transposed geometries (0 off, 1 / 2 taps per barrier); 11 = the same records with the halo through
+#  registers for convolutions with per-sample input scales; 12 = LDS-DMA staging of the weight-gradient kernel)
+HALO_VARIANT_CASES = [
+    # B, H, W, Cin, Cout, k, stride -- Cin a multiple of 32 (the DMA variants' domain), whole and ragged 16 x 16 tiles
+    (2, 32, 32, 64, 128, 3, 1),
+    (1, 48, 32, 128, 96, 3, 1),
+    (2, 32, 32, 96, 160, 1, 1),
+    (1, 32, 64, 64, 64, 3, 2),
+    (1, 40, 24, 32, 136, 3, 1),
+]
+
+
+@pytest.mark.parametrize("variant", [(0, 0), (1, 0), (2, 1), (1, 1), (2, 2)], ids=lambda v: f"dma{v[0]}-mod{v[1]}")
+@pytest.mark.parametrize("case", HALO_VARIANT_CASES)
+def test_conv_halo_staging_variants(H, case, variant):
+    B, Hh, W, Ci, Co, k, stride = case
+    dtype = torch.bfloat16
+    old = [H.lib.lcgan_set_option(6, 0), H.lib.lcgan_set_option(10, variant[0]), H.lib.lcgan_set_option(11, variant[1])]
+    try:
+        scale = 1 / math.sqrt(Ci * k * k)
+        w = torch.randn(Co, Ci, k, k, generator=torch.Generator().manual_seed(2))
+        bias = torch.randn(Co, generator=torch.Generator().manual_seed(3))
+        if stride == 1:                                                     # forward: plain, epilogue, modulated, residual
+            x = feat((B, Hh, W, Ci), dtype, 1)
+            pw_e, _ = E.prep_weight(w, scale, False, False)
+            pw_h, _ = H.prep_weight(w.cuda(), scale, False, False)
+            check(H.conv_fwd(x.cuda(), pw_h, Co, k, 1), E.conv_fwd(x, pw_e, Co, k, 1), dtype, "plain")
+            check(H.conv_fwd(x.cuda(), pw_h, Co, k, 1, bias=bias.cuda(), bias_scale=0.5, act=1, gain=1.4),
+                  E.conv_fwd(x, pw_e, Co, k, 1, bias=bias, bias_scale=0.5, act=1, gain=1.4), dtype, "bias+lrelu")
+            pre, post = vec((B, Ci), 4), vec((B, ceil8(Co)), 5)
+            res = feat((B, Hh, W, ceil8(Co)), dtype, 6, Co)
+            check(H.conv_fwd(x.cuda(), pw_h, Co, k, 1, residual=res.cuda()), E.conv_fwd(x, pw_e, Co, k, 1, residual=res), dtype, "residual")
+            check(H.conv_fwd(x.cuda(), pw_h, Co, k, 1, pre=pre.cuda(), post=post.cuda(), bias=bias.cuda(), residual=res.cuda()),
+                  E.conv_fwd(x, pw_e, Co, k, 1, pre=pre, post=post, bias=bias, residual=res), dtype, "mod+residual")
+        # data gradient of the same layer (stride 2: the 4-phase transposed convolution): g has Co channels, the output Ci
+        g = feat((B, Hh // stride, W // stride, ceil8(Co)), dtype, 11, Co)
+        pw_e, _ = E.prep_weight(w, scale, True, False)
+        pw_h, _ = H.prep_weight(w.cuda(), scale, True, False)
+        if ceil8(Co) % 32 == 0:
+            check(H.conv_bwd_data(g.cuda(), pw_h, Ci, k, stride), E.conv_bwd_data(g, pw_e, Ci, k, stride), dtype, "dgrad")
+            rh = feat((B, Hh // 2, W // 2, Ci), dtype, 16)
+            check(H.conv_bwd_data(g.cuda(), pw_h, Ci, k, stride, residual=rh.cuda(), residual_half=True),
+                  E.conv_bwd_data(g, pw_e, Ci, k, stride, residual=rh, residual_half=True), dtype, "dgrad + half-res residual")
+            pre, post = vec((B, ceil8(Co)), 13), vec((B, Ci), 14)
+            xs = feat((B, Hh, W, Ci), dtype, 17)
+            gx_h, gs_h = H.conv_bwd_data(g.cuda(), pw_h, Ci, k, stride, pre=pre.cuda(), post=post.cuda(), xs=xs.cuda())
+            gx_e, gs_e = E.conv_bwd_data(g, pw_e, Ci, k, stride, pre=pre, post=post, xs=xs)
+            check(gx_h, gx_e, dtype, "fused gx", l2_scale=2.0)
+            check(gs_h, gs_e, dtype, "fused gs", l2_scale=3.0)
+    finally:
+        for o, v in zip((6, 10, 11), old):
+            H.lib.lcgan_set_option(o, v)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("case", [(1, 64, 64, 128, 256, 3, 1), (2, 64, 128, 64, 72, 3, 1), (1, 128, 128, 96, 128, 3, 2), (3, 64, 64, 256, 128, 3, 1)])
+def test_conv_wgrad_staging_variants(H, case, mode):
+    B, Hh, W, Ci, Co, k, stride = case
+    dtype = torch.bfloat16
+    x = feat((B, Hh, W, ceil8(Ci)), dtype, 21, Ci)
+    g = feat((B, Hh // stride, W // stride, ceil8(Co)), dtype, 22, Co)
+    old = H.lib.lcgan_set_option(12, mode)
+    try:
+        check(H.conv_wgrad(x.cuda(), g.cuda(), Co, Ci, k, stride), E.conv_wgrad(x, g, Co, Ci, k, stride), dtype, "plain")
+        px, pg = vec((B, ceil8(Ci)), 23), vec((B, ceil8(Co)), 24)
+        got, ref_p = H.conv_wgrad(x.cuda(), g.cuda(), Co, Ci, k, stride, pre_x=px.cuda(), pre_g=pg.cuda()), E.conv_wgrad(x, g, Co, Ci, k, stride, pre_x=px, pre_g=pg)
+        e_l2 = float((got.float().cpu() - ref_p).norm() / ref_p.norm())
+        assert e_l2 <= 4e-3, e_l2
+    finally:
+        H.lib.lcgan_set_option(12, old)
+
+
 NARROW_CASES = [
     # B, H, W, Cin, Cout, stride: layers with <= 64 output channels on grids of whole 32 x 32 tiles (the C = 32 / 64 octaves of the
     # 512 x 512 and 1024 x 1024 networks) -> conv_halo_narrow_kernel (forced here for small grids through option 7)
