@@ -2163,7 +2163,10 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
     const size_t slab_bytes = (size_t)a.nsplit * k * k * A * Bc * sizeof(float);
     // (measured per layer shape with scripts/ab_conv.py: -17 % at 16x16, -6 % at 32x32, -3..-7 % on the stride-2 layers, neutral at
     // 64x64 and 256x256, +3 % at 128x128 stride 1: the atomics of the big stride-1 layers hide under other workgroups' compute)
-    if (pk == 1 && g_wgrad_slab_min > 0 && a.nsplit >= g_wgrad_slab_min && slab_bytes <= ((size_t)1 << 30) && (Hg * Wg <= 4096 || stride == 2 || g_wgrad_slab_min == 1))
+    // With the LDS-DMA kernel (shorter chunk loops) the big stride-1 layers are neutral at local batch 32 and -5 % of the whole
+    // iteration at local batch 4 (170 splits x 49 K atomics per layer were 77 us at the chip's 1.3 TB/s atomic rate), so every
+    // launch with enough splits takes the slab.
+    if (pk == 1 && g_wgrad_slab_min > 0 && a.nsplit >= g_wgrad_slab_min && slab_bytes <= ((size_t)1 << 30))
       a.slab = wgrad_slab_scratch(slab_bytes);                    // (packed groups: several waves add into one element -> atomics only)
     dim3 grid3(cdiv(A, 128), cdiv(Bc, 128), nkx * a.nsplit);
 #define LAUNCH_WG3(ST, SG, SW, NK)                                                                                      \
