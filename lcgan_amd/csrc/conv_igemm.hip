@@ -42,6 +42,8 @@ int g_wgrad3_pack = 1;                    // lcgan_set_option(9, ...): packed ch
 int g_halo_dma = 2;                       // lcgan_set_option(10, ...): LDS-DMA staging in the halo kernel (stride-1 geometries without input scales)
 int g_halo_dma_mod = 1;                   // lcgan_set_option(11, ...): the same structure for convolutions with per-sample input scales (halo through registers): 0 = off, 1 / 2 = taps per step
 int g_wgrad_dma = 2;                      // lcgan_set_option(12, ...): LDS-DMA staging in the row-segment weight-gradient kernel (3x3, 64-wide segments, stride 1): 0 = off, 1 = on with the one-workgroup-per-CU split, 2 = on, split for two workgroups per CU; 3 = also stride 2 (measured slower: one workgroup per CU, one chunk of prefetch)
+int g_halo_s2dma = 1;                     // lcgan_set_option(13, ...): stride-2 forward 3x3 on the parity-plane LDS-DMA structure (one barrier per 16-channel half-chunk)
+int g_halo_nb_group_kb = 8192;               // lcgan_set_option(14, ...): KB of weights (all taps x 128 rows x Cin) that concurrent channel blocks of one tile may hold in an XCD's L2; 0 = channel blocks slowest (one pass over the input per block)
 int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): experiments, bit mask (the wgrad3 no-atomics switch is gone: it sat in the epilogue);
                                           // halo kernel: 8 = linear tile order (the store / emit / main-loop skipping switches used for the
                                           // fixed-cost analysis in DESIGN.md were removed again: they sat in the hot epilogue)
@@ -291,6 +293,7 @@ struct HaloArgs {
   float bias_scale, gain; int act;
   TapTable taps[4];
   int hy0[4], hx0[4], hh[4], hw[4];          // per phase: halo origin (min dy, min dx) and extent in input pixels
+  int nblocks, nb_group;                     // channel blocks of 128; how many of them run together per tile (see the kernel's workgroup order)
   int halo_elems;                            // LDS elements reserved for the halo (max over phases)
   int dbg;                                   // option 3, bit 8: linear instead of XCD-contiguous tile order
 };
@@ -322,7 +325,8 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 template <int IN_MUL, bool M16, int EPI, int DMA = 0, bool MOD = false>
 __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_kernel(HaloArgs a) {
-  static_assert(DMA == 0 || (IN_MUL == 1 && !M16 && (MOD || EPI != 3)), "LDS-DMA staging: stride-1 geometries, 32x32x16 tiles");
+  static_assert(DMA == 0 || (IN_MUL == 1 && DMA <= 2 && !M16 && (MOD || EPI != 3)) || (IN_MUL == 2 && DMA == 3 && !M16 && !MOD && EPI != 3),
+                "LDS-DMA staging: stride-1 geometries (1 / 2 taps per barrier) or the stride-2 forward structure (DMA == 3)");
   static_assert(!MOD || DMA != 0, "MOD: the swizzled-record structure with the halo staged through registers (per-sample input scales)");
   constexpr bool SR = EPI == 3;
   // TR: the 32x32 MFMAs run with their operands swapped (weights as the row operand), so a lane's 16 accumulator registers are
@@ -339,11 +343,23 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   // the 4 sub-pixel phases of a transposed conv have 1/2/2/4 taps: dispatch the long ones first (shorter tail)
-  const int phase = gridDim.z - 1 - blockIdx.z, n0 = blockIdx.y * BN;
-  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so every XCD gets a contiguous run of tiles
-  // (neighbouring tiles share halo columns and rows in that XCD's L2): -1.3 % on the conv launches of an iteration
-  int tile = blockIdx.x;
-  if (!(a.dbg & 8) && (gridDim.x & 7) == 0) tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int phase = gridDim.z - 1 - blockIdx.z;
+  // Workgroup order (grid.x = tiles x channel blocks).  Workgroups are dealt round-robin over the 8 XCDs, so every XCD gets a
+  // contiguous run of tiles (neighbouring tiles share halo columns and rows in that XCD's L2: -1.3 % on the conv launches of an
+  // iteration).  Inside an XCD the channel blocks of one tile run TOGETHER in groups of a.nb_group blocks (as many as keep their
+  // weights resident in the XCD's 4 MB L2), so the tile's input is fetched from HBM once per group instead of once per block.
+  const int ntile = gridDim.x / a.nblocks;
+  int tile, nb;
+  if (!(a.dbg & 8) && (ntile & 7) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = (ntile >> 3) * a.nb_group;
+    const int nbo = slot / per, rem = slot - nbo * per;
+    tile = xcd * (ntile >> 3) + rem / a.nb_group;
+    nb = nbo * a.nb_group + rem % a.nb_group;
+  } else {
+    tile = blockIdx.x % ntile;
+    nb = blockIdx.x / ntile;
+  }
+  const int n0 = nb * BN;
   const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
   const TapTable& tt = a.taps[phase];
   const int hy0 = a.hy0[phase], hx0 = a.hx0[phase], hh = a.hh[phase], hw = a.hw[phase];
@@ -436,7 +452,94 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
 
-  if constexpr (DMA != 0) {
+  if constexpr (IN_MUL == 2 && DMA == 3) {
+    // ---- stride-2 forward, 3 x 3: everything by LDS-DMA, ONE barrier per 16-channel half-chunk (36 MFMAs per wave) --------------
+    // The 33 x 33 input patch of a 16 x 16 output tile is kept as its four (row parity, column parity) PLANES, so the stride-2
+    // gather of a tap is a unit-stride walk in one plane: tap (ky, kx) reads plane (ky & 1, kx & 1) at (y + (ky >> 1), x + (kx >> 1)).
+    // Records are 32 bytes (16 channels), plane rows 20 records; the two 16-byte slots of record (r, c) hold channel half
+    // slot ^ ((c >> 2) & 1): with the 640-byte row pitch the fixed lane groups of ds_read_b128 are conflict-free for every tap.
+    // A half-chunk stage = the four planes (42 KB) + the weight tiles of ALL nine taps (9 x 128 rows x 32 B = 36 KB); two stages
+    // (156 KB: one workgroup per CU, as the 33 x 33 patch always forced) let the next half-chunk land while this one's nine taps
+    // run without a barrier between them.
+    constexpr int PP = 20;                                       // plane row pitch in records
+    constexpr int P_OFF[4] = {0, 17 * PP, 2 * 17 * PP, 2 * 17 * PP + 16 * PP};   // record index of planes (0,0) (0,1) (1,0) (1,1)
+    constexpr int NREC = 2 * 17 * PP + 2 * 16 * PP;              // 1 320 records
+    constexpr int HPIECES = (NREC + 31) / 32;                    // 42 one-KB pieces
+    constexpr int S2_H = HPIECES * 1024, S2_B = 9 * 4096;        // bytes of the planes / of the nine weight tiles
+    constexpr int S2_STAGE = S2_H + S2_B;
+    const int widu = __builtin_amdgcn_readfirstlane(wid);
+    const int nh = 2 * nchunks;                                  // 16-channel half-chunks
+    unsigned hvo[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int L = 32 * (widu + 8 * k) + (lane >> 1);           // record of this lane in piece widu + 8 k
+      const int pl = L < P_OFF[1] ? 0 : L < P_OFF[2] ? 1 : L < P_OFF[3] ? 2 : 3;
+      const int rc = L - (pl == 0 ? P_OFF[0] : pl == 1 ? P_OFF[1] : pl == 2 ? P_OFF[2] : P_OFF[3]);
+      const int r = rc / PP, cc = rc - r * PP, pr = pl >> 1, pc = pl & 1;
+      const int ch = (lane & 1) ^ ((cc >> 2) & 1);
+      const int gy = gy0 + 2 * r + pr, gx = gx0 + 2 * cc + pc;
+      const bool ok = L < NREC && r < 17 - pr && cc < 17 - pc && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
+      hvo[k] = ok ? 2u * (unsigned)(((b * a.Hin + gy) * a.Win + gx) * a.Cin + ch * 8) : 0xffffffffu;
+    }
+    const int wrow = 32 * (widu & 3) + (lane >> 1);              // weight row of this lane: piece i = widu + 8 k is (tap i / 4, rows 32 (i % 4) ..)
+    const unsigned wvo = n0 + wrow < a.N ? 2u * (unsigned)((n0 + wrow) * a.Kpad + (((lane & 1) ^ ((wrow >> 3) & 1)) * 8)) : 0xffffffffu;
+    auto dma_stage = [&](int h, int buf) {
+      char* S = smem + buf * S2_STAGE;
+      const int cofs = __builtin_amdgcn_readfirstlane(h * 32);   // byte offset of the half-chunk's first channel
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        if (widu + 8 * k < HPIECES)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(S + (widu + 8 * k) * 1024), 16, hvo[k], cofs, 0, 0);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const int i = widu + 8 * k;
+        if (i < 36)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void*)(S + S2_H + i * 1024), 16, wvo,
+                                                   __builtin_amdgcn_readfirstlane(2 * (tt.wt[i >> 2] * a.N * a.Kpad) + h * 32), 0, 0);
+      }
+    };
+    // fragment byte addresses: A = plane (immediate) + row part + one of two column parts ; B = tap (immediate) + row part
+    const int half = lane >> 5, xl = lane & 15, yl = wm * 4 + ((lane & 31) >> 4);
+    int acol[2];
+#pragma unroll
+    for (int sft = 0; sft < 2; ++sft) acol[sft] = yl * (PP * 32) + (xl + sft) * 32 + ((half ^ (((xl + sft) >> 2) & 1)) << 4);
+    const int brl = wn * 64 + (lane & 31);
+    const int baddr = S2_H + brl * 32 + ((half ^ ((brl >> 3) & 1)) << 4);
+    dma_stage(0, 0);
+    __syncthreads();
+    auto half_chunk = [&](auto bufc) {
+      constexpr int buf = decltype(bufc)::value;
+      const char* S = smem + buf * S2_STAGE;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        // the stride-2 forward tap table is row-major over (ky, kx) (see conv_tap_tables): tap t = 3 ky + kx
+        constexpr int dummy = 0; (void)dummy;
+        const int ky = t / 3, kx = t - 3 * (t / 3);
+        const int pbase = P_OFF[(ky & 1) * 2 + (kx & 1)] * 32 + (ky >> 1) * (PP * 32);
+        const int aa = acol[kx >> 1] + pbase;
+        bf16x8 af[2], bf[2];
+        af[0] = *(const bf16x8*)(S + aa);
+        af[1] = *(const bf16x8*)(S + aa + 2 * PP * 32);
+        bf[0] = *(const bf16x8*)(S + baddr + t * 4096);
+        bf[1] = *(const bf16x8*)(S + baddr + t * 4096 + 32 * 32);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+      }
+    };
+    for (int h = 0; h < nh; h += 2) {
+      if (h + 1 < nh) dma_stage(h + 1, 1);
+      half_chunk(std::integral_constant<int, 0>{});
+      __syncthreads();
+      if (h + 1 < nh) {
+        if (h + 2 < nh) dma_stage(h + 2, 0);
+        half_chunk(std::integral_constant<int, 1>{});
+        __syncthreads();
+      }
+    }
+  } else if constexpr (DMA != 0) {
     char* Hb = smem;                                             // 2 halo images
     char* Bb = smem + 2 * DMA_HBUF;                              // 2 (x TP) weight tiles
     const int dslot = lane & 3, widu = __builtin_amdgcn_readfirstlane(wid);
@@ -746,7 +849,7 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
     }
 
 #ifdef HALO_STAMPS
-  if (!M16 && lane == 0 && blockIdx.x < 2048 && blockIdx.y == 0 && blockIdx.z == 0) {
+  if (!M16 && lane == 0 && blockIdx.x < 2048 && nb == 0 && blockIdx.z == 0) {
     unsigned long long* o = g_halo_stamps + ((size_t)blockIdx.x * 8 + wid) * 5;
     o[0] = sA; o[1] = sB; o[2] = sC; o[3] = sD; o[4] = total;
   }
@@ -1208,7 +1311,16 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   const int NBT = (in_mul == 2 && !g_mfma16) ? 4 : 2;             // stride-2 forward stages the weight tiles of two taps per step
   const size_t smem = std::max(((size_t)a.halo_elems + NBT * TILE) * sizeof(__bf16) + (size_t)c.Kpad * sizeof(float),
                                HALO_EPI_SMEM);
-  dim3 grid(c.B * a.tiles_x * a.tiles_y, cdiv(c.Cout, BN), nphase);
+  a.nblocks = cdiv(c.Cout, BN);
+  a.nb_group = 1;
+  if (g_halo_nb_group_kb > 0) {                                   // largest divisor of nblocks whose weights fit the budget
+    int ntaps_all = 0;
+    for (int p = 0; p < nphase; ++p) ntaps_all += c.taps[p].n;
+    const size_t wbytes = (size_t)ntaps_all * BN * c.Kpad * sizeof(__bf16);          // weights one channel block streams per tile
+    for (int gsz = a.nblocks; gsz >= 1; --gsz)
+      if (a.nblocks % gsz == 0 && gsz * wbytes <= (size_t)g_halo_nb_group_kb * 1024) { a.nb_group = gsz; break; }
+  }
+  dim3 grid(c.B * a.tiles_x * a.tiles_y * a.nblocks, 1, nphase);
 #define LAUNCH_HALO(IM, MM, EP)                                                                                         \
   {                                                                                                                     \
     static bool set = false;                                                                                            \
@@ -1219,6 +1331,19 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   {                                                                                                                     \
     if (a.xs) LAUNCH_HALO(IM, MM, 3) else if (a.residual && a.res_half) LAUNCH_HALO(IM, MM, 2)                          \
     else if (a.residual) LAUNCH_HALO(IM, MM, 1) else LAUNCH_HALO(IM, MM, 0)                                             \
+  }
+  if (g_halo_s2dma && in_mul == 2 && nphase == 1 && !g_mfma16 && !a.pre && !a.xs && c.taps[0].n == 9 && c.Cin % 32 == 0 && c.Kpad == c.Cin) {
+    constexpr size_t S2_SMEM = 2 * (size_t)(42 * 1024 + 9 * 4096);      // two half-chunk stages (see the kernel)
+    const size_t dsmem = std::max(S2_SMEM, HALO_EPI_SMEM);
+#define LAUNCH_S2(EP)                                                                                                   \
+  {                                                                                                                     \
+    static bool set = false;                                                                                            \
+    if (!set) { hipFuncSetAttribute((const void*)conv_halo_kernel<2, false, EP, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
+    hipLaunchKernelGGL((conv_halo_kernel<2, false, EP, 3>), grid, dim3(512), dsmem, s, a);                              \
+  }
+    if (a.residual && a.res_half) LAUNCH_S2(2) else if (a.residual) LAUNCH_S2(1) else LAUNCH_S2(0)
+#undef LAUNCH_S2
+    return true;
   }
   const bool mod = a.pre != nullptr;
   bool dma_ok = g_halo_dma && in_mul == 1 && !g_mfma16 && (mod ? g_halo_dma_mod != 0 : !a.xs) && c.Cin % 32 == 0 && c.Kpad == c.Cin;
@@ -1955,6 +2080,8 @@ int lcgan_set_option(int option, int value) {
   if (option == 10) { const int old = g_halo_dma; g_halo_dma = value; return old; }
   if (option == 11) { const int old = g_halo_dma_mod; g_halo_dma_mod = value; return old; }
   if (option == 12) { const int old = g_wgrad_dma; g_wgrad_dma = value; return old; }
+  if (option == 13) { const int old = g_halo_s2dma; g_halo_s2dma = value; return old; }
+  if (option == 14) { const int old = g_halo_nb_group_kb; g_halo_nb_group_kb = value; return old; }
   return LCGAN_EINVAL;
 }
 
