@@ -165,6 +165,7 @@ HALO_VARIANT_CASES = [
     (1, 48, 32, 128, 96, 3, 1),
     (2, 32, 32, 96, 160, 1, 1),
     (1, 32, 64, 64, 64, 3, 2),
+    (2, 64, 64, 96, 160, 3, 2),
     (1, 40, 24, 32, 136, 3, 1),
 ]
 
@@ -174,23 +175,24 @@ HALO_VARIANT_CASES = [
 def test_conv_halo_staging_variants(H, case, variant):
     B, Hh, W, Ci, Co, k, stride = case
     dtype = torch.bfloat16
-    old = [H.lib.lcgan_set_option(6, 0), H.lib.lcgan_set_option(10, variant[0]), H.lib.lcgan_set_option(11, variant[1])]
+    old = [H.lib.lcgan_set_option(6, 0), H.lib.lcgan_set_option(10, variant[0]), H.lib.lcgan_set_option(11, variant[1]), H.lib.lcgan_set_option(13, 1)]
     try:
         scale = 1 / math.sqrt(Ci * k * k)
         w = torch.randn(Co, Ci, k, k, generator=torch.Generator().manual_seed(2))
         bias = torch.randn(Co, generator=torch.Generator().manual_seed(3))
-        if stride == 1:                                                     # forward: plain, epilogue, modulated, residual
+        for s2dma in ((0, 1) if stride == 2 else (1,)):                     # forward: plain, epilogue, modulated, residual
+            H.lib.lcgan_set_option(13, s2dma)                                # (stride 2: both the register-staged and the parity-plane structure)
             x = feat((B, Hh, W, Ci), dtype, 1)
             pw_e, _ = E.prep_weight(w, scale, False, False)
             pw_h, _ = H.prep_weight(w.cuda(), scale, False, False)
-            check(H.conv_fwd(x.cuda(), pw_h, Co, k, 1), E.conv_fwd(x, pw_e, Co, k, 1), dtype, "plain")
-            check(H.conv_fwd(x.cuda(), pw_h, Co, k, 1, bias=bias.cuda(), bias_scale=0.5, act=1, gain=1.4),
-                  E.conv_fwd(x, pw_e, Co, k, 1, bias=bias, bias_scale=0.5, act=1, gain=1.4), dtype, "bias+lrelu")
+            check(H.conv_fwd(x.cuda(), pw_h, Co, k, stride), E.conv_fwd(x, pw_e, Co, k, stride), dtype, "plain")
+            check(H.conv_fwd(x.cuda(), pw_h, Co, k, stride, bias=bias.cuda(), bias_scale=0.5, act=1, gain=1.4),
+                  E.conv_fwd(x, pw_e, Co, k, stride, bias=bias, bias_scale=0.5, act=1, gain=1.4), dtype, "bias+lrelu")
             pre, post = vec((B, Ci), 4), vec((B, ceil8(Co)), 5)
-            res = feat((B, Hh, W, ceil8(Co)), dtype, 6, Co)
-            check(H.conv_fwd(x.cuda(), pw_h, Co, k, 1, residual=res.cuda()), E.conv_fwd(x, pw_e, Co, k, 1, residual=res), dtype, "residual")
-            check(H.conv_fwd(x.cuda(), pw_h, Co, k, 1, pre=pre.cuda(), post=post.cuda(), bias=bias.cuda(), residual=res.cuda()),
-                  E.conv_fwd(x, pw_e, Co, k, 1, pre=pre, post=post, bias=bias, residual=res), dtype, "mod+residual")
+            res = feat((B, Hh // stride, W // stride, ceil8(Co)), dtype, 6, Co)
+            check(H.conv_fwd(x.cuda(), pw_h, Co, k, stride, residual=res.cuda()), E.conv_fwd(x, pw_e, Co, k, stride, residual=res), dtype, "residual")
+            check(H.conv_fwd(x.cuda(), pw_h, Co, k, stride, pre=pre.cuda(), post=post.cuda(), bias=bias.cuda(), residual=res.cuda()),
+                  E.conv_fwd(x, pw_e, Co, k, stride, pre=pre, post=post, bias=bias, residual=res), dtype, "mod+residual")
         # data gradient of the same layer (stride 2: the 4-phase transposed convolution): g has Co channels, the output Ci
         g = feat((B, Hh // stride, W // stride, ceil8(Co)), dtype, 11, Co)
         pw_e, _ = E.prep_weight(w, scale, True, False)
@@ -207,7 +209,7 @@ def test_conv_halo_staging_variants(H, case, variant):
             check(gx_h, gx_e, dtype, "fused gx", l2_scale=2.0)
             check(gs_h, gs_e, dtype, "fused gs", l2_scale=3.0)
     finally:
-        for o, v in zip((6, 10, 11), old):
+        for o, v in zip((6, 10, 11, 13), old):
             H.lib.lcgan_set_option(o, v)
 
 
