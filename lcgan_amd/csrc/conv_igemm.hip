@@ -44,6 +44,7 @@ int g_halo_dma_mod = 1;                   // lcgan_set_option(11, ...): the same
 int g_wgrad_dma = 2;                      // lcgan_set_option(12, ...): LDS-DMA staging in the row-segment weight-gradient kernel (3x3, 64-wide segments, stride 1): 0 = off, 1 = on with the one-workgroup-per-CU split, 2 = on, split for two workgroups per CU; 3 = also stride 2 (measured slower: one workgroup per CU, one chunk of prefetch)
 int g_halo_s2dma = 1;                     // lcgan_set_option(13, ...): stride-2 forward 3x3 on the parity-plane LDS-DMA structure (one barrier per 16-channel half-chunk)
 int g_halo_nb_group_kb = 8192;               // lcgan_set_option(14, ...): KB of weights (all taps x 128 rows x Cin) that concurrent channel blocks of one tile may hold in an XCD's L2; 0 = channel blocks slowest (one pass over the input per block)
+int g_wgrad_xcd = 0;                      // lcgan_set_option(15, ...): row-segment wgrad workgroups of one split share an XCD (1-D grid)
 int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): experiments, bit mask (the wgrad3 no-atomics switch is gone: it sat in the epilogue);
                                           // halo kernel: 8 = linear tile order (the store / emit / main-loop skipping switches used for the
                                           // fixed-cost analysis in DESIGN.md were removed again: they sat in the hot epilogue)
@@ -1393,6 +1394,7 @@ struct WgradArgs {
   int parts;                                 // wgrad3: split = group * parts + part
   int cps_group;                             // wgrad3: chunks per group (group = one sample when per-sample scales exist, else the whole batch)
   float* slab;                               // wgrad3: non-null = every split stores its partial tile to slab[split][tap][A][Bc] (plain stores) instead of atomics
+  int xcd_order, na, nc;                     // wgrad3: 1-D XCD-aware workgroup order (see WG3_INDEX); a / c blocks of 128
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -1542,6 +1544,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 //     rows p*STRIDE + kx through the transposed LDS read),
 //   * (sample, row, segment) decoding is scalar, and chunks whose input row is padding are skipped.
 // =========================================================================================================
+// Workgroup -> (a block, c block, kernel row ky, split).  Every workgroup of one split reads the same chunk range (G rows for its a
+// block, X rows for its c block and ky), so they should share an L2: the grid is 1-D, workgroups go round-robin over the 8 XCDs, and
+// XCD i takes splits i, i + 8, ... with all (a, c, ky) workgroups of a split consecutive on it.  (The 3-D grid put the workgroups of
+// a split on neighbouring XCDs: their common reads met in the Infinity Cache at best.)
+#define WG3_INDEX(NKXV)                                                                                               \
+  int a0, c0, split, ky;                                                                                              \
+  if (a.xcd_order) {                                                                                                  \
+    const int tiles = a.na * a.nc * (NKXV), xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;                             \
+    const int sl = slot / tiles, t = slot - sl * tiles;                                                               \
+    split = sl * 8 + xcd;                                                                                             \
+    if (split >= a.nsplit) return;                                                                                    \
+    a0 = (t % a.na) * 128; c0 = ((t / a.na) % a.nc) * 128; ky = t / (a.na * a.nc);                                    \
+  } else {                                                                                                            \
+    a0 = blockIdx.x * 128; c0 = blockIdx.y * 128;                                                                     \
+    split = blockIdx.z / (NKXV); ky = blockIdx.z - split * (NKXV);                                                    \
+  }
+
 template <int STRIDE>
 __device__ __forceinline__ bf16x8 tr_frag_rows(const __bf16* tile, int row_a, int row_b, int col) {
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + row_a * WG_ROW + col));
@@ -1574,10 +1593,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 2, wn = wid & 3;                    // 8 waves: 2 (a) x 4 (c), wave tile 64 x 32
-  const int a0 = blockIdx.x * 128, c0 = blockIdx.y * 128;
-  // the NKX kernel rows of one chunk range are neighbours in dispatch order: they read the same G rows and overlapping X rows,
-  // so the 2nd and 3rd reads are served by the Infinity Cache instead of HBM
-  const int split = blockIdx.z / NKX, ky = blockIdx.z - split * NKX;
+  WG3_INDEX(NKX)
   const int segs = a.Wm / SEGW;                              // segments per image row (1 for narrow layers)
   const int rgroups = a.Hm / (ROWS * PK);                    // row groups per sample
   // split = (group, part).  With per-sample style / demod scales a group is ONE sample, so the scales can be applied once to
@@ -1736,8 +1752,7 @@ __global__ __launch_bounds__(512, STRIDE == 1 ? 4 : 2) void conv_wgrad3_dma_kern
   constexpr int STAGE_B = (GP + XP) * 1024;                  // bytes per stage
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, widu = __builtin_amdgcn_readfirstlane(wid);
   const int wm = wid >> 2, wn = wid & 3;                    // 8 waves: 2 (a) x 4 (c), wave tile 64 x 32
-  const int a0 = blockIdx.x * 128, c0 = blockIdx.y * 128;
-  const int split = blockIdx.z / NKX, ky = blockIdx.z - split * NKX;
+  WG3_INDEX(NKX)
   const int segs = a.Wm / SEG, rgroups = a.Hm;
   const int bsmp = split / a.parts, part = split - bsmp * a.parts;
   const int cps = a.cps_group;
@@ -2082,6 +2097,7 @@ int lcgan_set_option(int option, int value) {
   if (option == 12) { const int old = g_wgrad_dma; g_wgrad_dma = value; return old; }
   if (option == 13) { const int old = g_halo_s2dma; g_halo_s2dma = value; return old; }
   if (option == 14) { const int old = g_halo_nb_group_kb; g_halo_nb_group_kb = value; return old; }
+  if (option == 15) { const int old = g_wgrad_xcd; g_wgrad_xcd = value; return old; }
   return LCGAN_EINVAL;
 }
 
@@ -2277,7 +2293,9 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
       double best = 1e30;
       for (int pt = 1; pt <= max_parts; ++pt) {
         const int cpsplit = cdiv(cps, pt), real_parts = cdiv(cps, cpsplit);
-        const long long rounds = ((long long)tiles3 * groups * real_parts + 256 * occ - 1) / (256 * occ);
+        // (XCD order: XCD i runs splits i, i + 8, ...: the fullest XCD, 32 CUs, sets the number of rounds)
+        const long long rounds = g_wgrad_xcd ? ((long long)tiles3 * cdiv(groups * real_parts, 8) + 32 * occ - 1) / (32 * occ)
+                                             : ((long long)tiles3 * groups * real_parts + 256 * occ - 1) / (256 * occ);
         const double cost = (double)rounds * (1024.0 + (double)cpsplit * seg);   // (a packed chunk costs what a plain one does)
         if (cost < best) { best = cost; parts = real_parts; }
       }
@@ -2295,7 +2313,9 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
     // launch with enough splits takes the slab.
     if (pk == 1 && g_wgrad_slab_min > 0 && a.nsplit >= g_wgrad_slab_min && slab_bytes <= ((size_t)1 << 30))
       a.slab = wgrad_slab_scratch(slab_bytes);                    // (packed groups: several waves add into one element -> atomics only)
-    dim3 grid3(cdiv(A, 128), cdiv(Bc, 128), nkx * a.nsplit);
+    a.na = cdiv(A, 128); a.nc = cdiv(Bc, 128); a.xcd_order = g_wgrad_xcd;
+    dim3 grid3(a.na, a.nc, nkx * a.nsplit);
+    if (a.xcd_order) grid3 = dim3(8 * a.na * a.nc * nkx * cdiv(a.nsplit, 8), 1, 1);
 #define LAUNCH_WG3(ST, SG, SW, NK)                                                                                      \
     {                                                                                                                   \
       static bool set = false;                                                                                          \
