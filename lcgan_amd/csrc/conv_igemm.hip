@@ -1021,16 +1021,20 @@ __global__ __launch_bounds__(512, RW == 2 ? 4 : 2) void conv_halo_narrow_kernel(
   const int gy0 = ty * NTH + hy0, gx0 = tx * NTW + hx0;
 
   const int hvec = tid & 3;
-  int goff[NI], loff[NI];
+  // (raw buffer loads as in conv_halo_kernel: scalar resource + one 32-bit byte offset per lane, zeros by the range check)
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(2u * (unsigned)(a.B * a.Hin * a.Win * a.Cin)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
+  unsigned goff[NI];
+  int loff[NI];
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
     const int hp = (tid >> 2) + k * 128;
-    loff[k] = -1; goff[k] = -1;
+    loff[k] = -1; goff[k] = 0xffffffffu;
     if (hp < hh * hw) {
       const int hy = hp / hw, hx = hp - hy * hw;
       const int gy = gy0 + hy, gx = gx0 + hx;
       loff[k] = hp * HROW + hvec * 8;
-      if ((unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win) goff[k] = ((b * a.Hin + gy) * a.Win + gx) * a.Cin + hvec * 8;
+      if ((unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win) goff[k] = 2u * (unsigned)(((b * a.Hin + gy) * a.Win + gx) * a.Cin + hvec * 8);
     }
   }
   bf16x8 hreg[NI];
@@ -1043,8 +1047,8 @@ __global__ __launch_bounds__(512, RW == 2 ? 4 : 2) void conv_halo_narrow_kernel(
     h_c0 = c0;
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
-      const bool ok = goff[k] >= 0 && c0 + hvec * 8 < a.Cin;
-      hreg[k] = ok ? *(const bf16x8*)(a.x + (size_t)goff[k] + c0) : zero_bf16x8();
+      const unsigned go = c0 + hvec * 8 < a.Cin ? goff[k] : 0xffffffffu;
+      hreg[k] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xres, go, __builtin_amdgcn_readfirstlane(c0 * 2), 0));
     }
   };
   auto halo_store = [&]() {
@@ -1063,10 +1067,10 @@ __global__ __launch_bounds__(512, RW == 2 ? 4 : 2) void conv_halo_narrow_kernel(
   // weight tile: BNn rows x 4 vectors, one item per thread (threads beyond it idle); prefetched two taps ahead
   const int brow = tid >> 2;
   const int ntaps = tt.n, nchunks = a.kc_per_tap, total = ntaps * nchunks;
-  const size_t wrow = (size_t)(n0 + brow) * a.Kpad + hvec * 8;
+  const unsigned wrow = 2u * (unsigned)((n0 + brow) * a.Kpad + hvec * 8);
   const bool bthread = brow < BNn, bvalid = bthread && n0 + brow < a.N;
   auto b_load = [&](int c, int t) -> bf16x8 {
-    return bvalid ? *(const bf16x8*)(a.w + (size_t)tt.wt[t] * a.N * a.Kpad + wrow + c * BK) : zero_bf16x8();
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wres, bvalid ? wrow : 0xffffffffu, __builtin_amdgcn_readfirstlane(2 * (tt.wt[t] * a.N * a.Kpad + c * BK)), 0));
   };
   auto b_store = [&](int buf, const bf16x8& r) { if (bthread) *(bf16x8*)(Bt + buf * BTILE + brow * HROW + hvec * 8) = r; };
 
