@@ -306,21 +306,38 @@ __global__ void act_bwd_reduce_kernel(const T* __restrict__ gy, const T* __restr
     for (int j = 0; j < 8; ++j) bv[j] = (v * 8 + j < Clog) ? bias[v * 8 + j] * bias_scale : 0.f;
   }
   if (active) {
-    for (int p = p0 + grp; p < p1; p += groups) {
-      const size_t off = ((size_t)b * HW + p) * C + v * 8;
-      const F8 g = Feat<T>::load(gy + off);
-      F8 yo = f8_zero();
-      if (act != ACT_NONE || gdq) yo = Feat<T>::load(y + off);
+    const bool need_y = act != ACT_NONE || gdq;
+    const float inv_gain = 1.f / gain;
+    auto one = [&](size_t off, const F8& g, const F8& yo) {
       F8 z;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         z.v[j] = g.v[j] * act_grad_from_out(yo.v[j], act, gain);
         sb[j] += z.v[j];
-        float t = yo.v[j] / gain;
+        float t = yo.v[j] * inv_gain;
         if (act == ACT_LRELU && t < 0.f) t *= (1.f / LRELU_SLOPE);
         sq[j] += z.v[j] * (t - bv[j]);
       }
       if (gz) Feat<T>::store(gz + off, z);
+    };
+    // four pixels per trip: all eight loads are issued before the first is used (a thread otherwise has one pixel in flight)
+    int p = p0 + grp;
+    for (; p + 3 * groups < p1; p += 4 * groups) {
+      size_t off[4]; F8 g[4], yo[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        off[u] = ((size_t)b * HW + p + u * groups) * C + v * 8;
+        g[u] = Feat<T>::load(gy + off[u]);
+        yo[u] = need_y ? Feat<T>::load(y + off[u]) : f8_zero();
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(off[u], g[u], yo[u]);
+    }
+    for (; p < p1; p += groups) {
+      const size_t off = ((size_t)b * HW + p) * C + v * 8;
+      const F8 g = Feat<T>::load(gy + off);
+      const F8 yo = need_y ? Feat<T>::load(y + off) : f8_zero();
+      one(off, g, yo);
     }
   }
   if (!gbias && !gdq) return;
