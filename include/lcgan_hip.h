@@ -148,7 +148,15 @@ int lcgan_avg_latent(const float* w, float* avg, int B, int D, float beta, void*
 int lcgan_multi_tensor(const void* descs, const int* chunk_tensor, const int* chunk_index, int n_chunks, int op,
                        float a0, float a1, float a2, double total_elems, void* stream);
 
-/* tuning switches (A/B tests): option 0 = bf16 halo-tile conv kernel on/off; returns the previous value */
+/* tuning switches (A/B tests inside one process; every one only ROUTES between kernels that compute the same result); returns the
+ * previous value, LCGAN_EINVAL for an unknown option.  0 bf16 halo-tile conv kernels on/off; 1 split-K for small-M convolutions;
+ * 2 explicit workgroup target of the row-segment weight gradient (0 = cost model); 3 debug bits; 4 16x16x32 MFMA shape; 5 narrow /
+ * 1x1 routing of the row-segment weight gradient; 6 smallest halo grid before the split-K GEMM takes over; 7 smallest grid of the
+ * narrow-layer kernel; 8 smallest split count that reduces through a slab; 9 packed channel groups; 10 LDS-DMA staging of the halo
+ * kernel (0 off, 1 / 2 = taps per barrier); 11 the same record layout for convolutions with per-sample input scales; 12 LDS-DMA
+ * weight-gradient kernel (0 off, 1, 2 = split for two workgroups per CU, 3 = also stride 2); 13 parity-plane stride-2 forward;
+ * 14 KB of weights concurrent channel blocks of one tile may keep in an XCD's L2 (0 = one input pass per channel block);
+ * 15 XCD-grouped weight-gradient workgroup order.  DESIGN.md section 2 ("Switches") has the measurements behind the defaults. */
 int lcgan_set_option(int option, int value);
 
 /* ---- per-launch HIP-event profiling (bench.py roofline) ---------------------------------------------------- */
