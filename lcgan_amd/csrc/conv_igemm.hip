@@ -40,7 +40,7 @@ int g_wgrad_slab_min = 4;                 // lcgan_set_option(8, ...): row-segme
 int g_halo_narrow_min_wgs = 256;          // lcgan_set_option(7, ...): narrow-layer halo kernel (Cout <= 64, 16 x 32 tiles) from this many workgroups; 0 = never
 int g_wgrad3_pack = 1;                    // lcgan_set_option(9, ...): packed channel groups in the row-segment wgrad kernel for layers with <= 64 channels
 int g_halo_dma = 2;                       // lcgan_set_option(10, ...): LDS-DMA staging in the halo kernel (stride-1 geometries without input scales)
-int g_halo_dma_mod = 1;                   // lcgan_set_option(11, ...): the same structure for convolutions with per-sample input scales (halo through registers): 0 = off, 1 / 2 = taps per step
+int g_halo_dma_mod = 2;                   // lcgan_set_option(11, ...): the same structure for convolutions with per-sample input scales (halo by DMA, scaled in place in LDS): 0 = off, 1 / 2 = taps per step
 int g_wgrad_dma = 2;                      // lcgan_set_option(12, ...): LDS-DMA staging in the row-segment weight-gradient kernel (3x3, 64-wide segments, stride 1): 0 = off, 1 = on with the one-workgroup-per-CU split, 2 = on, split for two workgroups per CU; 3 = also stride 2 (measured slower: one workgroup per CU, one chunk of prefetch)
 int g_halo_s2dma = 1;                     // lcgan_set_option(13, ...): stride-2 forward 3x3 on the parity-plane LDS-DMA structure (one barrier per 16-channel half-chunk)
 int g_halo_nb_group_kb = 8192;               // lcgan_set_option(14, ...): KB of weights (all taps x 128 rows x Cin) that concurrent channel blocks of one tile may hold in an XCD's L2; 0 = channel blocks slowest (one pass over the input per block)
@@ -557,11 +557,12 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
       const bool ok = hy < hh && hx < hw && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
       hvo[k] = ok ? 2u * (unsigned)(((b * a.Hin + gy) * a.Win + gx) * a.Cin + ch * 8) : 0xffffffffu;
     }
-    // MOD (per-sample input scales: modulated convolutions and their data gradients): the halo pieces travel through registers
-    // into the SAME swizzled records -- loaded when a chunk starts, multiplied by the sample's channel scales and written to the
-    // other image in the chunk's last step (two images: no extra barrier); the weight tiles still go by LDS-DMA
+    // MOD (per-sample input scales: modulated convolutions and their data gradients): the halo goes by LDS-DMA like every other
+    // one and each lane then multiplies ITS OWN 16-byte pieces in place (ds_read -> 8 multiplies -> ds_write) in the last step of the
+    // previous chunk, right before that step's barrier: a DMA'd piece is visible to the wave that issued it after its vmcnt(0),
+    // which the barrier's wait would have taken anyway, so no staging registers live across the taps (the register-staged version
+    // of this held 12 VGPRs per chunk: 133 VGPRs at two taps per barrier).
     float* dpsc = (float*)(smem + 2 * DMA_HBUF + 2 * DMA * DMA_BBUF);        // [Cin] scales of this workgroup's sample
-    bf16x8 hreg[MOD ? 3 : 1];
     int hch[3];                                                  // this lane's channel offset within a chunk, per piece
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -570,29 +571,24 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
     }
     int h_c0 = 0;
     auto dma_halo = [&](int c0, int buf) {
-      if constexpr (MOD) {
-        h_c0 = c0;
+      h_c0 = c0;
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-          hreg[k] = hdo[k] ? __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xres, hvo[k], __builtin_amdgcn_readfirstlane(c0 * 2), 0))
-                           : zero_bf16x8();
-      } else {
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-          if (hdo[k])
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(Hb + buf * DMA_HBUF + (widu + 8 * k) * 1024), 16, hvo[k],
-                                                     __builtin_amdgcn_readfirstlane(c0 * 2), 0, 0);
-      }
+      for (int k = 0; k < 3; ++k)
+        if (hdo[k])
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(Hb + buf * DMA_HBUF + (widu + 8 * k) * 1024), 16, hvo[k],
+                                                   __builtin_amdgcn_readfirstlane(c0 * 2), 0, 0);
     };
-    auto halo_store_mod = [&](int buf) {
+    auto scale_inplace = [&](int buf) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces have landed
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         if (!hdo[k]) continue;
+        bf16x8* ptr = (bf16x8*)(Hb + buf * DMA_HBUF + (widu + 8 * k) * 1024 + lane * 16);
         const f32x4 s0 = *(const f32x4*)(dpsc + h_c0 + hch[k]), s1 = *(const f32x4*)(dpsc + h_c0 + hch[k] + 4);
-        bf16x8 v = hreg[k];
+        bf16x8 v = *ptr;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (__bf16)((float)v[j] * (j < 4 ? s0[j] : s1[j - 4]));
-        *(bf16x8*)(Hb + buf * DMA_HBUF + (widu + 8 * k) * 1024 + lane * 16) = v;
+        *ptr = v;
       }
     };
     // weights: wave `wid` moves rows 16 wid .. 16 wid + 15 x 4 slots
@@ -627,7 +623,7 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
     dma_halo(0, 0);
     dma_b(0, 0, 0);
     advance();
-    if constexpr (MOD) halo_store_mod(0);
+    if constexpr (MOD) scale_inplace(0);
     __syncthreads();
     int c = 0, g = 0;
     bf16x8 af[2][2], bf[2][2];
@@ -669,7 +665,7 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
       mfmas(0);
       mfmas(1);
       if constexpr (MOD) {
-        if (g == ngroups - 1 && c + 1 < nchunks) halo_store_mod((c + 1) & 1);
+        if (g == ngroups - 1 && c + 1 < nchunks) scale_inplace((c + 1) & 1);
       }
       __syncthreads();                                           // (waits for this step's DMA: vmcnt(0), then the barrier)
       if (++g == ngroups) { g = 0; ++c; }
