@@ -42,7 +42,7 @@ int g_wgrad3_pack = 1;                    // lcgan_set_option(9, ...): packed ch
 int g_halo_dma = 2;                       // lcgan_set_option(10, ...): LDS-DMA staging in the halo kernel (stride-1 geometries without input scales)
 int g_halo_dma_mod = 2;                   // lcgan_set_option(11, ...): the same structure for convolutions with per-sample input scales (halo by DMA, scaled in place in LDS): 0 = off, 1 / 2 = taps per step
 int g_wgrad_dma = 2;                      // lcgan_set_option(12, ...): LDS-DMA staging in the row-segment weight-gradient kernel (3x3, 64-wide segments, stride 1): 0 = off, 1 = on with the one-workgroup-per-CU split, 2 = on, split for two workgroups per CU; 3 = also stride 2 (measured slower: one workgroup per CU, one chunk of prefetch)
-int g_halo_s2dma = 1;                     // lcgan_set_option(13, ...): stride-2 forward 3x3 on the parity-plane LDS-DMA structure (one barrier per 16-channel half-chunk)
+int g_halo_s2dma = 2;                     // lcgan_set_option(13, ...): stride-2 forward 3x3 on the parity-plane LDS-DMA structure (one barrier per 16-channel half-chunk): 0 off, 1 = layers without per-sample input scales, 2 = all
 int g_halo_nb_group_kb = 8192;               // lcgan_set_option(14, ...): KB of weights (all taps x 128 rows x Cin) that concurrent channel blocks of one tile may hold in an XCD's L2; 0 = channel blocks slowest (one pass over the input per block)
 int g_wgrad_xcd = 0;                      // lcgan_set_option(15, ...): row-segment wgrad workgroups of one split share an XCD (1-D grid)
 int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): experiments, bit mask (the wgrad3 no-atomics switch is gone: it sat in the epilogue);
@@ -326,7 +326,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 template <int IN_MUL, bool M16, int EPI, int DMA = 0, bool MOD = false>
 __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_kernel(HaloArgs a) {
-  static_assert(DMA == 0 || (IN_MUL == 1 && DMA <= 2 && !M16 && (MOD || EPI != 3)) || (IN_MUL == 2 && DMA == 3 && !M16 && !MOD && EPI != 3),
+  static_assert(DMA == 0 || (IN_MUL == 1 && DMA <= 2 && !M16 && (MOD || EPI != 3)) || (IN_MUL == 2 && DMA == 3 && !M16 && (MOD || EPI != 3)),
                 "LDS-DMA staging: stride-1 geometries (1 / 2 taps per barrier) or the stride-2 forward structure (DMA == 3)");
   static_assert(!MOD || DMA != 0, "MOD: the swizzled-record structure with the halo staged through registers (per-sample input scales)");
   constexpr bool SR = EPI == 3;
@@ -484,6 +484,34 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
     }
     const int wrow = 32 * (widu & 3) + (lane >> 1);              // weight row of this lane: piece i = widu + 8 k is (tap i / 4, rows 32 (i % 4) ..)
     const unsigned wvo = n0 + wrow < a.N ? 2u * (unsigned)((n0 + wrow) * a.Kpad + (((lane & 1) ^ ((wrow >> 3) & 1)) * 8)) : 0xffffffffu;
+    // MOD: per-sample input scales are applied in place by the lanes that issued the pieces (see the stride-1 structure)
+    float* dpsc = (float*)(smem + 2 * S2_STAGE);                 // [Cin]
+    int hch6[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int L = 32 * (widu + 8 * k) + (lane >> 1);
+      const int pl = L < P_OFF[1] ? 0 : L < P_OFF[2] ? 1 : L < P_OFF[3] ? 2 : 3;
+      const int rc = L - (pl == 0 ? P_OFF[0] : pl == 1 ? P_OFF[1] : pl == 2 ? P_OFF[2] : P_OFF[3]);
+      hch6[k] = ((lane & 1) ^ (((rc % PP) >> 2) & 1)) * 8;
+    }
+    auto scale_stage = [&](int h, int buf) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      char* S = smem + buf * S2_STAGE;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        if (widu + 8 * k >= HPIECES) continue;
+        bf16x8* ptr = (bf16x8*)(S + (widu + 8 * k) * 1024 + lane * 16);
+        const f32x4 s0 = *(const f32x4*)(dpsc + h * 16 + hch6[k]), s1 = *(const f32x4*)(dpsc + h * 16 + hch6[k] + 4);
+        bf16x8 v = *ptr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)((float)v[j] * (j < 4 ? s0[j] : s1[j - 4]));
+        *ptr = v;
+      }
+    };
+    if constexpr (MOD) {
+      for (int i = tid; i < a.Cin; i += 512) dpsc[i] = a.pre[(size_t)b * a.Cin + i];
+      __syncthreads();
+    }
     auto dma_stage = [&](int h, int buf) {
       char* S = smem + buf * S2_STAGE;
       const int cofs = __builtin_amdgcn_readfirstlane(h * 32);   // byte offset of the half-chunk's first channel
@@ -507,6 +535,7 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
     const int brl = wn * 64 + (lane & 31);
     const int baddr = S2_H + brl * 32 + ((half ^ ((brl >> 3) & 1)) << 4);
     dma_stage(0, 0);
+    if constexpr (MOD) scale_stage(0, 0);
     __syncthreads();
     auto half_chunk = [&](auto bufc) {
       constexpr int buf = decltype(bufc)::value;
@@ -527,16 +556,19 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ni], af[mi], acc[mi][ni], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
       }
     };
     for (int h = 0; h < nh; h += 2) {
       if (h + 1 < nh) dma_stage(h + 1, 1);
       half_chunk(std::integral_constant<int, 0>{});
+      if constexpr (MOD) { if (h + 1 < nh) scale_stage(h + 1, 1); }
       __syncthreads();
       if (h + 1 < nh) {
         if (h + 2 < nh) dma_stage(h + 2, 0);
         half_chunk(std::integral_constant<int, 1>{});
+        if constexpr (MOD) { if (h + 2 < nh) scale_stage(h + 2, 0); }
         __syncthreads();
       }
     }
@@ -1333,9 +1365,21 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
     if (a.xs) LAUNCH_HALO(IM, MM, 3) else if (a.residual && a.res_half) LAUNCH_HALO(IM, MM, 2)                          \
     else if (a.residual) LAUNCH_HALO(IM, MM, 1) else LAUNCH_HALO(IM, MM, 0)                                             \
   }
-  if (g_halo_s2dma && in_mul == 2 && nphase == 1 && !g_mfma16 && !a.pre && !a.xs && c.taps[0].n == 9 && c.Cin % 32 == 0 && c.Kpad == c.Cin) {
+  if (g_halo_s2dma && in_mul == 2 && nphase == 1 && !g_mfma16 && (a.pre ? g_halo_s2dma >= 2 : !a.xs) && c.taps[0].n == 9 && c.Cin % 32 == 0 && c.Kpad == c.Cin &&
+      (!a.pre || c.Cin <= 1024)) {
     constexpr size_t S2_SMEM = 2 * (size_t)(42 * 1024 + 9 * 4096);      // two half-chunk stages (see the kernel)
-    const size_t dsmem = std::max(S2_SMEM, HALO_EPI_SMEM);
+    const size_t dsmem = std::max(S2_SMEM + (a.pre ? (size_t)c.Cin * sizeof(float) : 0), HALO_EPI_SMEM);
+#define LAUNCH_S2M(EP)                                                                                                  \
+  {                                                                                                                     \
+    static bool set = false;                                                                                            \
+    if (!set) { hipFuncSetAttribute((const void*)conv_halo_kernel<2, false, EP, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
+    hipLaunchKernelGGL((conv_halo_kernel<2, false, EP, 3, true>), grid, dim3(512), dsmem, s, a);                        \
+  }
+    if (a.pre) {
+      if (a.xs) LAUNCH_S2M(3) else if (a.residual && a.res_half) LAUNCH_S2M(2) else if (a.residual) LAUNCH_S2M(1) else LAUNCH_S2M(0)
+      return true;
+    }
+#undef LAUNCH_S2M
 #define LAUNCH_S2(EP)                                                                                                   \
   {                                                                                                                     \
     static bool set = false;                                                                                            \
