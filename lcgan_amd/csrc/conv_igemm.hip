@@ -45,6 +45,7 @@ int g_wgrad_dma = 2;                      // lcgan_set_option(12, ...): LDS-DMA 
 int g_halo_s2dma = 2;                     // lcgan_set_option(13, ...): stride-2 forward 3x3 on the parity-plane LDS-DMA structure (one barrier per 16-channel half-chunk): 0 off, 1 = layers without per-sample input scales, 2 = all
 int g_halo_nb_group_kb = 8192;               // lcgan_set_option(14, ...): KB of weights (all taps x 128 rows x Cin) that concurrent channel blocks of one tile may hold in an XCD's L2; 0 = channel blocks slowest (one pass over the input per block)
 int g_wgrad_xcd = 0;                      // lcgan_set_option(15, ...): row-segment wgrad workgroups of one split share an XCD (1-D grid)
+int g_igemm_dma = 1;                      // lcgan_set_option(16, ...): LDS-DMA staging in the generic implicit-GEMM kernel (bf16, no input scales, Cin % 32 == 0)
 int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): experiments, bit mask (the wgrad3 no-atomics switch is gone: it sat in the epilogue);
                                           // halo kernel: 8 = linear tile order (the store / emit / main-loop skipping switches used for the
                                           // fixed-cost analysis in DESIGN.md were removed again: they sat in the hot epilogue)
@@ -91,12 +92,19 @@ __device__ __forceinline__ bf16x8 zero_bf16x8() {
   return r;
 }
 
-template <typename T, int P>
+// DMAQ (bf16, P = 1, no per-sample input scales, Cin % 32 == 0): both operand tiles are staged by LDS-DMA as unpadded 64-byte
+// records (row x 32 channels) with the four 16-byte slots XOR-swizzled through the source address (slot = chunk ^ ((row >> 2) & 3):
+// conflict-free ds_read_b128), as in conv_halo_kernel: a step then issues 4 DMA pieces per wave instead of 4 loads, 2 fp32 round
+// trips and 4 LDS stores per thread, and the im2col address work is two adds and a range check per piece.  This is the kernel of
+// the low-resolution layers (4 x 4 ... 16 x 16 grids, and every layer whose halo grid would leave CUs idle: split-K partials).
+typedef __attribute__((address_space(3))) void lds_void_g;
+template <typename T, int P, bool DMAQ = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  static_assert(!DMAQ || P == 1, "LDS-DMA staging: bf16 operands");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = 2 * P;                            // operand tiles per stage: A parts 0..P-1, then B parts 0..P-1
   __bf16* lds = (__bf16*)smem;
-  int* row_off = (int*)(smem + 2 * NT * TILE * sizeof(__bf16));
+  int* row_off = (int*)(smem + (DMAQ ? 4 * 128 * 64 : 2 * NT * TILE * sizeof(__bf16)));   // (DMAQ: two stages of two 8-KB tiles)
   int* row_b = row_off + BM;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -212,6 +220,72 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int nq_all = tt.n * a.kc_per_tap;
   const int per = (nq_all + a.nsplit - 1) / a.nsplit;
   const int q0 = split * per, nq = min(q0 + per, nq_all);
+  if constexpr (DMAQ) {
+    if constexpr (sizeof(T) == 2) {
+    constexpr int QT = 128 * 64;                                 // bytes per operand tile; a stage = A then B
+    const int widu = __builtin_amdgcn_readfirstlane(wid);
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(2u * (unsigned)(a.B * a.Hin * a.Win * a.Cin)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
+    // pieces i = widu, widu + 4 of each tile: rows 16 i .. 16 i + 15, four slots per row
+    int abase[2], aiy[2], aix[2];
+    unsigned wvo[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int row = 16 * (widu + 4 * k) + (lane >> 2), ch = ((lane & 3) ^ ((row >> 2) & 3)) * 8;
+      const int m = m0 + row;
+      const bool ok = m < a.M;
+      const int mm = ok ? m : 0;
+      const int b = mm / HWm, rem = mm - b * HWm;
+      const int iy = (rem / a.Wm) * a.in_mul, ix = (rem % a.Wm) * a.in_mul;
+      aiy[k] = ok ? iy : -0x40000000; aix[k] = ix;
+      abase[k] = 2 * (((b * a.Hin + iy) * a.Win + ix) * a.Cin + ch);
+      const int n = n0 + row;
+      wvo[k] = n < a.N ? 2u * (unsigned)(n * a.Kpad + ch) : 0xffffffffu;
+    }
+    auto dma = [&](int q, int buf) {
+      const int tap = q / a.kc_per_tap, c0 = (q - tap * a.kc_per_tap) * BK;
+      const int dy = tt.dy[tap], dx = tt.dx[tap];
+      const int tofs = 2 * ((dy * a.Win + dx) * a.Cin + c0);
+      char* S = smem + buf * 2 * QT;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const bool ok = (unsigned)(aiy[k] + dy) < (unsigned)a.Hin && (unsigned)(aix[k] + dx) < (unsigned)a.Win;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void_g*)(S + (widu + 4 * k) * 1024), 16, ok ? (unsigned)(abase[k] + tofs) : 0xffffffffu, 0, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void_g*)(S + QT + (widu + 4 * k) * 1024), 16, wvo[k],
+                                                 __builtin_amdgcn_readfirstlane(2 * (tt.wt[tap] * a.N * a.Kpad + c0)), 0, 0);
+    };
+    const int half = lane >> 5, sw = (lane >> 2) & 3;
+    const int fa0 = (wm * 64 + (lane & 31)) * 64 + ((half ^ sw) << 4);          // mi = 1: + 32 rows; k-step 1: ^ 32
+    const int fb0 = QT + (wn * 64 + (lane & 31)) * 64 + ((half ^ sw) << 4);
+    auto computeq = [&](int buf) {
+      const char* S = smem + buf * 2 * QT;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[2], bf[2];
+        af[0] = *(const bf16x8*)(S + (fa0 ^ (ks * 32)));
+        af[1] = *(const bf16x8*)(S + (fa0 ^ (ks * 32)) + 32 * 64);
+        bf[0] = *(const bf16x8*)(S + (fb0 ^ (ks * 32)));
+        bf[1] = *(const bf16x8*)(S + (fb0 ^ (ks * 32)) + 32 * 64);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+      }
+    };
+    if (q0 < nq) dma(q0, 0);
+    __syncthreads();
+    for (int q = q0; q < nq; ++q) {
+      const int cur = (q - q0) & 1;
+      if (q + 1 < nq) dma(q + 1, cur ^ 1);
+      computeq(cur);
+      __syncthreads();
+    }
+    }
+  } else {
   if (q0 < nq) {
     gload(q0);
     sstore(0);
@@ -223,6 +297,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     compute(cur);
     if (q + 1 < nq) sstore(cur ^ 1);
     __syncthreads();
+  }
   }
 
   if (a.nsplit > 1) {                       // split-K: raw partial sums; lcgan finalize kernel applies the epilogue
@@ -2086,7 +2161,12 @@ int launch_igemm(const ConvArgs& a, int nphase, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(cdiv(a.M, BM), cdiv(a.Cout, BN), nphase * a.nsplit);
-  hipLaunchKernelGGL((conv_igemm_kernel<T, NS>), grid, dim3(256), smem, s, a);
+  bool dmaq = false;
+  if constexpr (NS == 1 && sizeof(T) == 2) {
+    dmaq = g_igemm_dma && !a.pre && a.Cin % 32 == 0 && a.Kpad == a.Cin && (long long)a.B * a.Hin * a.Win * a.Cin < (1ll << 31);
+    if (dmaq) hipLaunchKernelGGL((conv_igemm_kernel<T, NS, true>), grid, dim3(256), (size_t)(4 * 128 * 64 + 2 * BM * sizeof(int)), s, a);
+  }
+  if (!dmaq) hipLaunchKernelGGL((conv_igemm_kernel<T, NS>), grid, dim3(256), smem, s, a);
   if (a.nsplit > 1) launch_finalize<T>(a, a.ws, s);
   return launch_status();
 }
@@ -2142,6 +2222,7 @@ int lcgan_set_option(int option, int value) {
   if (option == 13) { const int old = g_halo_s2dma; g_halo_s2dma = value; return old; }
   if (option == 14) { const int old = g_halo_nb_group_kb; g_halo_nb_group_kb = value; return old; }
   if (option == 15) { const int old = g_wgrad_xcd; g_wgrad_xcd = value; return old; }
+  if (option == 16) { const int old = g_igemm_dma; g_igemm_dma = value; return old; }
   return LCGAN_EINVAL;
 }
 
