@@ -41,7 +41,7 @@ int g_halo_narrow_min_wgs = 256;          // lcgan_set_option(7, ...): narrow-la
 int g_wgrad3_pack = 1;                    // lcgan_set_option(9, ...): packed channel groups in the row-segment wgrad kernel for layers with <= 64 channels
 int g_halo_dma = 2;                       // lcgan_set_option(10, ...): LDS-DMA staging in the halo kernel (stride-1 geometries without input scales)
 int g_halo_dma_mod = 2;                   // lcgan_set_option(11, ...): the same structure for convolutions with per-sample input scales (halo by DMA, scaled in place in LDS): 0 = off, 1 / 2 = taps per step
-int g_wgrad_dma = 2;                      // lcgan_set_option(12, ...): LDS-DMA staging in the row-segment weight-gradient kernel (3x3, 64-wide segments, stride 1): 0 = off, 1 = on with the one-workgroup-per-CU split, 2 = on, split for two workgroups per CU; 3 = also stride 2 (measured slower: one workgroup per CU, one chunk of prefetch)
+int g_wgrad_dma = 3;                      // lcgan_set_option(12, ...): LDS-DMA staging in the row-segment weight-gradient kernel (3x3): 0 = off, 1 = stride 1 with the one-workgroup-per-CU split, 2 = stride 1, split for two workgroups per CU, 3 = also stride 2 (32-position chunks)
 int g_halo_s2dma = 2;                     // lcgan_set_option(13, ...): stride-2 forward 3x3 on the parity-plane LDS-DMA structure (one barrier per 16-channel half-chunk): 0 off, 1 = layers without per-sample input scales, 2 = all
 int g_halo_nb_group_kb = 8192;               // lcgan_set_option(14, ...): KB of weights (all taps x 128 rows x Cin) that concurrent channel blocks of one tile may hold in an XCD's L2; 0 = channel blocks slowest (one pass over the input per block)
 int g_wgrad_xcd = 0;                      // lcgan_set_option(15, ...): row-segment wgrad workgroups of one split share an XCD (1-D grid)
@@ -1861,13 +1861,15 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
 // f(r) = r & 3 for G and (r >> (STRIDE - 1)) & 3 for X, so the four rows a transposed 4 x 16 block read touches sit in four
 // different bank groups, exactly as the 320-byte padded pitch of the register-staged kernel arranged.
 // =========================================================================================================
+// positions per chunk: 64 at stride 1; 32 at stride 2, where a 64-position chunk (16 + 33 KB per stage) would leave one workgroup per CU
 template <int STRIDE>
-__global__ __launch_bounds__(512, STRIDE == 1 ? 4 : 2) void conv_wgrad3_dma_kernel(WgradArgs a) {
+__global__ __launch_bounds__(512, 4) void conv_wgrad3_dma_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int SEG = 64, NKX = 3;
+  constexpr int SEG = STRIDE == 1 ? 64 : 32, NKX = 3;
   constexpr int XW = SEG * STRIDE + 2;                       // halo pixels of a row segment
   constexpr int GP = SEG / 4, XP = (XW + 3) / 4;             // 1-KB DMA pieces (4 records each) of G and X
   constexpr int NXI = (XP + 7) / 8;                          // X pieces per wave
+  constexpr int NGI = (GP + 7) / 8;                          // G pieces per wave
   constexpr int STAGE_B = (GP + XP) * 1024;                  // bytes per stage
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, widu = __builtin_amdgcn_readfirstlane(wid);
   const int wm = wid >> 2, wn = wid & 3;                    // 8 waves: 2 (a) x 4 (c), wave tile 64 x 32
@@ -1885,7 +1887,7 @@ __global__ __launch_bounds__(512, STRIDE == 1 ? 4 : 2) void conv_wgrad3_dma_kern
   const int lrec = lane >> 4, slot = lane & 15;
   unsigned goffs[2];                                         // G piece i = widu + 8 k : positions 4 i .. 4 i + 3
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < NGI; ++k) {
     const int pos = 4 * (widu + 8 * k) + lrec;
     const int ch = (slot ^ ((pos & 3) << 2)) * 8;
     goffs[k] = a0 + ch < a.Cg ? 2u * (unsigned)(pos * a.Cg + a0 + ch) : 0xffffffffu;
@@ -1904,8 +1906,9 @@ __global__ __launch_bounds__(512, STRIDE == 1 ? 4 : 2) void conv_wgrad3_dma_kern
     char* G = smem + buf * STAGE_B;
     const int gbase = 2 * (((b * a.Hm + row0) * a.Wm + j0) * a.Cg);
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(gres, (lds_void*)(G + (widu + 8 * k) * 1024), 16, goffs[k], __builtin_amdgcn_readfirstlane(gbase), 0, 0);
+    for (int k = 0; k < NGI; ++k)
+      if (widu + 8 * k < GP)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(gres, (lds_void*)(G + (widu + 8 * k) * 1024), 16, goffs[k], __builtin_amdgcn_readfirstlane(gbase), 0, 0);
     const int yy = row0 * STRIDE + ky - 1, x0 = j0 * STRIDE;
     const bool yok = (unsigned)yy < (unsigned)a.Hx;
     const int xbase = 2 * (((b * a.Hx + yy) * a.Wx + x0) * a.Cx);
@@ -1945,8 +1948,7 @@ __global__ __launch_bounds__(512, STRIDE == 1 ? 4 : 2) void conv_wgrad3_dma_kern
     s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
   };
-  auto compute = [&](auto bufc) {
-    constexpr int buf = decltype(bufc)::value;
+  auto compute = [&](int buf) {
     const char* S = smem + buf * STAGE_B;
 #pragma unroll
     for (int ks = 0; ks < SEG / 16; ++ks) {
@@ -1967,11 +1969,11 @@ __global__ __launch_bounds__(512, STRIDE == 1 ? 4 : 2) void conv_wgrad3_dma_kern
   __syncthreads();
   for (int q = q_begin; q < q_end; q += 2) {
     if (q + 1 < q_end) dma(q + 1, 1);
-    compute(std::integral_constant<int, 0>{});
+    compute(0);
     __syncthreads();                                         // (vmcnt(0): the next chunk has landed; then the barrier)
     if (q + 1 < q_end) {
       if (q + 2 < q_end) dma(q + 2, 0);
-      compute(std::integral_constant<int, 1>{});
+      compute(1);
       __syncthreads();
     }
   }
@@ -2387,7 +2389,12 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
   char tag[96] = "";
   if (lcgan_prof_active()) snprintf(tag, sizeof(tag), "wgrad B%d %dx%d A%d Bc%d k%d s%d%s", B, Hg, Wg, A, Bc, k, stride, (pre_x || pre_g) ? " mod" : "");
   ProfScope p(KID_CONV_WGRAD, 2.0 * M * A * Bc * k * k, 0, s, tag);
-  const int segw = (Wg & 63) == 0 ? 64 : (Wg & 31) == 0 ? 32 : (Wg == 16 ? 16 : (Wg == 8 ? 8 : 0));
+  int segw = (Wg & 63) == 0 ? 64 : (Wg & 31) == 0 ? 32 : (Wg == 16 ? 16 : (Wg == 8 ? 8 : 0));
+  // LDS-DMA kernel: 64-position chunks at stride 1; 32-position chunks at stride 2 (two workgroups per CU either way)
+  const bool dma_geom = dtype == DT_BF16 && k == 3 && Cg % 8 == 0 && Cx % 8 == 0 && !(g_wgrad3_pack && Cg <= 64 && Cx <= 64);
+  const bool dma_s1 = dma_geom && g_wgrad_dma && stride == 1 && segw == 64;
+  const bool dma_s2 = dma_geom && g_wgrad_dma == 3 && stride == 2 && segw >= 32;
+  if (dma_s2) segw = 32;
   if (dtype == DT_BF16 && g_use_halo && segw != 0 && Hg * Wg >= 64 && (Hg & 3) == 0 && (g_wgrad3_small == 1 || (k == 3 && segw >= 32) || (g_wgrad3_small == 0 && !(pre_x || pre_g))) &&
       (long long)B * Hx * Wx * Cx < (1ll << 31) && (long long)B * Hg * Wg * Cg < (1ll << 31)) {
     // row-segment kernel: chunk = (sample, row group, SEGW-column segment) of `seg` positions; grid.z = split x kernel row
@@ -2413,7 +2420,7 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
     } else {
       // register-staged kernel: 166-236 VGPRs, one 512-thread workgroup per CU whatever the LDS size; the LDS-DMA kernel at
       // stride 1 keeps two (128 VGPRs, 66 KB of LDS each)
-      const int occ = (g_wgrad_dma >= 2 && segw == 64 && k == 3 && pk == 1 && stride == 1) ? 2 : 1;
+      const int occ = (g_wgrad_dma >= 2 && pk == 1 && (dma_s1 || dma_s2)) ? 2 : 1;
       const int max_parts = max(1, cps / (1024 / seg));
       double best = 1e30;
       for (int pt = 1; pt <= max_parts; ++pt) {
@@ -2456,13 +2463,14 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
 #define LAUNCH_WG3_K(ST, SG, SW) { if (k == 3) LAUNCH_WG3(ST, SG, SW, 3) else LAUNCH_WG3(ST, SG, SW, 1) }
     if (pk == 4) { if (stride == 1) LAUNCH_WG3_PK(1, 4) else LAUNCH_WG3_PK(2, 4) }
     else if (pk == 2) { if (stride == 1) LAUNCH_WG3_PK(1, 2) else LAUNCH_WG3_PK(2, 2) }
-    else if (g_wgrad_dma && (stride == 1 || g_wgrad_dma == 3) && segw == 64 && k == 3 && Cg % 8 == 0 && Cx % 8 == 0) {
-      const size_t dsm = 2 * (size_t)(16 + (64 * stride + 2 + 3) / 4) * 1024;
-      if (stride == 1) {
+    else if (dma_s1 || dma_s2) {
+      if (dma_s1) {
+        const size_t dsm = 2 * (size_t)(16 + 17) * 1024;
         static bool set = false;
         if (!set) { hipFuncSetAttribute((const void*)conv_wgrad3_dma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
         hipLaunchKernelGGL((conv_wgrad3_dma_kernel<1>), grid3, dim3(512), dsm, s, a);
       } else {
+        const size_t dsm = 2 * (size_t)(8 + 17) * 1024;
         static bool set = false;
         if (!set) { hipFuncSetAttribute((const void*)conv_wgrad3_dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
         hipLaunchKernelGGL((conv_wgrad3_dma_kernel<2>), grid3, dim3(512), dsm, s, a);
