@@ -231,6 +231,27 @@ def test_conv_wgrad_staging_variants(H, case, mode):
         H.lib.lcgan_set_option(12, old)
 
 
+@pytest.mark.parametrize("case", [(2, 8, 8, 64, 128, 3, 1), (4, 4, 4, 512, 512, 3, 1), (2, 16, 16, 64, 96, 3, 2), (2, 8, 8, 128, 256, 1, 1)])
+def test_conv_igemm_register_staging(H, case):
+    """the generic implicit-GEMM kernel's register-staged main loop (option 16 = 0; LDS-DMA staging is the default)"""
+    B, Hh, W, Ci, Co, k, stride = case
+    dtype = torch.bfloat16
+    old = H.lib.lcgan_set_option(16, 0)
+    try:
+        x = feat((B, Hh, W, Ci), dtype, 1)
+        w = torch.randn(Co, Ci, k, k, generator=torch.Generator().manual_seed(2))
+        scale = 1 / math.sqrt(Ci * k * k)
+        pw_e, _ = E.prep_weight(w, scale, False, False)
+        pw_h, _ = H.prep_weight(w.cuda(), scale, False, False)
+        check(H.conv_fwd(x.cuda(), pw_h, Co, k, stride), E.conv_fwd(x, pw_e, Co, k, stride), dtype, "plain")
+        g = feat((B, Hh // stride, W // stride, ceil8(Co)), dtype, 11, Co)
+        pw_e, _ = E.prep_weight(w, scale, True, False)
+        pw_h, _ = H.prep_weight(w.cuda(), scale, True, False)
+        check(H.conv_bwd_data(g.cuda(), pw_h, Ci, k, stride), E.conv_bwd_data(g, pw_e, Ci, k, stride), dtype, "dgrad")
+    finally:
+        H.lib.lcgan_set_option(16, old)
+
+
 NARROW_CASES = [
     # B, H, W, Cin, Cout, stride: layers with <= 64 output channels on grids of whole 32 x 32 tiles (the C = 32 / 64 octaves of the
     # 512 x 512 and 1024 x 1024 networks) -> conv_halo_narrow_kernel (forced here for small grids through option 7)
