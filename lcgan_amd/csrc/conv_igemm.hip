@@ -996,14 +996,26 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
   constexpr float res_scale = EPI == 2 ? 0.25f : 1.f;
   if constexpr (TR) {
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-    // this lane's pixels (mi = 0, 1) and, for the half-resolution residual, their source pixels
-    const __bf16* qsrc[2] = {nullptr, nullptr};
+    // half-resolution residual: the 16 eight-byte groups this lane needs (2 pixels x 2 x 4 channel groups) come by unconditional
+    // buffer loads issued together (an invalid source pixel / channel group gets offset 0xffffffff = zeros): as conditional loads
+    // inside the loop below they were 16 serialised L1 round trips per workgroup (+16 % on the 256 x 256 data gradient)
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 rq[2][2][4];
     if (quarter) {
+      const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc((void*)side, 0, (int)(2u * (unsigned)(a.B * (a.Hout >> 1) * (a.Wout >> 1) * a.Cout)), 0x00020000);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         const int row = wm * 64 + mi * 32 + (lane & 31);
         const int qy = (ty * HT + (row >> 4)) >> 1, qx = (tx * HT + (row & 15)) >> 1;
-        if (qy < (a.Hout >> 1) && qx < (a.Wout >> 1)) qsrc[mi] = side + ((size_t)(b * (a.Hout >> 1) + qy) * (a.Wout >> 1) + qx) * a.Cout + n0;
+        const bool pok = qy < (a.Hout >> 1) && qx < (a.Wout >> 1);
+        const unsigned pofs = 2u * (unsigned)(((b * (a.Hout >> 1) + qy) * (a.Wout >> 1) + qx) * a.Cout + n0);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int ch = wn * 64 + ni * 32 + 8 * g + 4 * (lane >> 5);
+            rq[mi][ni][g] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(qres, (pok && n0 + ch < a.Cout) ? pofs + 2u * ch : 0xffffffffu, 0, 0));
+          }
       }
     }
 #pragma unroll
@@ -1024,7 +1036,7 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
           if (EPI != 0) {
             bf16x4 rr = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
             if (!quarter) rr = *(const bf16x4*)(ot + row * OROW + ch);
-            else if (qsrc[mi] && n0 + ch < a.Cout) rr = *(const bf16x4*)(qsrc[mi] + ch);
+            else rr = __builtin_bit_cast(bf16x4, rq[mi][ni][g]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += res_scale * (float)rr[j];
           }
