@@ -977,19 +977,25 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
   // groups straight from global memory (L1 hits) in the loop below -- no staging pass, no 4x-redundant 16-byte loads
   const bool quarter = TR && EPI == 2 && a.out_mul == 1;
   if (EPI != 0 && !quarter) {                                      // stage it with coalesced 16-byte loads
+    // (unconditional buffer loads, rows outside the image / channels beyond Cout read zeros by the range check: the eight loads of
+    //  a thread are in flight together; as conditional loads each one waited for the one before)
+    const int sh = EPI == 2 ? 1 : 0;
+    const __amdgpu_buffer_rsrc_t sres = __builtin_amdgcn_make_buffer_rsrc((void*)side, 0, (int)(2u * (unsigned)(a.B * (a.Hout >> sh) * (a.Wout >> sh) * a.Cout)), 0x00020000);
+    bf16x8 rr[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int idx = tid + k * 512;
       const int row = idx >> 4, vv = idx & 15;
       const int py = ty * HT + (row >> 4), px = tx * HT + (row & 15);
       const int n = n0 + vv * 8;
-      bf16x8 rr = zero_bf16x8();
-      if (py < a.Hm && px < a.Wm && n < a.Cout) {
-        const int oy = py * a.out_mul + (phase >> 1), ox = px * a.out_mul + (phase & 1);
-        rr = (EPI == 2) ? *(const bf16x8*)(side + ((size_t)(b * (a.Hout >> 1) + (oy >> 1)) * (a.Wout >> 1) + (ox >> 1)) * a.Cout + n)
-                                   : *(const bf16x8*)(side + ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n);
-      }
-      *(bf16x8*)(ot + row * OROW + vv * 8) = rr;
+      const int oy = (py * a.out_mul + (phase >> 1)) >> sh, ox = (px * a.out_mul + (phase & 1)) >> sh;
+      const bool ok = py < a.Hm && px < a.Wm && n < a.Cout;
+      rr[k] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(sres, ok ? 2u * (unsigned)(((b * (a.Hout >> sh) + oy) * (a.Wout >> sh) + ox) * a.Cout + n) : 0xffffffffu, 0, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int idx = tid + k * 512;
+      *(bf16x8*)(ot + (idx >> 4) * OROW + (idx & 15) * 8) = rr[k];
     }
   }
   if (TR || EPI != 0) __syncthreads();
