@@ -16,6 +16,7 @@ namespace {
 
 constexpr int TPB = 256;
 constexpr int MT = 32;     // rows of the small-M GEMMs handled per block
+constexpr int LF_MT = 8;   // ... of linear_fwd_kernel
 
 // A group of L linear layers that share their input x [M,I] (L = 1: a plain linear layer).  The table travels BY VALUE in the
 // kernel arguments, so a grouped launch costs no host->device copy: the 20 style affines of a generator pass are 2 launches.
@@ -80,55 +81,56 @@ __global__ __launch_bounds__(TPB) void linear_fwd_generic_kernel(const float* __
 // thread); 63 such launches per iteration made the linear layers 2.6 ms of the step.
 __global__ __launch_bounds__(TPB) void linear_fwd_kernel(const float* __restrict__ x, const LinGroup g, int M, int I, int isplit,
                                                           int act, float gain) {
-  __shared__ float red[4][32][65];
+  // LF_MT rows per block (not the 32 of the other small-M kernels): with 32 rows a lane had 64 sixteen-byte loads of x to wait for
+  // in batches and a 512 x 512 layer occupied 64 CUs for 18 us; 8 rows put all 16 loads in flight at once on 256 blocks
+  __shared__ float red[4][2 * LF_MT][65];
   const int l = blockIdx.z, O = g.O[l];
   const int o0 = blockIdx.x * 8;
   if (o0 >= O) return;
   const float* __restrict__ w = g.w[l];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int mt = blockIdx.y / isplit, sp = blockIdx.y - mt * isplit;
-  const int m0 = mt * MT;
+  const int m0 = mt * LF_MT;
   const int ilen = cdiv(cdiv(I, isplit), 512) * 512;
   const int ibeg = sp * ilen, iend = min(I, ibeg + ilen);
   const int oa = o0 + 2 * wv, ob = oa + 1;
   typedef float f4 __attribute__((ext_vector_type(4)));
   const f4 z4 = {0.f, 0.f, 0.f, 0.f};
-  float acc[MT][2];
+  float acc[LF_MT][2];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) { acc[m][0] = 0.f; acc[m][1] = 0.f; }
+  for (int m = 0; m < LF_MT; ++m) { acc[m][0] = 0.f; acc[m][1] = 0.f; }
   for (int i0 = ibeg + lane * 8; i0 < iend; i0 += 512) {
     const f4 wa0 = oa < O ? *(const f4*)(w + (size_t)oa * I + i0) : z4, wa1 = oa < O ? *(const f4*)(w + (size_t)oa * I + i0 + 4) : z4;
     const f4 wb0 = ob < O ? *(const f4*)(w + (size_t)ob * I + i0) : z4, wb1 = ob < O ? *(const f4*)(w + (size_t)ob * I + i0 + 4) : z4;
+    f4 x0[LF_MT], x1[LF_MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      if (m0 + m < M) {
-        const f4 x0 = *(const f4*)(x + (size_t)(m0 + m) * I + i0), x1 = *(const f4*)(x + (size_t)(m0 + m) * I + i0 + 4);
-        acc[m][0] += wa0[0] * x0[0] + wa0[1] * x0[1] + wa0[2] * x0[2] + wa0[3] * x0[3] + wa1[0] * x1[0] + wa1[1] * x1[1] + wa1[2] * x1[2] + wa1[3] * x1[3];
-        acc[m][1] += wb0[0] * x0[0] + wb0[1] * x0[1] + wb0[2] * x0[2] + wb0[3] * x0[3] + wb1[0] * x1[0] + wb1[1] * x1[1] + wb1[2] * x1[2] + wb1[3] * x1[3];
-      }
+    for (int m = 0; m < LF_MT; ++m) {                          // rows beyond M re-read row M - 1 (discarded below): no branch around the loads
+      const int mr = min(m0 + m, M - 1);
+      x0[m] = *(const f4*)(x + (size_t)mr * I + i0); x1[m] = *(const f4*)(x + (size_t)mr * I + i0 + 4);
+    }
+#pragma unroll
+    for (int m = 0; m < LF_MT; ++m) {
+      acc[m][0] += wa0[0] * x0[m][0] + wa0[1] * x0[m][1] + wa0[2] * x0[m][2] + wa0[3] * x0[m][3] + wa1[0] * x1[m][0] + wa1[1] * x1[m][1] + wa1[2] * x1[m][2] + wa1[3] * x1[m][3];
+      acc[m][1] += wb0[0] * x0[m][0] + wb0[1] * x0[m][1] + wb0[2] * x0[m][2] + wb0[3] * x0[m][3] + wb1[0] * x1[m][0] + wb1[1] * x1[m][1] + wb1[2] * x1[m][2] + wb1[3] * x1[m][3];
     }
   }
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    __syncthreads();
-#pragma unroll
-    for (int mm = 0; mm < 16; ++mm) {
-      red[wv][mm * 2][lane] = acc[h * 16 + mm][0];
-      red[wv][mm * 2 + 1][lane] = acc[h * 16 + mm][1];
-    }
-    __syncthreads();
-    if (lane < 32) {
-      float v = 0.f;
+  for (int m = 0; m < LF_MT; ++m) {
+    red[wv][m * 2][lane] = acc[m][0];
+    red[wv][m * 2 + 1][lane] = acc[m][1];
+  }
+  __syncthreads();
+  if (lane < 2 * LF_MT) {
+    float v = 0.f;
 #pragma unroll 16
-      for (int k = 0; k < 64; ++k) v += red[wv][lane][k];
-      const int o = oa + (lane & 1), mrow = m0 + h * 16 + (lane >> 1);
-      if (o < O && mrow < M) {
-        float* y = g.out[l] + (size_t)mrow * O + o;
-        if (isplit > 1) atomicAdd(y, v * g.scale[l]);
-        else {
-          const float bv = g.aux[l] ? g.aux[l][o] * g.bscale[l] : 0.f;
-          *y = act_fwd(v * g.scale[l] + bv, act) * gain;
-        }
+    for (int k = 0; k < 64; ++k) v += red[wv][lane][k];
+    const int o = oa + (lane & 1), mrow = m0 + (lane >> 1);
+    if (o < O && mrow < M) {
+      float* y = g.out[l] + (size_t)mrow * O + o;
+      if (isplit > 1) atomicAdd(y, v * g.scale[l]);
+      else {
+        const float bv = g.aux[l] ? g.aux[l][o] * g.bscale[l] : 0.f;
+        *y = act_fwd(v * g.scale[l] + bv, act) * gain;
       }
     }
   }
@@ -491,7 +493,7 @@ extern "C" {
 static int linear_group_fwd(const float* x, const LinGroup& g, int L, int maxO, int M, int I, int act, float gain, hipStream_t s) {
   const int isplit = (L == 1 && I >= 2048) ? std::min(16, I / 1024) : 1;
   if (isplit > 1) hipMemsetAsync(g.out[0], 0, (size_t)M * g.O[0] * sizeof(float), s);
-  if (I % 8 == 0) hipLaunchKernelGGL(linear_fwd_kernel, dim3(cdiv(maxO, 8), cdiv(M, MT) * isplit, L), dim3(TPB), 0, s, x, g, M, I, isplit, act, gain);
+  if (I % 8 == 0) hipLaunchKernelGGL(linear_fwd_kernel, dim3(cdiv(maxO, 8), cdiv(M, LF_MT) * isplit, L), dim3(TPB), 0, s, x, g, M, I, isplit, act, gain);
   else hipLaunchKernelGGL(linear_fwd_generic_kernel, dim3(cdiv(maxO, 8), cdiv(M, MT) * isplit, L), dim3(TPB), 0, s, x, g, M, I, isplit, act, gain);
   if (isplit > 1)
     hipLaunchKernelGGL(linear_finalize_kernel, dim3(cdiv(M * g.O[0], TPB)), dim3(TPB), 0, s, g.out[0], g.aux[0], g.bscale[0], M, g.O[0],
