@@ -401,7 +401,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 template <int IN_MUL, bool M16, int EPI, int DMA = 0, bool MOD = false>
 __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_kernel(HaloArgs a) {
-  static_assert(DMA == 0 || (IN_MUL == 1 && DMA <= 2 && !M16 && (MOD || EPI != 3)) || (IN_MUL == 2 && DMA == 3 && !M16 && (MOD || EPI != 3)),
+  static_assert(DMA == 0 || (IN_MUL == 1 && DMA <= 2 && (!M16 || DMA == 2) && (MOD || EPI != 3)) || (IN_MUL == 2 && DMA == 3 && !M16 && (MOD || EPI != 3)),
                 "LDS-DMA staging: stride-1 geometries (1 / 2 taps per barrier) or the stride-2 forward structure (DMA == 3)");
   static_assert(!MOD || DMA != 0, "MOD: the swizzled-record structure with the halo staged through registers (per-sample input scales)");
   constexpr bool SR = EPI == 3;
@@ -751,11 +751,56 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
           acc[mi][ni] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[ks][ni], af[ks][mi], acc[mi][ni], 0, 0, 0)
                            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][mi], bf[ks][ni], acc[mi][ni], 0, 0, 0);
     };
+    // M16: v_mfma_f32_16x16x32_bf16 (lane row = lane & 15, the lane's 16-byte chunk = lane >> 4; 4 x 4 tiles per wave, one k-step per
+    // tap): same LDS traffic and MFMA cycles, but the chip holds a higher clock on this shape (guide, DVFS item 7)
+    const int kq = lane >> 4, l16 = lane & 15;
+    const int rowofs16 = (wm * 4) * (DMA_HP * 64);                               // mi: + one image row
+    const int bn16 = wn * 64 + l16;
+    const int baddr16 = 2 * DMA_HBUF + bn16 * 64 + ((kq ^ ((bn16 >> 2) & 3)) << 4);   // ni: + 16 rows (same swizzle)
+    bf16x8 af16[4], bf16[4];
+    auto readsA16 = [&](int t, int p) {
+      const int hxl = l16 + tt.dx[t] - hx0;
+      const int a0 = rowofs16 + (c & 1) * DMA_HBUF + (tt.dy[t] - hy0) * (DMA_HP * 64) + ((hxl << 6) | ((kq << 4) ^ ((hxl << 2) & 0x30)));
+      af16[2 * p] = *(const bf16x8*)(smem + a0 + (2 * p) * DMA_HP * 64);
+      af16[2 * p + 1] = *(const bf16x8*)(smem + a0 + (2 * p + 1) * DMA_HP * 64);
+    };
+    auto readsB16 = [&](int tilebase) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) bf16[ni] = *(const bf16x8*)(smem + baddr16 + tilebase + ni * 16 * 64);
+    };
+    auto mfmas16 = [&](int p) {
+#pragma unroll
+      for (int mi = 2 * p; mi < 2 * p + 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af16[mi], bf16[ni], acc16[mi][ni], 0, 0, 0);
+    };
     auto step = [&](int q, auto bufc) {
       constexpr int buf = decltype(bufc)::value;
       if (q + 1 < total) { dma_b(lc, lg, buf ^ 1); advance(); }
       if (g == 0 && c + 1 < nchunks) dma_halo((c + 1) * BK, (c + 1) & 1);
       const int t0 = g * TP;
+      if constexpr (M16) {
+        readsA16(t0, 0); readsA16(t0, 1); readsB16(buf * TP * DMA_BBUF);
+        if (TP == 2 && t0 + 1 < ntaps) {
+          mfmas16(0);
+          __builtin_amdgcn_sched_barrier(0);
+          readsA16(t0 + 1, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          mfmas16(1);
+          __builtin_amdgcn_sched_barrier(0);
+          readsA16(t0 + 1, 1); readsB16((buf * TP + 1) * DMA_BBUF);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        mfmas16(0);
+        mfmas16(1);
+        if constexpr (MOD) {
+          if (g == ngroups - 1 && c + 1 < nchunks) scale_inplace((c + 1) & 1);
+        }
+        __syncthreads();
+        if (++g == ngroups) { g = 0; ++c; }
+        return;
+      }
       frag_reads(t0, buf * TP * DMA_BBUF, 0);
       frag_reads(t0, buf * TP * DMA_BBUF, 1);
 #pragma unroll
@@ -1434,7 +1479,7 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   const int halo_wgs = c.B * a.tiles_x * a.tiles_y * cdiv(c.Cout, BN) * nphase;
   if (g_use_splitk && halo_wgs < g_halo_min_wgs && c.taps[0].n * c.kc_per_tap >= 8) return false;
   a.halo_elems = max_halo_elems;
-  const int NBT = (in_mul == 2 && !g_mfma16) ? 4 : 2;             // stride-2 forward stages the weight tiles of two taps per step
+  const int NBT = (in_mul == 2 && g_mfma16 != 1) ? 4 : 2;             // stride-2 forward stages the weight tiles of two taps per step
   const size_t smem = std::max(((size_t)a.halo_elems + NBT * TILE) * sizeof(__bf16) + (size_t)c.Kpad * sizeof(float),
                                HALO_EPI_SMEM);
   a.nblocks = cdiv(c.Cout, BN);
@@ -1458,7 +1503,7 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
     if (a.xs) LAUNCH_HALO(IM, MM, 3) else if (a.residual && a.res_half) LAUNCH_HALO(IM, MM, 2)                          \
     else if (a.residual) LAUNCH_HALO(IM, MM, 1) else LAUNCH_HALO(IM, MM, 0)                                             \
   }
-  if (g_halo_s2dma && in_mul == 2 && nphase == 1 && !g_mfma16 && (a.pre ? g_halo_s2dma >= 2 : !a.xs) && c.taps[0].n == 9 && c.Cin % 32 == 0 && c.Kpad == c.Cin &&
+  if (g_halo_s2dma && in_mul == 2 && nphase == 1 && g_mfma16 != 1 && (a.pre ? g_halo_s2dma >= 2 : !a.xs) && c.taps[0].n == 9 && c.Cin % 32 == 0 && c.Kpad == c.Cin &&
       (!a.pre || c.Cin <= 1024)) {
     constexpr size_t S2_SMEM = 2 * (size_t)(42 * 1024 + 9 * 4096);      // two half-chunk stages (see the kernel)
     const size_t dsmem = std::max(S2_SMEM + (a.pre ? (size_t)c.Cin * sizeof(float) : 0), HALO_EPI_SMEM);
@@ -1484,7 +1529,7 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
     return true;
   }
   const bool mod = a.pre != nullptr;
-  bool dma_ok = g_halo_dma && in_mul == 1 && !g_mfma16 && (mod ? g_halo_dma_mod != 0 : !a.xs) && c.Cin % 32 == 0 && c.Kpad == c.Cin;
+  bool dma_ok = g_halo_dma && in_mul == 1 && g_mfma16 != 1 && (mod ? g_halo_dma_mod != 0 : !a.xs) && c.Cin % 32 == 0 && c.Kpad == c.Cin;
   for (int p = 0; p < nphase; ++p) dma_ok = dma_ok && a.hh[p] <= DMA_HROWS && a.hw[p] <= DMA_HP && a.hw[p] - HT <= 2;
   if (dma_ok) {
     const int tp = mod ? (g_halo_dma_mod == 2 ? 2 : 1) : (g_halo_dma == 2 ? 2 : 1);
@@ -1500,16 +1545,24 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
 #define LAUNCH_DMA_MOD(TPV)                                                                                             \
   { if (a.xs) LAUNCH_DMA(3, TPV, true) else if (a.residual && a.res_half) LAUNCH_DMA(2, TPV, true)                      \
     else if (a.residual) LAUNCH_DMA(1, TPV, true) else LAUNCH_DMA(0, TPV, true) }
-    if (mod) { if (tp == 2) LAUNCH_DMA_MOD(2) else LAUNCH_DMA_MOD(1) }
+#define LAUNCH_DMA16(EP)                                                                                               \
+  {                                                                                                                     \
+    static bool set = false;                                                                                            \
+    if (!set) { hipFuncSetAttribute((const void*)conv_halo_kernel<1, true, EP, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
+    hipLaunchKernelGGL((conv_halo_kernel<1, true, EP, 2, false>), grid, dim3(512), dsmem, s, a);                        \
+  }
+    if (g_mfma16 == 2 && !mod && tp == 2) { if (a.residual && a.res_half) LAUNCH_DMA16(2) else if (a.residual) LAUNCH_DMA16(1) else LAUNCH_DMA16(0) }
+    else if (mod) { if (tp == 2) LAUNCH_DMA_MOD(2) else LAUNCH_DMA_MOD(1) }
     else if (tp == 2) LAUNCH_DMA_EPI(2) else LAUNCH_DMA_EPI(1)
+#undef LAUNCH_DMA16
 #undef LAUNCH_DMA_MOD
 #undef LAUNCH_DMA_EPI
 #undef LAUNCH_DMA
     return true;
   }
-  if (in_mul == 1 && g_mfma16 && !a.xs && !a.residual) LAUNCH_HALO(1, true, 0)
+  if (in_mul == 1 && g_mfma16 == 1 && !a.xs && !a.residual) LAUNCH_HALO(1, true, 0)
   else if (in_mul == 1) LAUNCH_HALO_EPI(1, false)
-  else if (g_mfma16 && !a.xs && !a.residual) LAUNCH_HALO(2, true, 0)
+  else if (g_mfma16 == 1 && !a.xs && !a.residual) LAUNCH_HALO(2, true, 0)
   else LAUNCH_HALO_EPI(2, false)
 #undef LAUNCH_HALO_EPI
 #undef LAUNCH_HALO
