@@ -41,6 +41,12 @@ int lcgan_conv_weight_prep_group(const void* descs, const int* chunk_entry, cons
  * transposed != 0 reads gwp as [t][Bc][A] (weight gradient of the transposed convolution) */
 int lcgan_conv_wgrad_unprep(const float* gwp, int A, int Bc, int k, float scale, int transposed, const float* w,
                             const float* gwsq, float* gw, void* stream);
+/* lcgan_conv_wgrad + lcgan_conv_wgrad_unprep in one call (the slab reduction writes the weight-layout gradient directly);
+ * replaces the same autograd step as the two calls above: torch conv weight gradient, custom_layers.py:41,43,78,83 */
+int lcgan_conv_wgrad_fused(const void* x, const void* g, float* gwp,
+                           int B, int Hx, int Wx, int Cx, int Hg, int Wg, int Cg, int A, int Bc, int k, int stride,
+                           const float* pre_x, const float* pre_g, int dtype,
+                           float scale, int transposed, const float* w, const float* gwsq, float* gw, void* stream);
 /* y = act(post[b,n] * conv_{k,stride,pad=k/2}(pre[b,c] * x, wp) + bias[n]*bias_scale) * gain + residual
    residual_half = 1: residual is [B,Hout/2,Wout/2,Cout] and enters as 0.25 * residual[ho/2][wo/2], the adjoint of
    F.avg_pool2d(x, 2) (custom_layers.py:202) -- the gradient of a DiscriminatorBlock's pooled skip branch lands in the

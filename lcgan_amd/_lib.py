@@ -21,6 +21,7 @@ SIGNATURES = {
     "lcgan_conv_fwd": [P, P, P, I, I, I, I, I, I, I, I, P, P, P, F, I, F, P, I, P, P, I, P],
     "lcgan_conv_bwd_data": [P, P, P, I, I, I, I, I, I, I, I, P, P, P, F, I, F, P, I, P, P, I, P],
     "lcgan_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P, I, P],
+    "lcgan_conv_wgrad_fused": [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P, I, F, I, P, P, P, P],
     "lcgan_box3_act": [P, P, I, I, I, I, I, F, I, P],
     "lcgan_box3_act_bwd": [P, P, P, I, I, I, I, I, F, I, P],
     "lcgan_box3_actbwd_reduce": [P, P, P, P, I, I, I, I, I, I, F, I, P],

@@ -2079,6 +2079,24 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
   gwp[i] = acc;
 }
 
+// slab reduction fused with the un-prep of the weight gradient (lcgan_conv_wgrad_unprep): gw[a][b][t] = scale * sum_s slab[s][src] (+ demod
+// term), src = the element's place in the prepared layout.  One launch instead of slab_reduce + unprep and no gwp round trip.
+__global__ void slab_reduce_unprep_kernel(const float* __restrict__ slab, int nsplit, int A, int Bc, int kk, float scale, int transposed,
+                                          const float* __restrict__ w, const float* __restrict__ gwsq, float* __restrict__ gw) {
+  const int total = A * Bc * kk;
+  const int i = blockIdx.x * 256 + threadIdx.x;              // index in the prepared layout ([t][A][Bc] or [t][Bc][A]): coalesced slab reads
+  if (i >= total) return;
+  float acc = 0.f;
+#pragma unroll 4
+  for (int sI = 0; sI < nsplit; ++sI) acc += slab[(size_t)sI * total + i];
+  const int t = i / (A * Bc), r = i - t * (A * Bc);
+  const int aa = transposed ? r % A : r / Bc, b = transposed ? r / A : r % Bc;
+  const size_t ab = (size_t)aa * Bc + b, idx = ab * kk + t;
+  float v = acc * scale;
+  if (gwsq) v += 2.f * scale * scale * w[idx] * gwsq[ab];
+  gw[idx] = v;
+}
+
 float* g_slab[MAX_DEV] = {};
 size_t g_slab_bytes[MAX_DEV] = {};
 float* wgrad_slab_scratch(size_t bytes) {          // grow-only, per device, owned by the library; every element is written before it is read
@@ -2439,9 +2457,10 @@ int lcgan_conv_bwd_data(const void* g, const void* wpT, void* gx,
 
 // Weight gradient: gwp[t][a][c] += sum_{b,i,j} (pre_g[b,a] g[b,i,j,a]) * (pre_x[b,c] x[b, i*stride+ky-pad, j*stride+kx-pad, c])
 // x: [B,Hx,Wx,Cx] (the conv's input side), g: [B,Hg,Wg,Cg] (the conv's output side); gwp fp32 [k*k][A][Bc], must be zeroed.
-int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
+struct UnprepArgs { float scale; int transposed; const float* w; const float* gwsq; float* gw; };   // optional fused un-prep (gw != NULL)
+static int conv_wgrad_impl(const void* x, const void* g, float* gwp,
                      int B, int Hx, int Wx, int Cx, int Hg, int Wg, int Cg, int A, int Bc, int k, int stride,
-                     const float* pre_x, const float* pre_g, int dtype, void* stream) {
+                     const float* pre_x, const float* pre_g, int dtype, void* stream, const UnprepArgs* up) {
   hipStream_t s = (hipStream_t)stream;
   if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || (Cx & 7) || (Cg & 7) || A > Cg || Bc > Cx) return LCGAN_EINVAL;
   WgradArgs a = {};
@@ -2559,6 +2578,12 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
 #undef LAUNCH_WG3_PK
     if (a.slab) {
       const int total = k * k * A * Bc;
+      if (up && up->gw) {
+        // (the un-prep's A / Bc are the WEIGHT's [A][Bc] = this call's [A][Bc] or its transpose; prepared layout [t][A][Bc] of this call)
+        hipLaunchKernelGGL(slab_reduce_unprep_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, a.slab, a.nsplit,
+                           up->transposed ? Bc : A, up->transposed ? A : Bc, k * k, up->scale, up->transposed, up->w, up->gwsq, up->gw);
+        return launch_status() ? launch_status() : 1;          // 1 = un-prep done
+      }
       hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, a.slab, gwp, total, a.nsplit);
     }
   } else if (dtype == DT_BF16) {
@@ -2576,6 +2601,27 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
     return LCGAN_EINVAL;
   }
   return launch_status();
+}
+
+int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
+                     int B, int Hx, int Wx, int Cx, int Hg, int Wg, int Cg, int A, int Bc, int k, int stride,
+                     const float* pre_x, const float* pre_g, int dtype, void* stream) {
+  return conv_wgrad_impl(x, g, gwp, B, Hx, Wx, Cx, Hg, Wg, Cg, A, Bc, k, stride, pre_x, pre_g, dtype, stream, nullptr);
+}
+
+// lcgan_conv_wgrad followed by lcgan_conv_wgrad_unprep(gwp, ..., gw) as one call: when the partial tiles meet through the slab, the
+// reduction pass writes gw directly (one launch less per convolution backward, no gwp round trip); gwp is scratch either way.
+// wA / wBc: the WEIGHT's [wA][wBc][k][k] (= [A][Bc] of the gradient call, or its transpose with transposed = 1).
+int lcgan_conv_wgrad_fused(const void* x, const void* g, float* gwp,
+                           int B, int Hx, int Wx, int Cx, int Hg, int Wg, int Cg, int A, int Bc, int k, int stride,
+                           const float* pre_x, const float* pre_g, int dtype,
+                           float scale, int transposed, const float* w, const float* gwsq, float* gw, void* stream) {
+  if (!gw) return LCGAN_EINVAL;
+  UnprepArgs up = {scale, transposed, w, gwsq, gw};
+  const int rc = conv_wgrad_impl(x, g, gwp, B, Hx, Wx, Cx, Hg, Wg, Cg, A, Bc, k, stride, pre_x, pre_g, dtype, stream, &up);
+  if (rc == 1) return 0;
+  if (rc != 0) return rc;
+  return lcgan_conv_wgrad_unprep(gwp, transposed ? Bc : A, transposed ? A : Bc, k, scale, transposed, w, gwsq, gw, stream);
 }
 
 }  // extern "C"

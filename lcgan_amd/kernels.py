@@ -213,6 +213,20 @@ class HipKernels:
                    _p(pre_x), _p(pre_g), dt_code(x.dtype), self._stream())
         return gwp
 
+    def conv_wgrad_unprep(self, x: Tensor, g: Tensor, A: int, Bc: int, k: int, stride: int, scale: float, transposed: bool = False,
+                          pre_x=None, pre_g=None, w: Optional[Tensor] = None, gwsq: Optional[Tensor] = None) -> Tensor:
+        """conv_wgrad + unprep_wgrad as one call (lcgan_conv_wgrad_fused): returns the gradient in weight layout
+        ([A][Bc][k][k], or [Bc][A][k][k] with transposed)."""
+        self._chk(x, g, pre_x, pre_g, w, gwsq)
+        B, Hx, Wx, Cx = x.shape
+        _, Hg, Wg, Cg = g.shape
+        gwp = self._zeros.take((k * k, A, Bc), x.device)
+        wA, wBc = (Bc, A) if transposed else (A, Bc)
+        gw = torch.empty((wA, wBc, k, k), dtype=torch.float32, device=x.device)
+        self._call("lcgan_conv_wgrad_fused", x.data_ptr(), g.data_ptr(), gwp.data_ptr(), B, Hx, Wx, Cx, Hg, Wg, Cg, A, Bc, k, stride,
+                   _p(pre_x), _p(pre_g), dt_code(x.dtype), float(scale), int(transposed), _p(w), _p(gwsq), gw.data_ptr(), self._stream())
+        return gw
+
     # ---- MX-fp8 convolution path (BASELINE configs[4]) ------------------------------------------------------------------
     def prep_weight_fp8(self, w: Tensor, scale: float, transpose: bool):
         self._chk(w)

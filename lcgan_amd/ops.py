@@ -314,8 +314,7 @@ class ConvWeightGradFn(Function):
     @staticmethod
     def forward(ctx, x, g, k, stride, wscale, A, Bc):
         K = _K()
-        gwp = K.conv_wgrad(x, g, A, Bc, k, stride)
-        gw = K.unprep_wgrad(gwp, A, Bc, k, wscale)
+        gw = K.conv_wgrad_unprep(x, g, A, Bc, k, stride, wscale)
         ctx.save_for_backward(x, g)
         ctx.cfg = (k, stride, wscale)
         return gw
@@ -687,11 +686,9 @@ class ModConvFn(Function):
             gx, gs = K.conv_bwd_data(gz, pwT, Cin, k, 1, pre=d, post=s, xs=x)
         gwsq = K.demod_bwd(gdq, d, s, wsq, gs)                                   # gs += demod path
         if up == 2:
-            gwp = K.conv_wgrad(gz, x, Cin, O, k, 2, pre_x=d, pre_g=s)            # [t][Cin][O]
-            gw = K.unprep_wgrad(gwp, O, Cin, k, c_eq, transposed=True, w=w, gwsq=gwsq)
+            gw = K.conv_wgrad_unprep(gz, x, Cin, O, k, 2, c_eq, transposed=True, pre_x=d, pre_g=s, w=w, gwsq=gwsq)    # gwp [t][Cin][O]
         else:
-            gwp = K.conv_wgrad(x, gz, O, Cin, k, 1, pre_x=s, pre_g=d)            # [t][O][Cin]
-            gw = K.unprep_wgrad(gwp, O, Cin, k, c_eq, transposed=False, w=w, gwsq=gwsq)
+            gw = K.conv_wgrad_unprep(x, gz, O, Cin, k, 1, c_eq, transposed=False, pre_x=s, pre_g=d, w=w, gwsq=gwsq)   # gwp [t][O][Cin]
         return gx, gw, gb, gs, None, None, None
 
 

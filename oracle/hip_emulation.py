@@ -106,6 +106,12 @@ class EmulatedKernels:
             gw = gw + 2 * scale * scale * w.detach() * gwsq[:, :, None, None]
         return gw.contiguous()
 
+    def conv_wgrad_unprep(self, x, g, A, Bc, k, stride, scale, transposed=False, pre_x=None, pre_g=None, w=None, gwsq=None):
+        """lcgan_conv_wgrad_fused: the two steps above as one call"""
+        gwp = self.conv_wgrad(x, g, A, Bc, k, stride, pre_x=pre_x, pre_g=pre_g)
+        wA, wBc = (Bc, A) if transposed else (A, Bc)
+        return self.unprep_wgrad(gwp, wA, wBc, k, scale, transposed=transposed, w=w, gwsq=gwsq)
+
     def _epilogue(self, v, N, post, bias, bias_scale, act, gain, residual, dtype):
         if post is not None:
             v = v * post[:, :N, None, None]

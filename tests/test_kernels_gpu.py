@@ -252,6 +252,29 @@ def test_conv_igemm_register_staging(H, case):
         H.lib.lcgan_set_option(16, old)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64, 128, 128, 3, 1, False), (2, 64, 64, 64, 96, 3, 2, True), (4, 16, 16, 128, 256, 3, 1, False),
+                                  (1, 32, 32, 72, 40, 1, 1, False)])
+def test_conv_wgrad_unprep_fused(H, case):
+    """lcgan_conv_wgrad_fused == lcgan_conv_wgrad + lcgan_conv_wgrad_unprep (slab and atomic routes, both orientations, demod term)"""
+    B, Hh, W, Ci, Co, k, stride, tr = case
+    dtype = torch.bfloat16
+    x = feat((B, Hh, W, ceil8(Ci)), dtype, 21, Ci).cuda()
+    g = feat((B, Hh // stride, W // stride, ceil8(Co)), dtype, 22, Co).cuda()
+    a, bc = (g, x) if tr else (x, g)                           # transposed: the gradient call runs with the roles swapped (up-sampling convs)
+    A, Bc = (Ci, Co) if tr else (Co, Ci)
+    wA, wBc = (Bc, A) if tr else (A, Bc)
+    w = torch.randn(wA, wBc, k, k, generator=torch.Generator().manual_seed(25)).cuda()
+    gwsq = torch.randn(wA, wBc, generator=torch.Generator().manual_seed(26)).cuda()
+    px = vec((B, a.shape[-1]), 23).cuda()
+    pg = vec((B, bc.shape[-1]), 24).cuda()
+    for kw in (dict(), dict(pre_x=px, pre_g=pg)):
+        ref = H.unprep_wgrad(H.conv_wgrad(a, bc, A, Bc, k, stride, **kw), wA, wBc, k, 0.3, tr, w, gwsq)
+        got = H.conv_wgrad_unprep(a, bc, A, Bc, k, stride, 0.3, tr, w=w, gwsq=gwsq, **kw)
+        assert got.shape == ref.shape
+        err = float((got - ref).abs().max() / ref.abs().max())
+        assert err < 2e-5, err                                  # (fp32 sums in a different order)
+
+
 NARROW_CASES = [
     # B, H, W, Cin, Cout, stride: layers with <= 64 output channels on grids of whole 32 x 32 tiles (the C = 32 / 64 octaves of the
     # 512 x 512 and 1024 x 1024 networks) -> conv_halo_narrow_kernel (forced here for small grids through option 7)
