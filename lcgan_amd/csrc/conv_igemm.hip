@@ -42,7 +42,7 @@ int g_wgrad3_pack = 1;                    // lcgan_set_option(9, ...): packed ch
 int g_halo_dma = 2;                       // lcgan_set_option(10, ...): LDS-DMA staging in the halo kernel (stride-1 geometries without input scales)
 int g_halo_dma_mod = 2;                   // lcgan_set_option(11, ...): the same structure for convolutions with per-sample input scales (halo by DMA, scaled in place in LDS): 0 = off, 1 / 2 = taps per step
 int g_wgrad_dma = 3;                      // lcgan_set_option(12, ...): LDS-DMA staging in the row-segment weight-gradient kernel (3x3): 0 = off, 1 = stride 1 with the one-workgroup-per-CU split, 2 = stride 1, split for two workgroups per CU, 3 = also stride 2 (32-position chunks)
-int g_halo_s2dma = 2;                     // lcgan_set_option(13, ...): stride-2 forward 3x3 on the parity-plane LDS-DMA structure (one barrier per 16-channel half-chunk): 0 off, 1 = layers without per-sample input scales, 2 = all
+int g_halo_s2dma = 4;                     // lcgan_set_option(13, ...): stride-2 forward 3x3 on the parity-plane LDS-DMA structure: 0 off, 1 = layers without per-sample input scales, 2 = all (two stages per workgroup, one workgroup per CU), 4 = as 2 but unscaled layers with ONE stage per workgroup and two workgroups per CU
 int g_halo_nb_group_kb = 8192;               // lcgan_set_option(14, ...): KB of weights (all taps x 128 rows x Cin) that concurrent channel blocks of one tile may hold in an XCD's L2; 0 = channel blocks slowest (one pass over the input per block)
 int g_wgrad_xcd = 0;                      // lcgan_set_option(15, ...): row-segment wgrad workgroups of one split share an XCD (1-D grid)
 int g_igemm_dma = 1;                      // lcgan_set_option(16, ...): LDS-DMA staging in the generic implicit-GEMM kernel (bf16, no input scales, Cin % 32 == 0)
@@ -400,8 +400,8 @@ constexpr int DMA_BBUF = 128 * 64;                               // bytes per we
 typedef __attribute__((address_space(3))) void lds_void;
 
 template <int IN_MUL, bool M16, int EPI, int DMA = 0, bool MOD = false>
-__global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_kernel(HaloArgs a) {
-  static_assert(DMA == 0 || (IN_MUL == 1 && DMA <= 2 && (!M16 || DMA == 2) && (MOD || EPI != 3)) || (IN_MUL == 2 && DMA == 3 && !M16 && (MOD || EPI != 3)),
+__global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) void conv_halo_kernel(HaloArgs a) {
+  static_assert(DMA == 0 || (IN_MUL == 1 && DMA <= 2 && (!M16 || DMA == 2) && (MOD || EPI != 3)) || (IN_MUL == 2 && (DMA == 3 || DMA == 4) && !M16 && (MOD || EPI != 3)),
                 "LDS-DMA staging: stride-1 geometries (1 / 2 taps per barrier) or the stride-2 forward structure (DMA == 3)");
   static_assert(!MOD || DMA != 0, "MOD: the swizzled-record structure with the halo staged through registers (per-sample input scales)");
   constexpr bool SR = EPI == 3;
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
 
-  if constexpr (IN_MUL == 2 && DMA == 3) {
+  if constexpr (IN_MUL == 2 && (DMA == 3 || DMA == 4)) {
     // ---- stride-2 forward, 3 x 3: everything by LDS-DMA, ONE barrier per 16-channel half-chunk (36 MFMAs per wave) --------------
     // The 33 x 33 input patch of a 16 x 16 output tile is kept as its four (row parity, column parity) PLANES, so the stride-2
     // gather of a tap is a unit-stride walk in one plane: tap (ky, kx) reads plane (ky & 1, kx & 1) at (y + (ky >> 1), x + (kx >> 1)).
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
     const int wrow = 32 * (widu & 3) + (lane >> 1);              // weight row of this lane: piece i = widu + 8 k is (tap i / 4, rows 32 (i % 4) ..)
     const unsigned wvo = n0 + wrow < a.N ? 2u * (unsigned)((n0 + wrow) * a.Kpad + (((lane & 1) ^ ((wrow >> 3) & 1)) * 8)) : 0xffffffffu;
     // MOD: per-sample input scales are applied in place by the lanes that issued the pieces (see the stride-1 structure)
-    float* dpsc = (float*)(smem + 2 * S2_STAGE);                 // [Cin]
+    float* dpsc = (float*)(smem + (DMA == 4 ? 1 : 2) * S2_STAGE);   // [Cin]
     int hch6[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -635,6 +635,19 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
       }
     };
+    if constexpr (DMA == 4) {
+      // ONE stage per workgroup (78 KB): two workgroups share a CU and overlap each other's load and compute phases instead of a
+      // workgroup double-buffering its own
+      for (int h = 0; h < nh; ++h) {
+        if (h > 0) {
+          dma_stage(h, 0);
+          if constexpr (MOD) scale_stage(h, 0);
+          __syncthreads();
+        }
+        half_chunk(std::integral_constant<int, 0>{});
+        __syncthreads();
+      }
+    } else {
     for (int h = 0; h < nh; h += 2) {
       if (h + 1 < nh) dma_stage(h + 1, 1);
       half_chunk(std::integral_constant<int, 0>{});
@@ -646,6 +659,7 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 && M16) ? 4 : 2) void conv_halo_k
         if constexpr (MOD) { if (h + 2 < nh) scale_stage(h + 2, 0); }
         __syncthreads();
       }
+    }
     }
   } else if constexpr (DMA != 0) {
     char* Hb = smem;                                             // 2 halo images
@@ -1506,6 +1520,18 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   if (g_halo_s2dma && in_mul == 2 && nphase == 1 && g_mfma16 != 1 && (a.pre ? g_halo_s2dma >= 2 : !a.xs) && c.taps[0].n == 9 && c.Cin % 32 == 0 && c.Kpad == c.Cin &&
       (!a.pre || c.Cin <= 1024)) {
     constexpr size_t S2_SMEM = 2 * (size_t)(42 * 1024 + 9 * 4096);      // two half-chunk stages (see the kernel)
+    if (g_halo_s2dma == 4 && !a.pre) {                                    // one stage per workgroup, two workgroups per CU
+      const size_t dsm1 = std::max(S2_SMEM / 2, HALO_EPI_SMEM);
+#define LAUNCH_S2S(EP)                                                                                                  \
+  {                                                                                                                     \
+    static bool set = false;                                                                                            \
+    if (!set) { hipFuncSetAttribute((const void*)conv_halo_kernel<2, false, EP, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
+    hipLaunchKernelGGL((conv_halo_kernel<2, false, EP, 4>), grid, dim3(512), dsm1, s, a);                               \
+  }
+      if (a.residual && a.res_half) LAUNCH_S2S(2) else if (a.residual) LAUNCH_S2S(1) else LAUNCH_S2S(0)
+#undef LAUNCH_S2S
+      return true;
+    }
     const size_t dsmem = std::max(S2_SMEM + (a.pre ? (size_t)c.Cin * sizeof(float) : 0), HALO_EPI_SMEM);
 #define LAUNCH_S2M(EP)                                                                                                  \
   {                                                                                                                     \

@@ -180,7 +180,7 @@ def test_conv_halo_staging_variants(H, case, variant):
         scale = 1 / math.sqrt(Ci * k * k)
         w = torch.randn(Co, Ci, k, k, generator=torch.Generator().manual_seed(2))
         bias = torch.randn(Co, generator=torch.Generator().manual_seed(3))
-        for s2dma in ((0, 1, 2) if stride == 2 else (1,)):                     # forward: plain, epilogue, modulated, residual
+        for s2dma in ((0, 1, 2, 4) if stride == 2 else (1,)):                     # forward: plain, epilogue, modulated, residual
             H.lib.lcgan_set_option(13, s2dma)                                # (stride 2: both the register-staged and the parity-plane structure)
             x = feat((B, Hh, W, Ci), dtype, 1)
             pw_e, _ = E.prep_weight(w, scale, False, False)
