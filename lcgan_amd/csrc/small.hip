@@ -467,9 +467,25 @@ __global__ __launch_bounds__(TPB) void multi_tensor_kernel(const MTDesc* __restr
   const MTDesc d = descs[t];
   const long long base = (long long)chunk_index[blockIdx.x] * MT_CHUNK;
   const long long end = min(base + MT_CHUNK, d.n);
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  // 16-byte path: every pointer of the tensor 16-byte aligned (chunks start at multiples of 65 536 elements); the tail and unaligned
+  // tensors (views into a gradient bucket at odd offsets) take the scalar loops below.  4 bytes per lane ran these streams at 2.5 TB/s.
+  const bool al16 = ((((size_t)d.p0) | ((size_t)d.p1) | ((size_t)d.p2) | ((size_t)d.p3)) & 15) == 0;
+  const long long vend = al16 ? base + ((end - base) & ~3ll) : base;      // elements [base, vend) go as float4
   if (op == MT_ADAM) {         // a0 = beta1, a1 = beta2, a2 = eps ; f0 = lr / bias_correction1, f1 = 1 / sqrt(bias_correction2)
     float* p = (float*)d.p0; const float* g = (const float*)d.p1; float* m = (float*)d.p2; float* v = (float*)d.p3;
-    for (long long i = base + threadIdx.x; i < end; i += TPB) {
+    for (long long i = base + 4 * threadIdx.x; i < vend; i += 4 * TPB) {
+      const f4 g4 = *(const f4*)(g + i), m4 = *(const f4*)(m + i), v4 = *(const f4*)(v + i);
+      f4 p4 = *(const f4*)(p + i), mo, vo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        mo[j] = a0 * m4[j] + (1.f - a0) * g4[j];
+        vo[j] = a1 * v4[j] + (1.f - a1) * g4[j] * g4[j];
+        p4[j] -= d.f0 * mo[j] / (sqrtf(vo[j]) * d.f1 + a2);
+      }
+      *(f4*)(m + i) = mo; *(f4*)(v + i) = vo; *(f4*)(p + i) = p4;
+    }
+    for (long long i = vend + threadIdx.x; i < end; i += TPB) {
       const float gi = g[i];
       const float mi = a0 * m[i] + (1.f - a0) * gi;
       const float vi = a1 * v[i] + (1.f - a1) * gi * gi;
@@ -478,10 +494,23 @@ __global__ __launch_bounds__(TPB) void multi_tensor_kernel(const MTDesc* __restr
     }
   } else if (op == MT_EMA) {   // p0 = ema (target), p1 = source ; a0 = decay
     float* pe = (float*)d.p0; const float* ps = (const float*)d.p1;
-    for (long long i = base + threadIdx.x; i < end; i += TPB) { const float sv = ps[i]; pe[i] = sv + a0 * (pe[i] - sv); }
+    for (long long i = base + 4 * threadIdx.x; i < vend; i += 4 * TPB) {
+      const f4 s4 = *(const f4*)(ps + i);
+      f4 e4 = *(const f4*)(pe + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) e4[j] = s4[j] + a0 * (e4[j] - s4[j]);
+      *(f4*)(pe + i) = e4;
+    }
+    for (long long i = vend + threadIdx.x; i < end; i += TPB) { const float sv = ps[i]; pe[i] = sv + a0 * (pe[i] - sv); }
   } else {                     // MT_PACK: p0 = dst, p1 = src ; a0 = scale
     float* dst = (float*)d.p0; const float* src = (const float*)d.p1;
-    for (long long i = base + threadIdx.x; i < end; i += TPB) dst[i] = src[i] * a0;
+    for (long long i = base + 4 * threadIdx.x; i < vend; i += 4 * TPB) {
+      f4 s4 = *(const f4*)(src + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s4[j] *= a0;
+      *(f4*)(dst + i) = s4;
+    }
+    for (long long i = vend + threadIdx.x; i < end; i += TPB) dst[i] = src[i] * a0;
   }
 }
 

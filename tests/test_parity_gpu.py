@@ -172,6 +172,7 @@ def test_adam_and_ema_kernels_vs_torch():
     from lcgan_amd.optim import Adam
     torch.manual_seed(0)
     ps = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in ((5, 3), (200001,), (1,), (512, 513, 3, 3))]
+    ps.append(torch.nn.Parameter(torch.randn(70003, device=DEV)[1:70002]))      # 4-byte-aligned view: the kernel's scalar path
     ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
     opt, topt = Adam(ps, lr=0.002, betas=(0.0, 0.99)), torch.optim.Adam(ref, lr=0.002, betas=(0.0, 0.99), eps=1e-8)
     for it in range(3):
