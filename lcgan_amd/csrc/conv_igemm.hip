@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = 2 * P;                            // operand tiles per stage: A parts 0..P-1, then B parts 0..P-1
   __bf16* lds = (__bf16*)smem;
-  int* row_off = (int*)(smem + (DMAQ ? 4 * 128 * 64 : 2 * NT * TILE * sizeof(__bf16)));   // (DMAQ: two stages of two 8-KB tiles)
+  int* row_off = (int*)(smem + (DMAQ ? 12 * 128 * 64 : 2 * NT * TILE * sizeof(__bf16)));   // (DMAQ: three stages of four 8-KB tiles)
   int* row_b = row_off + BM;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -242,47 +242,70 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       const int n = n0 + row;
       wvo[k] = n < a.N ? 2u * (unsigned)(n * a.Kpad + ch) : 0xffffffffu;
     }
-    auto dma = [&](int q, int buf) {
-      const int tap = q / a.kc_per_tap, c0 = (q - tap * a.kc_per_tap) * BK;
-      const int dy = tt.dy[tap], dx = tt.dx[tap];
-      const int tofs = 2 * ((dy * a.Win + dx) * a.Cin + c0);
-      char* S = smem + buf * 2 * QT;
+    // A stage = TWO K chunks (A, B, A, B: 32 KB); three stages, loads two stages ahead.  These launches run one workgroup of 4 waves
+    // per CU (few tiles x split-K), so nothing hides a wave's own LDS / barrier latency: with one chunk per barrier and one step of
+    // prefetch a step took ~1 us for 8 MFMAs per wave (a layer worth 12 us took 36-46).  Now 16 MFMAs per barrier, and the loads of the
+    // next two stages stay in flight across it: a stage is 8 DMA instructions per wave, `s_waitcnt vmcnt(8)` leaves the youngest
+    // stage pending, and a raw s_barrier (no vmcnt(0), which __syncthreads would add while a DMA is pending) publishes the stage
+    // that landed and retires the one just read.  A chunk beyond the split's range is issued with out-of-range offsets (zeros).
+    constexpr int NST = 3, SB = 4 * QT;                          // stages, bytes per stage
+    auto dma = [&](int q, int buf) {                             // chunks q, q + 1 -> stage buf
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const bool ok = (unsigned)(aiy[k] + dy) < (unsigned)a.Hin && (unsigned)(aix[k] + dx) < (unsigned)a.Win;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void_g*)(S + (widu + 4 * k) * 1024), 16, ok ? (unsigned)(abase[k] + tofs) : 0xffffffffu, 0, 0, 0);
+      for (int h = 0; h < 2; ++h) {
+        const bool live = q + h < nq;
+        const int qq = live ? q + h : q;
+        const int tap = qq / a.kc_per_tap, c0 = (qq - tap * a.kc_per_tap) * BK;
+        const int dy = tt.dy[tap], dx = tt.dx[tap];
+        const int tofs = 2 * ((dy * a.Win + dx) * a.Cin + c0);
+        char* S = smem + buf * SB + h * 2 * QT;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const bool ok = live && (unsigned)(aiy[k] + dy) < (unsigned)a.Hin && (unsigned)(aix[k] + dx) < (unsigned)a.Win;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void_g*)(S + (widu + 4 * k) * 1024), 16, ok ? (unsigned)(abase[k] + tofs) : 0xffffffffu, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void_g*)(S + QT + (widu + 4 * k) * 1024), 16, live ? wvo[k] : 0xffffffffu,
+                                                   __builtin_amdgcn_readfirstlane(2 * (tt.wt[tap] * a.N * a.Kpad + c0)), 0, 0);
       }
-#pragma unroll
-      for (int k = 0; k < 2; ++k)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void_g*)(S + QT + (widu + 4 * k) * 1024), 16, wvo[k],
-                                                 __builtin_amdgcn_readfirstlane(2 * (tt.wt[tap] * a.N * a.Kpad + c0)), 0, 0);
     };
     const int half = lane >> 5, sw = (lane >> 2) & 3;
     const int fa0 = (wm * 64 + (lane & 31)) * 64 + ((half ^ sw) << 4);          // mi = 1: + 32 rows; k-step 1: ^ 32
     const int fb0 = QT + (wn * 64 + (lane & 31)) * 64 + ((half ^ sw) << 4);
     auto computeq = [&](int buf) {
-      const char* S = smem + buf * 2 * QT;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 af[2], bf[2];
-        af[0] = *(const bf16x8*)(S + (fa0 ^ (ks * 32)));
-        af[1] = *(const bf16x8*)(S + (fa0 ^ (ks * 32)) + 32 * 64);
-        bf[0] = *(const bf16x8*)(S + (fb0 ^ (ks * 32)));
-        bf[1] = *(const bf16x8*)(S + (fb0 ^ (ks * 32)) + 32 * 64);
+      for (int h = 0; h < 2; ++h) {
+        const char* S = smem + buf * SB + h * 2 * QT;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8 af[2], bf[2];
+          af[0] = *(const bf16x8*)(S + (fa0 ^ (ks * 32)));
+          af[1] = *(const bf16x8*)(S + (fa0 ^ (ks * 32)) + 32 * 64);
+          bf[0] = *(const bf16x8*)(S + (fb0 ^ (ks * 32)));
+          bf[1] = *(const bf16x8*)(S + (fb0 ^ (ks * 32)) + 32 * 64);
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        }
       }
     };
-    if (q0 < nq) dma(q0, 0);
-    __syncthreads();
-    for (int q = q0; q < nq; ++q) {
-      const int cur = (q - q0) & 1;
-      if (q + 1 < nq) dma(q + 1, cur ^ 1);
+    const int nstep = (nq - q0 + 1) >> 1;                        // stages of this split
+    if (nstep > 0) dma(q0, 0);
+    if (nstep > 1) dma(q0 + 2, 1);
+    if (nstep > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int st = 0; st < nstep; ++st) {
+      const int nxt2 = cur + 2 >= NST ? cur + 2 - NST : cur + 2;
+      if (st + 2 < nstep) dma(q0 + 2 * (st + 2), nxt2);
       computeq(cur);
-      __syncthreads();
+      // stage st + 1 must have landed: everything but the stage issued after it (st + 2, where it exists)
+      if (st + 2 < nstep) asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      cur = cur + 1 == NST ? 0 : cur + 1;
     }
     }
   } else {
@@ -2293,7 +2316,11 @@ int launch_igemm(const ConvArgs& a, int nphase, hipStream_t s) {
   bool dmaq = false;
   if constexpr (NS == 1 && sizeof(T) == 2) {
     dmaq = g_igemm_dma && !a.pre && a.Cin % 32 == 0 && a.Kpad == a.Cin && (long long)a.B * a.Hin * a.Win * a.Cin < (1ll << 31);
-    if (dmaq) hipLaunchKernelGGL((conv_igemm_kernel<T, NS, true>), grid, dim3(256), (size_t)(4 * 128 * 64 + 2 * BM * sizeof(int)), s, a);
+    if (dmaq) {
+      static bool dset = false;
+      if (!dset) { hipFuncSetAttribute((const void*)conv_igemm_kernel<T, NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); dset = true; }
+      hipLaunchKernelGGL((conv_igemm_kernel<T, NS, true>), grid, dim3(256), (size_t)(12 * 128 * 64 + 2 * BM * sizeof(int)), s, a);
+    }
   }
   if (!dmaq) hipLaunchKernelGGL((conv_igemm_kernel<T, NS>), grid, dim3(256), smem, s, a);
   if (a.nsplit > 1) launch_finalize<T>(a, a.ws, s);
