@@ -462,6 +462,13 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
   const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
   const TapTable& tt = a.taps[phase];
   const int hy0 = a.hy0[phase], hx0 = a.hx0[phase], hh = a.hh[phase], hw = a.hw[phase];
+  // the epilogue's per-channel constants, fetched now (thread t < 128: channel n0 + t) instead of in front of the epilogue's barrier
+  float ep_bias = 0.f, ep_post = 1.f;
+  if (TR && tid < BN) {
+    const int n = n0 + tid;
+    if (a.bias && n < a.N) ep_bias = a.bias[n] * a.bias_scale;
+    if (a.post && n < a.Cout) ep_post = a.post[(size_t)b * a.Cout + n];
+  }
   // LDS pitch of a halo ROW in elements: a multiple of 256 bytes.  A wave's 32 fragment rows are 2 image rows of 16 pixels; with the
   // second row a whole number of bank rows below the first, the fixed lane groups of ds_read_b128 see the same conflict-free
   // pattern as 32 consecutive pixels (at the natural pitch hw * 80 B every A read was a 2-way bank conflict)
@@ -722,8 +729,8 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
           __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(Hb + buf * DMA_HBUF + (widu + 8 * k) * 1024), 16, hvo[k],
                                                    __builtin_amdgcn_readfirstlane(c0 * 2), 0, 0);
     };
-    auto scale_inplace = [&](int buf) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces have landed
+    auto scale_inplace = [&](int buf, bool wait) {
+      if (wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces have landed (no wait needed one barrier after their issue)
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         if (!hdo[k]) continue;
@@ -760,14 +767,14 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
 
     int lc = 0, lg = 0;
     auto advance = [&]() { if (++lg == ngroups) { lg = 0; ++lc; } };
-    if constexpr (MOD) {
-      for (int i = tid; i < a.Cin; i += 512) dpsc[i] = a.pre[(size_t)b * a.Cin + i];
-      __syncthreads();
-    }
     dma_halo(0, 0);
     dma_b(0, 0, 0);
     advance();
-    if constexpr (MOD) scale_inplace(0);
+    if constexpr (MOD) {                                         // (the sample's scales are fetched while the first tiles are in flight)
+      for (int i = tid; i < a.Cin; i += 512) dpsc[i] = a.pre[(size_t)b * a.Cin + i];
+      __syncthreads();
+      scale_inplace(0, true);
+    }
     __syncthreads();
     int c = 0, g = 0;
     bf16x8 af[2][2], bf[2][2];
@@ -814,6 +821,11 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
     };
     auto step = [&](int q, auto bufc) {
       constexpr int buf = decltype(bufc)::value;
+      if constexpr (MOD) {
+        // the next chunk's halo was issued in step g == 0 and that step's barrier waited for it: it is scaled at the top of step 1,
+        // under this step's MFMAs, not in the chunk's last step where every wave would do it right in front of the barrier
+        if (ngroups > 1 && g == 1 && c + 1 < nchunks) scale_inplace((c + 1) & 1, false);
+      }
       if (q + 1 < total) { dma_b(lc, lg, buf ^ 1); advance(); }
       if (g == 0 && c + 1 < nchunks) dma_halo((c + 1) * BK, (c + 1) & 1);
       const int t0 = g * TP;
@@ -832,7 +844,7 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
         mfmas16(0);
         mfmas16(1);
         if constexpr (MOD) {
-          if (g == ngroups - 1 && c + 1 < nchunks) scale_inplace((c + 1) & 1);
+          if (ngroups == 1 && c + 1 < nchunks) scale_inplace((c + 1) & 1, true);
         }
         __syncthreads();
         if (++g == ngroups) { g = 0; ++c; }
@@ -854,7 +866,7 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
       mfmas(0);
       mfmas(1);
       if constexpr (MOD) {
-        if (g == ngroups - 1 && c + 1 < nchunks) scale_inplace((c + 1) & 1);
+        if (ngroups == 1 && c + 1 < nchunks) scale_inplace((c + 1) & 1, true);
       }
       __syncthreads();                                           // (waits for this step's DMA: vmcnt(0), then the barrier)
       if (++g == ngroups) { g = 0; ++c; }
@@ -1050,11 +1062,7 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
   float* cpost = cbias + BN;
   const __bf16* side = SR ? a.xs : a.residual;                     // the tile that meets the accumulators: residual, or xs
   if (SR && tid < BN) colbuf[tid] = 0.f;
-  if (TR && tid < BN) {
-    const int n = n0 + tid;
-    cbias[tid] = (a.bias && n < a.N) ? a.bias[n] * a.bias_scale : 0.f;
-    cpost[tid] = (a.post && n < a.Cout) ? a.post[(size_t)b * a.Cout + n] : 1.f;
-  }
+  if (TR && tid < BN) { cbias[tid] = ep_bias; cpost[tid] = ep_post; }
   // half-resolution residual under a stride-1 geometry (TR layout): the 4 lanes that share a source pixel read its 8-byte channel
   // groups straight from global memory (L1 hits) in the loop below -- no staging pass, no 4x-redundant 16-byte loads
   const bool quarter = TR && EPI == 2 && a.out_mul == 1;
