@@ -50,3 +50,20 @@ def test_every_entry_point_cites_the_reference():
     hdr = open(os.path.join(ROOT, "include", "lcgan_hip.h")).read()
     for token in ("custom_layers.py", "cnn.py", "loss.py", "ema.py", "worker.py"):
         assert token in hdr
+
+
+def test_routing_switches_round_trip_and_reject_unknown():
+    """lcgan_set_option is host-only: each of the 17 switches the header lists returns its previous value, an unknown one LCGAN_EINVAL"""
+    from lcgan_amd import _lib, build
+    build.build(verbose=False)
+    lib = _lib.load()
+    hdr = re.sub(r"\s*\n\s*\*\s*", " ", open(os.path.join(ROOT, "include", "lcgan_hip.h")).read())
+    n_opt = 17
+    assert f"; {n_opt - 1} " in hdr and f"; {n_opt} " not in hdr[hdr.index("tuning switches"):hdr.index("int lcgan_set_option")]
+    for opt in range(n_opt):
+        old = lib.lcgan_set_option(opt, 1)
+        assert old >= 0, opt
+        assert lib.lcgan_set_option(opt, old) == 1
+        assert lib.lcgan_set_option(opt, old) == old
+    assert lib.lcgan_set_option(n_opt, 0) == -1
+    assert lib.lcgan_set_option(-5, 0) == -1
