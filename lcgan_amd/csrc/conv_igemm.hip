@@ -2002,10 +2002,10 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
 // different bank groups, exactly as the 320-byte padded pitch of the register-staged kernel arranged.
 // =========================================================================================================
 // positions per chunk: 64 at stride 1; 32 at stride 2, where a 64-position chunk (16 + 33 KB per stage) would leave one workgroup per CU
-template <int STRIDE>
+template <int STRIDE, bool HALF = false>                     // HALF: 32-position chunks at stride 1 too (32-wide grids)
 __global__ __launch_bounds__(512, 4) void conv_wgrad3_dma_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int SEG = STRIDE == 1 ? 64 : 32, NKX = 3;
+  constexpr int SEG = (STRIDE == 1 && !HALF) ? 64 : 32, NKX = 3;
   constexpr int XW = SEG * STRIDE + 2;                       // halo pixels of a row segment
   constexpr int GP = SEG / 4, XP = (XW + 3) / 4;             // 1-KB DMA pieces (4 records each) of G and X
   constexpr int NXI = (XP + 7) / 8;                          // X pieces per wave
@@ -2556,6 +2556,7 @@ static int conv_wgrad_impl(const void* x, const void* g, float* gwp,
   // LDS-DMA kernel: 64-position chunks at stride 1; 32-position chunks at stride 2 (two workgroups per CU either way)
   const bool dma_geom = dtype == DT_BF16 && k == 3 && Cg % 8 == 0 && Cx % 8 == 0 && !(g_wgrad3_pack && Cg <= 64 && Cx <= 64);
   const bool dma_s1 = dma_geom && g_wgrad_dma && stride == 1 && segw == 64;
+  const bool dma_s1h = dma_geom && g_wgrad_dma == 3 && stride == 1 && segw == 32;      // 32-wide grids, stride 1
   const bool dma_s2 = dma_geom && g_wgrad_dma == 3 && stride == 2 && segw >= 32;
   if (dma_s2) segw = 32;
   if (dtype == DT_BF16 && g_use_halo && segw != 0 && Hg * Wg >= 64 && (Hg & 3) == 0 && (g_wgrad3_small == 1 || (k == 3 && segw >= 32) || (g_wgrad3_small == 0 && !(pre_x || pre_g))) &&
@@ -2583,7 +2584,7 @@ static int conv_wgrad_impl(const void* x, const void* g, float* gwp,
     } else {
       // register-staged kernel: 166-236 VGPRs, one 512-thread workgroup per CU whatever the LDS size; the LDS-DMA kernel at
       // stride 1 keeps two (128 VGPRs, 66 KB of LDS each)
-      const int occ = (g_wgrad_dma >= 2 && pk == 1 && (dma_s1 || dma_s2)) ? 2 : 1;
+      const int occ = (g_wgrad_dma >= 2 && pk == 1 && (dma_s1 || dma_s2 || dma_s1h)) ? 2 : 1;
       const int max_parts = max(1, cps / (1024 / seg));
       double best = 1e30;
       for (int pt = 1; pt <= max_parts; ++pt) {
@@ -2626,6 +2627,12 @@ static int conv_wgrad_impl(const void* x, const void* g, float* gwp,
 #define LAUNCH_WG3_K(ST, SG, SW) { if (k == 3) LAUNCH_WG3(ST, SG, SW, 3) else LAUNCH_WG3(ST, SG, SW, 1) }
     if (pk == 4) { if (stride == 1) LAUNCH_WG3_PK(1, 4) else LAUNCH_WG3_PK(2, 4) }
     else if (pk == 2) { if (stride == 1) LAUNCH_WG3_PK(1, 2) else LAUNCH_WG3_PK(2, 2) }
+    else if (dma_s1h) {
+      const size_t dsm = 2 * (size_t)(8 + 9) * 1024;              // 32 positions + 34 halo pixels per stage
+      static bool set = false;
+      if (!set) { hipFuncSetAttribute((const void*)conv_wgrad3_dma_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+      hipLaunchKernelGGL((conv_wgrad3_dma_kernel<1, true>), grid3, dim3(512), dsm, s, a);
+    }
     else if (dma_s1 || dma_s2) {
       if (dma_s1) {
         const size_t dsm = 2 * (size_t)(16 + 17) * 1024;
