@@ -1551,7 +1551,9 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   if (g_halo_s2dma && in_mul == 2 && nphase == 1 && g_mfma16 != 1 && (a.pre ? g_halo_s2dma >= 2 : !a.xs) && c.taps[0].n == 9 && c.Cin % 32 == 0 && c.Kpad == c.Cin &&
       (!a.pre || c.Cin <= 1024)) {
     constexpr size_t S2_SMEM = 2 * (size_t)(42 * 1024 + 9 * 4096);      // two half-chunk stages (see the kernel)
-    if (g_halo_s2dma == 4 && a.pre && c.Cin <= 512) {                     // one stage per workgroup + the sample's scales: exactly 80 KB at Cin = 512
+    // one stage per workgroup only pays when two workgroups share a CU: a grid that cannot give every CU two keeps the two-stage form
+    const bool single = g_halo_s2dma == 4 && (long long)grid.x * grid.z >= 2 * 256;
+    if (single && a.pre && c.Cin <= 512) {                     // one stage per workgroup + the sample's scales: exactly 80 KB at Cin = 512
       const size_t dsm1 = std::max(S2_SMEM / 2 + (size_t)c.Cin * sizeof(float), HALO_EPI_SMEM);
 #define LAUNCH_S2SM(EP)                                                                                                 \
   {                                                                                                                     \
@@ -1563,7 +1565,7 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
 #undef LAUNCH_S2SM
       return true;
     }
-    if (g_halo_s2dma == 4 && !a.pre) {                                    // one stage per workgroup, two workgroups per CU
+    if (single && !a.pre) {                                               // one stage per workgroup, two workgroups per CU
       const size_t dsm1 = std::max(S2_SMEM / 2, HALO_EPI_SMEM);
 #define LAUNCH_S2S(EP)                                                                                                  \
   {                                                                                                                     \
