@@ -45,7 +45,7 @@ int g_wgrad_dma = 3;                      // lcgan_set_option(12, ...): LDS-DMA 
 int g_halo_s2dma = 4;                     // lcgan_set_option(13, ...): stride-2 forward 3x3 on the parity-plane LDS-DMA structure: 0 off, 1 = layers without per-sample input scales, 2 = all (two stages per workgroup, one workgroup per CU), 4 = as 2 but unscaled layers with ONE stage per workgroup and two workgroups per CU
 int g_halo_nb_group_kb = 8192;               // lcgan_set_option(14, ...): KB of weights (all taps x 128 rows x Cin) that concurrent channel blocks of one tile may hold in an XCD's L2; 0 = channel blocks slowest (one pass over the input per block)
 int g_wgrad_xcd = 0;                      // lcgan_set_option(15, ...): row-segment wgrad workgroups of one split share an XCD (1-D grid)
-int g_igemm_dma = 1;                      // lcgan_set_option(16, ...): LDS-DMA staging in the generic implicit-GEMM kernel (bf16, no input scales, Cin % 32 == 0)
+int g_igemm_dma = 2;                      // lcgan_set_option(16, ...): LDS-DMA staging in the generic implicit-GEMM kernel (bf16, no input scales, Cin % 32 == 0)
 int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): experiments, bit mask (the wgrad3 no-atomics switch is gone: it sat in the epilogue);
                                           // halo kernel: 8 = linear tile order (the store / emit / main-loop skipping switches used for the
                                           // fixed-cost analysis in DESIGN.md were removed again: they sat in the hot epilogue)
@@ -2337,12 +2337,54 @@ int launch_igemm(const ConvArgs& a, int nphase, hipStream_t s) {
   return launch_status();
 }
 
+// x_scaled[b,p,c] = bf16(x[b,p,c] * pre[b,c]): the per-sample input scale of a LOW-RESOLUTION modulated convolution applied once (a few
+// MB, ~5 us) so that the launch can take the LDS-DMA main loop of the generic kernel (which has no register stage to scale in); same
+// rounding as the register-staged loop (fp32 product, one bf16 rounding).
+__global__ void prescale_kernel(const __bf16* __restrict__ x, const float* __restrict__ pre, __bf16* __restrict__ out,
+                                long long nvec, int HW, int C, int pre_stride) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nvec) return;
+  const int cv = C >> 3, v = (int)(i % cv);
+  const int b = (int)(i / ((long long)cv * HW));
+  const bf16x8 t = *(const bf16x8*)(x + i * 8);
+  const float* ps = pre + (size_t)b * pre_stride + v * 8;
+  const f32x4 p0 = *(const f32x4*)ps, p1 = *(const f32x4*)(ps + 4);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (__bf16)((float)t[j] * (j < 4 ? p0[j] : p1[j - 4]));
+  *(bf16x8*)(out + i * 8) = o;
+}
+__bf16* g_prescale[MAX_DEV] = {};
+size_t g_prescale_bytes[MAX_DEV] = {};
+__bf16* prescale_scratch(size_t bytes) {               // grow-only, per device; written in full before every use, one launch stream
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  if (bytes > g_prescale_bytes[dev]) {
+    if (g_prescale[dev]) hipFree(g_prescale[dev]);
+    g_prescale_bytes[dev] = std::max(bytes, (size_t)16 << 20);
+    if (hipMalloc((void**)&g_prescale[dev], g_prescale_bytes[dev]) != hipSuccess) { g_prescale[dev] = nullptr; g_prescale_bytes[dev] = 0; return nullptr; }
+  }
+  return g_prescale[dev];
+}
+
 // Small-M layers (4x4 ... 16x16 grids) are weight-streaming bound and would occupy a handful of CUs: split the (tap, chunk)
 // loop over blockIdx.z so >= ~256 workgroups stream disjoint weight slices; partials meet in an fp32 workspace.
 int dispatch_igemm(const ConvArgs& a_in, int nphase, int dtype, hipStream_t s) {
   ConvArgs a = a_in;
   a.nsplit = 1; a.ws = nullptr;
   if (dtype == DT_BF16 && g_use_halo && try_launch_halo(a, nphase, a.in_mul, s)) return launch_status();
+  if (g_igemm_dma >= 2 && dtype == DT_BF16 && a.pre && a.Cin % 32 == 0 && a.Kpad == a.Cin && a.M >= 2048) {   // (below that the extra launch costs what the faster main loop gains: measured at local batch 4)
+    const size_t elems = (size_t)a.B * a.Hin * a.Win * a.Cin;
+    if (elems * sizeof(__bf16) <= ((size_t)32 << 20)) {
+      __bf16* xs_ = prescale_scratch(elems * sizeof(__bf16));
+      if (xs_) {
+        const long long nvec = (long long)(elems / 8);
+        hipLaunchKernelGGL(prescale_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, s, (const __bf16*)a.x, a.pre, xs_, nvec,
+                           a.Hin * a.Win, a.Cin, a.pre_stride);
+        a.x = xs_; a.pre = nullptr;
+      }
+    }
+  }
   const int wgs = cdiv(a.M, BM) * cdiv(a.Cout, BN) * nphase;
   int nq_min = 1 << 30;
   for (int p = 0; p < nphase; ++p) nq_min = std::min(nq_min, a.taps[p].n * a.kc_per_tap);
