@@ -162,7 +162,7 @@ int lcgan_multi_tensor(const void* descs, const int* chunk_tensor, const int* ch
  * kernel (0 off, 1 / 2 = taps per barrier); 11 the same record layout for convolutions with per-sample input scales; 12 LDS-DMA
  * weight-gradient kernel (0 off, 1, 2 = split for two workgroups per CU, 3 = also stride 2); 13 parity-plane stride-2 forward;
  * 14 KB of weights concurrent channel blocks of one tile may keep in an XCD's L2 (0 = one input pass per channel block);
- * 15 XCD-grouped weight-gradient workgroup order; 16 LDS-DMA staging of the generic implicit-GEMM kernel.  DESIGN.md section 2 ("Switches") has the measurements behind the defaults. */
+ * 15 XCD-grouped weight-gradient workgroup order; 16 LDS-DMA staging of the generic implicit-GEMM kernel (2 = modulated low-resolution layers too, through one prescale pass).  DESIGN.md section 2 ("Switches") has the measurements behind the defaults. */
 int lcgan_set_option(int option, int value);
 
 /* ---- per-launch HIP-event profiling (bench.py roofline) ---------------------------------------------------- */
