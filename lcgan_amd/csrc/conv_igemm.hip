@@ -731,16 +731,23 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
     };
     auto scale_inplace = [&](int buf, bool wait) {
       if (wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces have landed (no wait needed one barrier after their issue)
+      // all nine LDS reads first (a piece that does not exist reads inside the allocation and is not written back): one LDS round
+      // trip per chunk instead of three serialised ones
+      bf16x8 v[3];
+      f32x4 s0[3], s1[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        if (!hdo[k]) continue;
-        bf16x8* ptr = (bf16x8*)(Hb + buf * DMA_HBUF + (widu + 8 * k) * 1024 + lane * 16);
-        const f32x4 s0 = *(const f32x4*)(dpsc + h_c0 + hch[k]), s1 = *(const f32x4*)(dpsc + h_c0 + hch[k] + 4);
-        bf16x8 v = *ptr;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (__bf16)((float)v[j] * (j < 4 ? s0[j] : s1[j - 4]));
-        *ptr = v;
+        v[k] = *(const bf16x8*)(Hb + buf * DMA_HBUF + (hdo[k] ? (widu + 8 * k) * 1024 : 0) + lane * 16);
+        s0[k] = *(const f32x4*)(dpsc + h_c0 + hch[k]); s1[k] = *(const f32x4*)(dpsc + h_c0 + hch[k] + 4);
       }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[k][j] = (__bf16)((float)v[k][j] * (j < 4 ? s0[k][j] : s1[k][j - 4]));
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (hdo[k]) *(bf16x8*)(Hb + buf * DMA_HBUF + (widu + 8 * k) * 1024 + lane * 16) = v[k];
     };
     // weights: wave `wid` moves rows 16 wid .. 16 wid + 15 x 4 slots
     const int drow = 16 * widu + (lane >> 2);
