@@ -213,6 +213,29 @@ def test_conv_halo_staging_variants(H, case, variant):
             H.lib.lcgan_set_option(o, v)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64, 128, 128, 3, 1), (1, 64, 128, 64, 256, 3, 1), (2, 64, 64, 96, 160, 1, 1)])
+def test_conv_staging_variants_bit_identical(H, case):
+    """register staging, LDS-DMA with one / two taps per barrier and the modulated in-place scaling accumulate in the SAME order:
+    identical bits (the stride-2 parity-plane structure walks 16-channel half-chunks and may differ by one bf16 ulp, not tested here)"""
+    B, Hh, W, Ci, Co, k, stride = case
+    x = feat((B, Hh, W, Ci), torch.bfloat16, 1).cuda()
+    w = torch.randn(Co, Ci, k, k, generator=torch.Generator().manual_seed(2)).cuda()
+    bias = torch.randn(Co, generator=torch.Generator().manual_seed(3)).cuda()
+    pre, post = vec((B, Ci), 4).cuda(), vec((B, ceil8(Co)), 5).cuda()
+    pw, _ = H.prep_weight(w, 1 / math.sqrt(Ci * k * k), False, False)
+    old = [H.lib.lcgan_set_option(6, 0), H.lib.lcgan_set_option(10, 0), H.lib.lcgan_set_option(11, 0)]
+    try:
+        ref_p = H.conv_fwd(x, pw, Co, k, 1, bias=bias, act=1, gain=1.4)
+        ref_m = H.conv_fwd(x, pw, Co, k, 1, pre=pre, post=post, bias=bias, act=1, gain=1.4)
+        for dma, mod in ((1, 1), (2, 2)):
+            H.lib.lcgan_set_option(10, dma); H.lib.lcgan_set_option(11, mod)
+            assert torch.equal(H.conv_fwd(x, pw, Co, k, 1, bias=bias, act=1, gain=1.4), ref_p), (dma, "plain")
+            assert torch.equal(H.conv_fwd(x, pw, Co, k, 1, pre=pre, post=post, bias=bias, act=1, gain=1.4), ref_m), (dma, mod, "modulated")
+    finally:
+        for o, v in zip((6, 10, 11), old):
+            H.lib.lcgan_set_option(o, v)
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("case", [(1, 64, 64, 128, 256, 3, 1), (2, 64, 128, 64, 72, 3, 1), (1, 128, 128, 96, 128, 3, 2), (3, 64, 64, 256, 128, 3, 1)])
 def test_conv_wgrad_staging_variants(H, case, mode):
