@@ -33,8 +33,10 @@ int lcgan_conv_weight_prep(const float* w, int A, int Bc, int k, float scale, in
 /* every weight preparation of a network in one launch (EqualizedWeight.forward custom_layers.py:14 for all its convs, both
  * GEMM layouts, + the demodulation statistics).  descs: DEVICE array of 64-byte jobs {const float* w; int64 out_off (bf16
  * elements into out_base); int64 wsq_off (floats into wsq_base); int A, Bc, kk, transpose, parts, N, Kc, Kpad; float scale;
- * int pad}; chunk_entry / chunk_index: device int arrays, one entry per 16384-element chunk of a job (index >= 0: prepared
- * elements, < 0: wsq chunk -index-1).  Output layout per job as lcgan_conv_weight_prep. */
+ * int pad}; chunk_entry / chunk_index: device int arrays, one entry per chunk of a job (index >= 0: tile `index` of the
+ * prepared weight, 16 rows n x 64 channels c x all taps, row-major over ceil(N/16) x ceil(Kpad/64); index < 0: the
+ * 16384-element chunk -index-1 of wsq; a job with kk <= 9 and pad != 0 gets wsq written by its tiles instead and needs no
+ * such chunks).  Output layout per job as lcgan_conv_weight_prep. */
 int lcgan_conv_weight_prep_group(const void* descs, const int* chunk_entry, const int* chunk_index, int n_chunks,
                                  void* out_base, float* wsq_base, double total_elems, void* stream);
 /* gw[a][b][t] = scale*gwp[t][a][b] + 2 scale^2 w[a][b][t] gwsq[a][b]  (w, gwsq may be NULL);
@@ -42,6 +44,7 @@ int lcgan_conv_weight_prep_group(const void* descs, const int* chunk_entry, cons
 int lcgan_conv_wgrad_unprep(const float* gwp, int A, int Bc, int k, float scale, int transposed, const float* w,
                             const float* gwsq, float* gw, void* stream);
 /* lcgan_conv_wgrad + lcgan_conv_wgrad_unprep in one call (the slab reduction writes the weight-layout gradient directly);
+ * gwp: scratch of k*k*A*Bc floats, contents irrelevant on entry (unlike lcgan_conv_wgrad, which ACCUMULATES into gwp);
  * replaces the same autograd step as the two calls above: torch conv weight gradient, custom_layers.py:41,43,78,83 */
 int lcgan_conv_wgrad_fused(const void* x, const void* g, float* gwp,
                            int B, int Hx, int Wx, int Cx, int Hg, int Wg, int Cg, int A, int Bc, int k, int stride,

@@ -2216,34 +2216,102 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, int A, int Bc, i
 
 // All weight preparations of a network in ONE launch (after its Adam step every conv weight needs its forward layout, its
 // transposed layout and, for modulated convs, the demodulation statistic: ~120 launches per iteration otherwise).  A device
-// table describes the jobs; a block handles one 16384-element chunk of one job (chunk_index >= 0: prepared-weight elements,
-// < 0: chunk -index-1 of the wsq statistic).  Outputs live in two flat buffers at the offsets recorded in the table.
+// table describes the jobs; a block handles one chunk of one job: chunk_index >= 0 is a tile of 16 output rows n x 64 input
+// channels c with ALL taps (tile = index, row-major over ceil(N/16) x ceil(Kpad/64)), chunk_index < 0 is the 16384-element
+// chunk -index-1 of the wsq statistic.  Outputs live in two flat buffers at the offsets recorded in the table.
+// The parameter keeps its taps innermost ([A][Bc][k][k]) and the prepared layouts keep them outermost, so a tile is read as
+// whole runs of the parameter (64*kk floats per row, or 16*kk for the transposed layout), transposed through LDS and written
+// as 128-byte runs of every tap plane; an element-per-thread gather fetched each parameter line once per tap (9 x).
 struct PrepDesc { const float* w; long long out_off; long long wsq_off; int A, Bc, kk, transpose, parts, N, Kc, Kpad; float scale; int pad; };
 constexpr int PREP_CHUNK = 16384;
+constexpr int PREP_TN = 16, PREP_TC = 64, PREP_TT = 9;                 // tile rows, tile channels, taps staged per pass
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+template <int TT>                                                      // TT = taps per pass when known (1, 9); 0 = min(kk, 9) at run time
+__device__ __forceinline__ void prep_tile(const PrepDesc& d, int tile, __bf16* __restrict__ out, float* __restrict__ wsq_base, float* lds) {
+  const int tiles_c = (d.Kpad + PREP_TC - 1) / PREP_TC;
+  const int n0 = (tile / tiles_c) * PREP_TN, c0 = (tile % tiles_c) * PREP_TC;
+  const size_t total = (size_t)d.kk * d.N * d.Kpad;
+  const int tid = threadIdx.x;
+  for (int t0 = 0; t0 < d.kk; t0 += PREP_TT) {
+    const int tt_n = TT ? TT : min(d.kk - t0, PREP_TT);
+    const int pitch = PREP_TC * tt_n + 1;                              // lds[nl][cl][tt], odd row pitch
+    if (t0) __syncthreads();
+    if constexpr (TT != 0) {
+      // Known tap count: every thread owns E / 256 elements; it issues them in batches of unconditional range-checked buffer
+      // loads (an element outside the weight reads 0 through offset -1) so the batch's latencies overlap, then parks them in LDS.
+      constexpr int E = PREP_TN * PREP_TC * TT, PER = E / 256, BATCH = PER % 12 == 0 ? 12 : 4;
+      static_assert(E % 256 == 0 && PER % BATCH == 0, "tile elements per thread");
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)d.w, 0, (int)((size_t)d.A * d.Bc * d.kk * 4), 0x00020000);
+      for (int b0 = 0; b0 < PER; b0 += BATCH) {
+        float v[BATCH];
+        int dst[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+          const int e = tid + (b0 + j) * 256;
+          int nl, cl, tt;
+          if (!d.transpose) { nl = e / (PREP_TC * TT); const int r = e % (PREP_TC * TT); cl = r / TT; tt = r % TT; }   // w[n][c][t]: 64*TT-float runs
+          else              { cl = e / (PREP_TN * TT); const int r = e % (PREP_TN * TT); nl = r / TT; tt = r % TT; }   // w[c][n][t]: 16*TT-float runs
+          const int n = n0 + nl, c = c0 + cl;
+          const unsigned row = d.transpose ? (unsigned)c * d.Bc + n : (unsigned)n * d.Bc + c;
+          const unsigned off = (n < d.N && c < d.Kc) ? (row * d.kk + t0 + tt) * 4u : 0xffffffffu;
+          v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+          dst[j] = nl * pitch + cl * TT + tt;
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) lds[dst[j]] = v[j];
+      }
+    } else if (!d.transpose) {                                         // w[n][c][t]: a row n holds 64 * kk contiguous floats of the tile
+      const int run = PREP_TC * tt_n;
+      for (int e = tid; e < PREP_TN * run; e += 256) {
+        const int nl = e / run, r = e - nl * run, cl = r / tt_n, tt = r - cl * tt_n;
+        const int n = n0 + nl, c = c0 + cl;
+        lds[nl * pitch + r] = (n < d.N && c < d.Kc) ? d.w[((size_t)n * d.Bc + c) * d.kk + t0 + tt] : 0.f;
+      }
+    } else {                                                           // w[c][n][t]: a row c holds 16 * kk contiguous floats of the tile
+      const int run = PREP_TN * tt_n;
+      for (int e = tid; e < PREP_TC * run; e += 256) {
+        const int cl = e / run, r = e - cl * run, nl = r / tt_n, tt = r - nl * tt_n;
+        const int n = n0 + nl, c = c0 + cl;
+        lds[nl * pitch + cl * tt_n + tt] = (n < d.N && c < d.Kc) ? d.w[((size_t)c * d.Bc + n) * d.kk + t0 + tt] : 0.f;
+      }
+    }
+    __syncthreads();
+    if (d.pad && d.kk <= PREP_TT) {                                    // the tile holds every tap of its weights: wsq comes for free
+      float* wsq = wsq_base + d.wsq_off;
+      for (int e = tid; e < PREP_TN * PREP_TC; e += 256) {
+        const int nl = e / PREP_TC, cl = e % PREP_TC, n = n0 + nl, c = c0 + cl;
+        if (n >= d.N || c >= d.Kc) continue;
+        float acc = 0.f;
+        for (int tt = 0; tt < tt_n; ++tt) { const float v = lds[nl * pitch + cl * tt_n + tt] * d.scale; acc += v * v; }
+        wsq[d.transpose ? (size_t)c * d.Bc + n : (size_t)n * d.Bc + c] = acc;
+      }
+    }
+    for (int e = tid; e < tt_n * PREP_TN * (PREP_TC / 2); e += 256) {  // two channels per thread: 32 lanes write one 128-byte run
+      const int tt = e / (PREP_TN * PREP_TC / 2), r = e % (PREP_TN * PREP_TC / 2), nl = r / (PREP_TC / 2), cp = r % (PREP_TC / 2);
+      const int n = n0 + nl, c = c0 + 2 * cp;
+      if (n >= d.N || c >= d.Kpad) continue;                           // Kpad is a multiple of 32: a pair is in or out as a whole
+      float v0 = lds[nl * pitch + (2 * cp) * tt_n + tt] * d.scale, v1 = lds[nl * pitch + (2 * cp + 1) * tt_n + tt] * d.scale;
+      const size_t idx = ((size_t)(t0 + tt) * d.N + n) * d.Kpad + c;
+      for (int pp = 0; pp < d.parts; ++pp) {
+        bf16x2 h;
+        h[0] = (__bf16)v0; h[1] = (__bf16)v1;
+        *(bf16x2*)(out + (size_t)pp * total + idx) = h;
+        v0 -= (float)h[0]; v1 -= (float)h[1];
+      }
+    }
+  }
+}
 __global__ __launch_bounds__(256) void prep_group_kernel(const PrepDesc* __restrict__ descs, const int* __restrict__ chunk_entry,
                                                          const int* __restrict__ chunk_index, __bf16* __restrict__ out_base,
                                                          float* __restrict__ wsq_base) {
+  __shared__ float lds[PREP_TN * (PREP_TC * PREP_TT + 1)];
   const PrepDesc d = descs[chunk_entry[blockIdx.x]];
   const int ci = chunk_index[blockIdx.x];
   if (ci >= 0) {
-    const size_t total = (size_t)d.kk * d.N * d.Kpad;
-    const size_t beg = (size_t)ci * PREP_CHUNK, end = min(beg + PREP_CHUNK, total);
     __bf16* out = out_base + d.out_off;
-    for (size_t idx = beg + threadIdx.x; idx < end; idx += 256) {
-      const int c = (int)(idx % d.Kpad);
-      const int n = (int)((idx / d.Kpad) % d.N);
-      const int t = (int)(idx / ((size_t)d.Kpad * d.N));
-      float v = 0.f;
-      if (c < d.Kc) {
-        const int aa = d.transpose ? c : n, bb = d.transpose ? n : c;
-        v = d.w[((size_t)aa * d.Bc + bb) * d.kk + t] * d.scale;
-      }
-      for (int pp = 0; pp < d.parts; ++pp) {
-        const __bf16 h = (__bf16)v;
-        out[(size_t)pp * total + idx] = h;
-        v -= (float)h;
-      }
-    }
+    if (d.kk == 9) prep_tile<9>(d, ci, out, wsq_base, lds);
+    else if (d.kk == 1) prep_tile<1>(d, ci, out, wsq_base, lds);
+    else prep_tile<0>(d, ci, out, wsq_base, lds);
   } else {
     const int AB = d.A * d.Bc;
     const int beg = (-ci - 1) * PREP_CHUNK, end = min(beg + PREP_CHUNK, AB);
@@ -2461,8 +2529,10 @@ int lcgan_conv_weight_prep(const float* w, int A, int Bc, int k, float scale, in
 }
 
 // descs: device array of 64-byte job descriptors {w (8 B), out_off (8 B, bf16 elements), wsq_off (8 B, floats, unused when the
-// job has no wsq chunks), A, Bc, kk, transpose, parts, N, Kc, Kpad (8 ints), scale (float), pad}; chunk_entry / chunk_index:
-// device int arrays, one entry per 16384-element chunk (chunk_index >= 0: prepared elements, < 0: wsq chunk -index-1).
+// job has no wsq chunks), A, Bc, kk, transpose, parts, N, Kc, Kpad (8 ints), scale (float), pad (!= 0 with kk <= 9: the
+// job's tiles also write wsq)}; chunk_entry / chunk_index:
+// device int arrays, one entry per chunk (chunk_index >= 0: tile of 16 rows x 64 channels x all taps of the prepared weight,
+// row-major over ceil(N/16) x ceil(Kpad/64); < 0: 16384-element wsq chunk -index-1).
 int lcgan_conv_weight_prep_group(const void* descs, const int* chunk_entry, const int* chunk_index, int n_chunks,
                                  void* out_base, float* wsq_base, double total_elems, void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -2660,6 +2730,7 @@ static int conv_wgrad_impl(const void* x, const void* g, float* gwp,
     // launch with enough splits takes the slab.
     if (pk == 1 && g_wgrad_slab_min > 0 && a.nsplit >= g_wgrad_slab_min && slab_bytes <= ((size_t)1 << 30))
       a.slab = wgrad_slab_scratch(slab_bytes);                    // (packed groups: several waves add into one element -> atomics only)
+    if (up && !a.slab) hipMemsetAsync(gwp, 0, (size_t)k * k * A * Bc * sizeof(float), s);   // fused entry: gwp arrives uncleared
     a.na = cdiv(A, 128); a.nc = cdiv(Bc, 128); a.xcd_order = g_wgrad_xcd;
     dim3 grid3(a.na, a.nc, nkx * a.nsplit);
     if (a.xcd_order) grid3 = dim3(8 * a.na * a.nc * nkx * cdiv(a.nsplit, 8), 1, 1);
@@ -2719,9 +2790,11 @@ static int conv_wgrad_impl(const void* x, const void* g, float* gwp,
     }
   } else if (dtype == DT_BF16) {
     const size_t smem = 2 * 2 * WG_TILE * sizeof(__bf16);
+    if (up) hipMemsetAsync(gwp, 0, (size_t)k * k * A * Bc * sizeof(float), s);
     hipLaunchKernelGGL((conv_wgrad_kernel<__bf16, 1>), grid, dim3(256), smem, s, a);
   } else if (dtype == DT_F32) {
     const size_t smem = 2 * 6 * WG_TILE * sizeof(__bf16);
+    if (up) hipMemsetAsync(gwp, 0, (size_t)k * k * A * Bc * sizeof(float), s);
     static bool attr_set = false;
     if (!attr_set) {
       hipFuncSetAttribute((const void*)conv_wgrad_kernel<float, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -2741,7 +2814,9 @@ int lcgan_conv_wgrad(const void* x, const void* g, float* gwp,
 }
 
 // lcgan_conv_wgrad followed by lcgan_conv_wgrad_unprep(gwp, ..., gw) as one call: when the partial tiles meet through the slab, the
-// reduction pass writes gw directly (one launch less per convolution backward, no gwp round trip); gwp is scratch either way.
+// reduction pass writes gw directly (one launch less per convolution backward, no gwp round trip); gwp is scratch either way
+// and need NOT be cleared by the caller: the call clears it itself on the paths that accumulate into it (the big layers, which
+// all take the slab, never touch it: 0.5 GB of fills per iteration at 256x256).
 // wA / wBc: the WEIGHT's [wA][wBc][k][k] (= [A][Bc] of the gradient call, or its transpose with transposed = 1).
 int lcgan_conv_wgrad_fused(const void* x, const void* g, float* gwp,
                            int B, int Hx, int Wx, int Cx, int Hg, int Wg, int Cg, int A, int Bc, int k, int stride,

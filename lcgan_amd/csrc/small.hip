@@ -393,9 +393,60 @@ __global__ void avg_latent_kernel(const float* __restrict__ w, float* __restrict
 // Replaces ~200 rocSOLVER micro-launches per call.  The reflectors are applied to the augmented matrix [A | I]:
 // H_{n-1}..H_0 [A | I] = [R | Q^T], so R and Q come out of the SAME n steps (two waves: thread c < 64 owns column c of A,
 // thread 64+r owns column r of the identity block = row r of Q) instead of a second, serial backward accumulation.
-// Columns live in registers (fully unrolled, predicated loops keep the indices static); only the current reflector travels
+// Columns live in registers (the n steps are unrolled so every register index is static); only the current reflector travels
 // through LDS, double-buffered so one barrier per step suffices, and is read back as 16 broadcast ds_read_b128.
 constexpr int QR_MAX = 64;
+// One Householder step with the column index J a compile-time constant: every row predicate (i == J, i > J) folds away, so the
+// thread that forms the reflector runs ~3 (64 - J) instructions instead of the ~1000 of a predicated 64-row sweep (that one
+// thread was 2/3 of the kernel's 220 us), and the update skips the rows above J, where the reflector is zero.  Rows and
+// columns >= n hold zeros (padded at load), so they need no predicate either.  Summation order is that of the predicated
+// loops (the skipped terms were exact zeros).
+template <int J>
+__device__ __forceinline__ void qr_step(float (&a)[QR_MAX], float (*vrow)[QR_MAX], float* taus, int c, bool isq, int n) {
+  constexpr int buf = J & 1;
+  if (!isq && c == J) {                                     // dlarfg on column J, rows J..n-1
+    const float alpha = a[J];
+    float xn2 = 0.f;
+#pragma unroll
+    for (int i = J + 1; i < QR_MAX; ++i) xn2 += a[i] * a[i];
+    float tau = 0.f, beta = alpha, sc = 0.f;
+    if (xn2 != 0.f) {
+      beta = -copysignf(sqrtf(alpha * alpha + xn2), alpha);
+      tau = (beta - alpha) / beta;
+      sc = 1.f / (alpha - beta);
+    }
+    vrow[buf][J] = 1.f;
+#pragma unroll
+    for (int i = J + 1; i < QR_MAX; ++i) vrow[buf][i] = a[i] * sc;
+    a[J] = beta;                                            // R_JJ ; rows below the diagonal are not part of R
+    taus[buf] = tau;
+  }
+  __syncthreads();
+  if (c < n && (isq || c > J)) {                            // column -= tau v (v^T column), rows J..63
+    constexpr int I0 = J & ~3;
+    float v[QR_MAX];
+#pragma unroll
+    for (int k = I0 / 4; k < QR_MAX / 4; ++k) {
+      const f32x4 t = *(const f32x4*)(&vrow[buf][4 * k]);
+      v[4 * k] = t[0]; v[4 * k + 1] = t[1]; v[4 * k + 2] = t[2]; v[4 * k + 3] = t[3];
+    }
+    float w[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = J; i < QR_MAX; ++i) w[i & 3] += v[i] * a[i];
+    const float wv = ((w[0] + w[1]) + (w[2] + w[3])) * taus[buf];
+#pragma unroll
+    for (int i = J; i < QR_MAX; ++i) a[i] -= v[i] * wv;
+  }
+}
+template <int J>
+__device__ __forceinline__ void qr_steps(float (&a)[QR_MAX], float (*vrow)[QR_MAX], float* taus, int c, bool isq, int n) {
+  if constexpr (J < QR_MAX) {
+    if (J < n) {                                            // n is uniform: every wave reaches the same barriers
+      qr_step<J>(a, vrow, taus, c, isq, n);
+      qr_steps<J + 1>(a, vrow, taus, c, isq, n);
+    }
+  }
+}
 __global__ __launch_bounds__(2 * QR_MAX) void qr_householder_kernel(const float* __restrict__ A, float* __restrict__ Q,
                                                                      float* __restrict__ R, int n) {
   A += (size_t)blockIdx.x * n * n; Q += (size_t)blockIdx.x * n * n; R += (size_t)blockIdx.x * n * n;   // one matrix per workgroup
@@ -406,42 +457,7 @@ __global__ __launch_bounds__(2 * QR_MAX) void qr_householder_kernel(const float*
   float a[QR_MAX];
 #pragma unroll
   for (int i = 0; i < QR_MAX; ++i) a[i] = isq ? ((i == c) ? 1.f : 0.f) : ((i < n && c < n) ? A[i * n + c] : 0.f);
-  for (int j = 0; j < n; ++j) {
-    const int buf = j & 1;
-    if (!isq && c == j) {                                   // dlarfg on column j, rows j..n-1
-      float alpha = 0.f, xn2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < QR_MAX; ++i) { if (i == j) alpha = a[i]; if (i > j && i < n) xn2 += a[i] * a[i]; }
-      float tau = 0.f, beta = alpha, sc = 0.f;
-      if (xn2 != 0.f) {
-        beta = -copysignf(sqrtf(alpha * alpha + xn2), alpha);
-        tau = (beta - alpha) / beta;
-        sc = 1.f / (alpha - beta);
-      }
-#pragma unroll
-      for (int i = 0; i < QR_MAX; ++i) {
-        const float vi = (i == j) ? 1.f : ((i > j && i < n) ? a[i] * sc : 0.f);
-        vrow[buf][i] = vi;
-        if (i == j) a[i] = beta;                            // R_jj ; rows below the diagonal are not part of R
-      }
-      taus[buf] = tau;
-    }
-    __syncthreads();
-    if (c < n && (isq || c > j)) {                          // column -= tau v (v^T column)
-      float v[QR_MAX];
-#pragma unroll
-      for (int k = 0; k < QR_MAX / 4; ++k) {
-        const f32x4 t = *(const f32x4*)(&vrow[buf][4 * k]);
-        v[4 * k] = t[0]; v[4 * k + 1] = t[1]; v[4 * k + 2] = t[2]; v[4 * k + 3] = t[3];
-      }
-      float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
-#pragma unroll
-      for (int i = 0; i < QR_MAX; i += 4) { w0 += v[i] * a[i]; w1 += v[i + 1] * a[i + 1]; w2 += v[i + 2] * a[i + 2]; w3 += v[i + 3] * a[i + 3]; }
-      const float wv = ((w0 + w1) + (w2 + w3)) * taus[buf];
-#pragma unroll
-      for (int i = 0; i < QR_MAX; ++i) a[i] -= v[i] * wv;
-    }
-  }
+  qr_steps<0>(a, vrow, taus, c, isq, n);
   if (c < n) {
 #pragma unroll
     for (int i = 0; i < QR_MAX; ++i) {

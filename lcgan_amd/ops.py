@@ -52,6 +52,26 @@ class inputs_only:
         _inputs_only = self.prev
 
 
+class _NoGraphCtx:
+    """stand-in for a Function's ctx when no graph is recorded: forward()'s bookkeeping calls become no-ops"""
+    __slots__ = ("cfg", "G", "clog", "per_sample", "scale", "t", "tau")
+
+    def save_for_backward(self, *tensors):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
+def _ap(fn, *args):
+    """fn.apply(*args) from inside a backward pass.  The nested Functions exist so that a backward pass is itself differentiable
+    (R1: create_graph=True).  In an ordinary backward pass grad mode is off, no node would be recorded, and Function.apply is
+    pure dispatch overhead (~5 us x ~600 nested calls per iteration; a batch-4 step is launch-bound): call forward() directly."""
+    if torch.is_grad_enabled():
+        return fn.apply(*args)
+    return fn.forward(_NoGraphCtx(), *args)
+
+
 def _wants(ctx, i: int) -> bool:
     """does this backward owe a gradient for PARAMETER input i?"""
     return ctx.needs_input_grad[i] and not _inputs_only
@@ -201,11 +221,11 @@ class Conv2dFn(Function):
         A = w.shape[0]
         want_gb = has_bias and _wants(ctx, 2)
         if act != ACT_NONE or want_gb:
-            gz, gb = ActBwdFn.apply(gy, y, act, gain, A, want_gb, bias_scale)
+            gz, gb = _ap(ActBwdFn, gy, y, act, gain, A, want_gb, bias_scale)
         else:
             gz, gb = gy, None
-        gx = ConvTransposeFn.apply(gz, w, k, stride, wscale, x.shape[-1], None) if ctx.needs_input_grad[0] else None
-        gw = ConvWeightGradFn.apply(x, gz, k, stride, wscale, w.shape[0], w.shape[1]) if _wants(ctx, 1) else None
+        gx = _ap(ConvTransposeFn, gz, w, k, stride, wscale, x.shape[-1], None) if ctx.needs_input_grad[0] else None
+        gw = _ap(ConvWeightGradFn, x, gz, k, stride, wscale, w.shape[0], w.shape[1]) if _wants(ctx, 1) else None
         gres = gy if (has_res and ctx.needs_input_grad[3]) else None
         return gx, gw, (gb if want_gb else None), gres, None, None, None, None, None, None
 
@@ -233,9 +253,9 @@ class ConvTransposeFn(Function):
         g, w = ctx.saved_tensors
         k, stride, wscale = ctx.cfg
         ggx = ggx.contiguous()
-        gg = Conv2dFn.apply(ggx, w, None, None, k, stride, ACT_NONE, 1.0, wscale, 0.0) if ctx.needs_input_grad[0] else None
-        gw = ConvWeightGradFn.apply(ggx, g, k, stride, wscale, w.shape[0], w.shape[1]) if ctx.needs_input_grad[1] else None
-        gres = AvgPool2Fn.apply(ggx) if ctx.needs_input_grad[6] else None
+        gg = _ap(Conv2dFn, ggx, w, None, None, k, stride, ACT_NONE, 1.0, wscale, 0.0) if ctx.needs_input_grad[0] else None
+        gw = _ap(ConvWeightGradFn, ggx, g, k, stride, wscale, w.shape[0], w.shape[1]) if ctx.needs_input_grad[1] else None
+        gres = _ap(AvgPool2Fn, ggx) if ctx.needs_input_grad[6] else None
         return gg, gw, None, None, None, None, gres
 
 
@@ -266,22 +286,22 @@ class ConvPoolFn(Function):
         A = w.shape[0]
         want_gb = has_bias and _wants(ctx, 2)
         if gy is None:                                                   # only the pooled branch was used
-            gx = AvgPool2TFn.apply(gpooled.contiguous()) if ctx.needs_input_grad[0] else None
+            gx = _ap(AvgPool2TFn, gpooled.contiguous()) if ctx.needs_input_grad[0] else None
             return gx, None, None, None, None, None, None, None, None
         gy = gy.contiguous()
         if box and act != ACT_NONE:
-            gz, gb = BoxActBwdFn.apply(gy, y, act, gain, A, want_gb, bias_scale)
+            gz, gb = _ap(BoxActBwdFn, gy, y, act, gain, A, want_gb, bias_scale)
         else:
             if box:
-                gy = Box3Fn.apply(gy)
+                gy = _ap(Box3Fn, gy)
             if act != ACT_NONE or want_gb:
-                gz, gb = ActBwdFn.apply(gy, y, act, gain, A, want_gb, bias_scale)
+                gz, gb = _ap(ActBwdFn, gy, y, act, gain, A, want_gb, bias_scale)
             else:
                 gz, gb = gy, None
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = ConvTransposeFn.apply(gz, w, k, 1, wscale, x.shape[-1], None if gpooled is None else gpooled.contiguous())
-        gw = ConvWeightGradFn.apply(x, gz, k, 1, wscale, w.shape[0], w.shape[1]) if _wants(ctx, 1) else None
+            gx = _ap(ConvTransposeFn, gz, w, k, 1, wscale, x.shape[-1], None if gpooled is None else gpooled.contiguous())
+        gw = _ap(ConvWeightGradFn, x, gz, k, 1, wscale, w.shape[0], w.shape[1]) if _wants(ctx, 1) else None
         return gx, gw, (gb if want_gb else None), None, None, None, None, None, None
 
 
@@ -292,7 +312,7 @@ class BoxActBwdFn(Function):
     def forward(ctx, gy, y, act, gain, clog, want_gbias, bias_scale):
         gz, gb = _K().box3_actbwd(gy, y, act, gain, clog, want_gbias)
         if gb is None:
-            gb = gy.new_zeros((0,), dtype=torch.float32)
+            gb = gy.new_empty((0,), dtype=torch.float32)
         else:
             gb = gb * bias_scale if bias_scale != 1.0 else gb
         ctx.save_for_backward(y)
@@ -324,8 +344,8 @@ class ConvWeightGradFn(Function):
         x, g = ctx.saved_tensors
         k, stride, wscale = ctx.cfg
         ggw = ggw.contiguous()
-        gx = ConvTransposeFn.apply(g, ggw, k, stride, wscale, x.shape[-1], None) if ctx.needs_input_grad[0] else None
-        gg = Conv2dFn.apply(x, ggw, None, None, k, stride, ACT_NONE, 1.0, wscale, 0.0) if ctx.needs_input_grad[1] else None
+        gx = _ap(ConvTransposeFn, g, ggw, k, stride, wscale, x.shape[-1], None) if ctx.needs_input_grad[0] else None
+        gg = _ap(Conv2dFn, x, ggw, None, None, k, stride, ACT_NONE, 1.0, wscale, 0.0) if ctx.needs_input_grad[1] else None
         return gx, gg, None, None, None, None, None
 
 
@@ -341,7 +361,7 @@ class ActBwdFn(Function):
         else:
             gz, gb, _ = K.act_bwd_reduce(gy, y, act, gain, clog, want_gz=True, want_gbias=want_gbias)
         if gb is None:
-            gb = gy.new_zeros((0,), dtype=torch.float32)
+            gb = gy.new_empty((0,), dtype=torch.float32)
         else:
             gb = gb * bias_scale if bias_scale != 1.0 else gb
         ctx.save_for_backward(y)
@@ -355,7 +375,7 @@ class ActBwdFn(Function):
         act, gain, clog = ctx.cfg
         if act == ACT_NONE:
             return ggz, None, None, None, None, None, None
-        g, _ = ActBwdFn.apply(ggz.contiguous(), y, act, gain, clog, False, 1.0)
+        g, _ = _ap(ActBwdFn, ggz.contiguous(), y, act, gain, clog, False, 1.0)
         return g, None, None, None, None, None, None
 
 
@@ -368,7 +388,7 @@ class Box3Fn(Function):
 
     @staticmethod
     def backward(ctx, gy):
-        return Box3Fn.apply(gy.contiguous())
+        return _ap(Box3Fn, gy.contiguous())
 
 
 class AvgPool2Fn(Function):
@@ -380,7 +400,7 @@ class AvgPool2Fn(Function):
 
     @staticmethod
     def backward(ctx, gy):
-        return AvgPool2TFn.apply(gy.contiguous())
+        return _ap(AvgPool2TFn, gy.contiguous())
 
 
 class AvgPool2TFn(Function):
@@ -390,7 +410,7 @@ class AvgPool2TFn(Function):
 
     @staticmethod
     def backward(ctx, ggx):
-        return AvgPool2Fn.apply(ggx.contiguous())
+        return _ap(AvgPool2Fn, ggx.contiguous())
 
 
 # ---- 1x1 convs that touch the f32 NCHW image; wt is [Bw,3,C] f32 (built from the parameter with torch glue) ----
@@ -411,11 +431,11 @@ class RGBExpandFn(Function):
         gy = gy.contiguous()
         want_gb = has_bias and _wants(ctx, 2)
         if act != ACT_NONE or want_gb:
-            gz, gb = ActBwdFn.apply(gy, y, act, gain, clog, want_gb, bias_scale)
+            gz, gb = _ap(ActBwdFn, gy, y, act, gain, clog, want_gb, bias_scale)
         else:
             gz, gb = gy, None
-        gimg = RGBReduceFn.apply(gz, wt, None, 0.0) if ctx.needs_input_grad[0] else None
-        gwt = RGBWeightGradFn.apply(img, gz, wt.shape[0] > 1) if _wants(ctx, 1) else None
+        gimg = _ap(RGBReduceFn, gz, wt, None, 0.0) if ctx.needs_input_grad[0] else None
+        gwt = _ap(RGBWeightGradFn, img, gz, wt.shape[0] > 1) if _wants(ctx, 1) else None
         return gimg, gwt, (gb if want_gb else None), None, None, None, None, None
 
 
@@ -433,9 +453,9 @@ class RGBReduceFn(Function):
         feat, wt = ctx.saved_tensors
         bias_scale, has_bias = ctx.cfg
         gimg = gimg.contiguous()
-        gfeat = (RGBExpandFn.apply(gimg, wt, None, 0.0, wt.shape[-1], ACT_NONE, 1.0, feat.dtype)
+        gfeat = (_ap(RGBExpandFn, gimg, wt, None, 0.0, wt.shape[-1], ACT_NONE, 1.0, feat.dtype)
                  if ctx.needs_input_grad[0] else None)
-        gwt = RGBWeightGradFn.apply(gimg, feat, wt.shape[0] > 1) if ctx.needs_input_grad[1] else None
+        gwt = _ap(RGBWeightGradFn, gimg, feat, wt.shape[0] > 1) if ctx.needs_input_grad[1] else None
         gb = gimg.sum(dim=(0, 2, 3)) * bias_scale if (has_bias and ctx.needs_input_grad[2]) else None   # 3 numbers
         return gfeat, gwt, gb, None
 
@@ -453,8 +473,8 @@ class RGBWeightGradFn(Function):
     def backward(ctx, ggw):
         img, feat = ctx.saved_tensors
         ggw = ggw.contiguous()
-        gimg = RGBReduceFn.apply(feat, ggw, None, 0.0) if ctx.needs_input_grad[0] else None
-        gfeat = (RGBExpandFn.apply(img, ggw, None, 0.0, ggw.shape[-1], ACT_NONE, 1.0, feat.dtype)
+        gimg = _ap(RGBReduceFn, feat, ggw, None, 0.0) if ctx.needs_input_grad[0] else None
+        gfeat = (_ap(RGBExpandFn, img, ggw, None, 0.0, ggw.shape[-1], ACT_NONE, 1.0, feat.dtype)
                  if ctx.needs_input_grad[1] else None)
         return gimg, gfeat, None
 
@@ -470,7 +490,7 @@ class MbstdFn(Function):
     @staticmethod
     def backward(ctx, gy):
         (x,) = ctx.saved_tensors
-        return MbstdBwdFn.apply(gy.contiguous(), x, ctx.G), None
+        return _ap(MbstdBwdFn, gy.contiguous(), x, ctx.G), None
 
 
 class MbstdBwdFn(Function):
@@ -500,7 +520,7 @@ class ToNCHWFn(Function):
     @staticmethod
     def backward(ctx, g):
         calloc, dtype = ctx.cfg
-        return ToNHWCFn.apply(g.contiguous(), calloc, dtype), None
+        return _ap(ToNHWCFn, g.contiguous(), calloc, dtype), None
 
 
 class ToNHWCFn(Function):
@@ -511,7 +531,7 @@ class ToNHWCFn(Function):
 
     @staticmethod
     def backward(ctx, g):
-        return ToNCHWFn.apply(g.contiguous(), ctx.clog), None, None
+        return _ap(ToNCHWFn, g.contiguous(), ctx.clog), None, None
 
 
 class ConstInputFn(Function):
@@ -543,9 +563,9 @@ class LinearFn(Function):
         x, w, y = ctx.saved_tensors
         scale, bias_scale, act, gain, has_bias = ctx.cfg
         gy = gy.contiguous()
-        gz = ActBwdF32Fn.apply(gy, y, act, gain) if act != ACT_NONE else (gy * gain if gain != 1.0 else gy)
-        gx = LinearTFn.apply(gz, w, scale) if ctx.needs_input_grad[0] else None
-        gw = LinearWeightGradFn.apply(gz, x, scale) if _wants(ctx, 1) else None
+        gz = _ap(ActBwdF32Fn, gy, y, act, gain) if act != ACT_NONE else (gy * gain if gain != 1.0 else gy)
+        gx = _ap(LinearTFn, gz, w, scale) if ctx.needs_input_grad[0] else None
+        gw = _ap(LinearWeightGradFn, gz, x, scale) if _wants(ctx, 1) else None
         gb = _K().colsum(gz.detach().contiguous(), bias_scale) if (has_bias and _wants(ctx, 2)) else None
         return gx, gw, gb, None, None, None, None
 
@@ -602,8 +622,8 @@ class LinearTFn(Function):
     def backward(ctx, ggx):
         g, w = ctx.saved_tensors
         ggx = ggx.contiguous()
-        gg = LinearFn.apply(ggx, w, None, ctx.scale, 0.0, ACT_NONE, 1.0) if ctx.needs_input_grad[0] else None
-        gw = LinearWeightGradFn.apply(g, ggx, ctx.scale) if ctx.needs_input_grad[1] else None
+        gg = _ap(LinearFn, ggx, w, None, ctx.scale, 0.0, ACT_NONE, 1.0) if ctx.needs_input_grad[0] else None
+        gw = _ap(LinearWeightGradFn, g, ggx, ctx.scale) if ctx.needs_input_grad[1] else None
         return gg, gw, None
 
 
@@ -620,8 +640,8 @@ class LinearWeightGradFn(Function):
     def backward(ctx, ggw):
         g, x = ctx.saved_tensors
         ggw = ggw.contiguous()
-        gg = LinearFn.apply(x, ggw, None, ctx.scale, 0.0, ACT_NONE, 1.0) if ctx.needs_input_grad[0] else None
-        gx = LinearTFn.apply(g, ggw, ctx.scale) if ctx.needs_input_grad[1] else None
+        gg = _ap(LinearFn, x, ggw, None, ctx.scale, 0.0, ACT_NONE, 1.0) if ctx.needs_input_grad[0] else None
+        gx = _ap(LinearTFn, g, ggw, ctx.scale) if ctx.needs_input_grad[1] else None
         return gg, gx, None
 
 
@@ -635,7 +655,7 @@ class ActBwdF32Fn(Function):
     @staticmethod
     def backward(ctx, gg):
         (y,) = ctx.saved_tensors
-        return ActBwdF32Fn.apply(gg.contiguous(), y, *ctx.cfg), None, None, None
+        return _ap(ActBwdF32Fn, gg.contiguous(), y, *ctx.cfg), None, None, None
 
 
 # =====================================================================================================
