@@ -507,9 +507,9 @@ def test_warp_bwd_rough_flow_large(H):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("N,G", [(4, 4), (8, 8), (16, 8), (32, 8)])
-def test_mbstd(H, dtype, N, G):
-    C = 64
+@pytest.mark.parametrize("N,G,C", [(4, 4, 64), (8, 8, 64), (16, 8, 64), (32, 8, 64), (32, 4, 512), (8, 4, 20)])
+def test_mbstd(H, dtype, N, G, C):
+    """C = 20: the element-per-thread path of channel counts that are not a multiple of 8; the others take 8 channels per thread"""
     x = feat((N, 4, 4, C), dtype, 61)
     Cy = ceil8(C + 1)
     check(H.mbstd_fwd(x.cuda(), G, Cy), E.mbstd_fwd(x, G, Cy), dtype, "fwd")
