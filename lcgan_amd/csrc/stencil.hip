@@ -605,19 +605,25 @@ __global__ void warp_fill_kernel(const T* __restrict__ flow, int* __restrict__ c
   float cx[4], cy[4];
   cubic_coeffs(ix - fx0, cx); cubic_coeffs(iy - fy0, cy);
   const int x0 = (int)fx0 - 1, y0 = (int)fy0 - 1;
+  // three passes over the 16 taps so that the returning atomics, then the offset loads, are all in flight together (one tap at a
+  // time the chain  atomic -> offset -> store  was 16 round trips per thread)
+  int q[16], slot[16], base[16];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int yy = y0 + i;
-    if ((unsigned)yy >= (unsigned)H) continue;
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int xx = x0 + j;
-      if ((unsigned)xx >= (unsigned)W) continue;
-      const int q = (b * H + yy) * W + xx;
-      const int slot = atomicSub(cnt + q, 1) - 1;
-      WarpEntry e; e.p = (int)pix; e.w = cy[i] * cx[j];
-      entries[(size_t)offs[q] + slot] = e;
+      const int yy = y0 + i, xx = x0 + j;
+      q[4 * i + j] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? (b * H + yy) * W + xx : -1;
     }
+#pragma unroll
+  for (int t = 0; t < 16; ++t) slot[t] = q[t] >= 0 ? atomicSub(cnt + q[t], 1) - 1 : 0;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) base[t] = offs[max(q[t], 0)];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    if (q[t] < 0) continue;
+    WarpEntry e; e.p = (int)pix; e.w = cy[t >> 2] * cx[t & 3];
+    entries[(size_t)base[t] + slot[t]] = e;
   }
 }
 
