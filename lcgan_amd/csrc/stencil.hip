@@ -25,9 +25,12 @@ static inline dim3 grid1d(long long n) { return dim3((unsigned)((n + TPB - 1) / 
 // Separable sliding window: a thread owns one (column w, 8-channel vector) and walks BOX_RH consecutive rows, keeping the
 // last three horizontal 3-sums in registers: 3 vector loads per output instead of 9 (the 9-tap version was L1-bound, 2.3x
 // off the HBM roofline).
-constexpr int BOX_RH = 8;
+// Rows per thread: 16 on the big maps (the two halo rows of a strip are re-read from L2: 25 % extra loads at 8 rows, 12 % at 16;
+// -3..-8 % at >= 64 x 64 x 512, batch 32), 8 below 4M channel vectors, where 16 leaves too few threads (+30 % at 32 x 32 x 512).
+int box_rh(long long nvectors) { return nvectors >= (1ll << 22) ? 16 : 8; }
 template <typename T>
-__global__ void box3_act_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int act, float gain) {
+__global__ void box3_act_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int act, float gain,
+                                int BOX_RH) {
   const int nvec = C >> 3;
   const int strips = (H + BOX_RH - 1) / BOX_RH;
   const long long total = (long long)B * strips * W * nvec;
@@ -42,13 +45,13 @@ __global__ void box3_act_kernel(const T* __restrict__ x, T* __restrict__ y, int 
   // branch-free taps: the column neighbours are clamped and masked once per thread, a row outside the image contributes zero
   const int xl = max(w - 1, 0) * C, xc = w * C, xr = min(w + 1, W - 1) * C;
   const float ml = w > 0 ? 1.f : 0.f, mr = w + 1 < W ? 1.f : 0.f;
-  auto rowsum = [&](int hh) {
-    F8 s = f8_zero();
-    if ((unsigned)hh >= (unsigned)H) return s;
-    const T* row = xb + (size_t)hh * W * C;
+  auto rowsum = [&](int hh) {                          // (rows too: a row outside the image is read clamped and scaled by 0 -- a branch
+    F8 s;                                              //  around the loads kept the next row's loads from issuing under this row's)
+    const float mh = (unsigned)hh < (unsigned)H ? 1.f : 0.f;
+    const T* row = xb + (size_t)min(max(hh, 0), H - 1) * W * C;
     const F8 a = Feat<T>::load(row + xl), c = Feat<T>::load(row + xc), d = Feat<T>::load(row + xr);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s.v[j] = a.v[j] * ml + c.v[j] + d.v[j] * mr;
+    for (int j = 0; j < 8; ++j) s.v[j] = (a.v[j] * ml + c.v[j] + d.v[j] * mr) * mh;
     return s;
   };
   F8 r0 = rowsum(h0 - 1), r1 = rowsum(h0);
@@ -94,12 +97,12 @@ __global__ void box3_actbwd_reduce_kernel(const T* __restrict__ gy, const T* __r
     const int xl = max(w - 1, 0) * C, xc = w * C, xr = min(w + 1, W - 1) * C;     // branch-free column taps (see box3_act_kernel)
     const float ml = w > 0 ? 1.f : 0.f, mr = w + 1 < W ? 1.f : 0.f;
     auto rowsum = [&](int hh) {
-      F8 s = f8_zero();
-      if ((unsigned)hh >= (unsigned)H) return s;
-      const T* row = gb + (size_t)hh * W * C;
+      F8 s;
+      const float mh = (unsigned)hh < (unsigned)H ? 1.f : 0.f;
+      const T* row = gb + (size_t)min(max(hh, 0), H - 1) * W * C;
       const F8 a = Feat<T>::load(row + xl), c = Feat<T>::load(row + xc), d = Feat<T>::load(row + xr);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s.v[j] = a.v[j] * ml + c.v[j] + d.v[j] * mr;
+      for (int j = 0; j < 8; ++j) s.v[j] = (a.v[j] * ml + c.v[j] + d.v[j] * mr) * mh;
       return s;
     };
     F8 r0 = rowsum(h0 - 1), r1 = rowsum(h0);
@@ -131,7 +134,7 @@ __global__ void box3_actbwd_reduce_kernel(const T* __restrict__ gy, const T* __r
 // (6 vector loads per output instead of 18: the 9-tap version ran 2.2x off the HBM roofline).
 template <typename T>
 __global__ void box3_act_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ y, T* __restrict__ gx,
-                                    int B, int H, int W, int C, int act, float gain) {
+                                    int B, int H, int W, int C, int act, float gain, int BOX_RH) {
   const int nvec = C >> 3;
   const int strips = (H + BOX_RH - 1) / BOX_RH;
   const long long total = (long long)B * strips * W * nvec;
@@ -147,18 +150,19 @@ __global__ void box3_act_bwd_kernel(const T* __restrict__ gy, const T* __restric
   const float mk[3] = {w > 0 ? 1.f : 0.f, 1.f, w + 1 < W ? 1.f : 0.f};
   auto rowsum = [&](int hh) {
     F8 s = f8_zero();
-    if ((unsigned)hh >= (unsigned)H) return s;
+    const float mh = (unsigned)hh < (unsigned)H ? 1.f : 0.f;        // branch-free rows as well (see box3_act_kernel)
+    const int hc = min(max(hh, 0), H - 1);
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      const size_t off = base + ((size_t)hh * W + xo[d]) * C;
+      const size_t off = base + ((size_t)hc * W + xo[d]) * C;
       const F8 g = Feat<T>::load(gy + off);
       if (act == ACT_NONE) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s.v[j] += g.v[j] * (gain * mk[d]);
+        for (int j = 0; j < 8; ++j) s.v[j] += g.v[j] * (gain * (mk[d] * mh));
       } else {
         const F8 yo = Feat<T>::load(y + off);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s.v[j] += g.v[j] * (act_grad_from_out(yo.v[j], act, gain) * mk[d]);
+        for (int j = 0; j < 8; ++j) s.v[j] += g.v[j] * (act_grad_from_out(yo.v[j], act, gain) * (mk[d] * mh));
       }
     }
     return s;
@@ -1049,8 +1053,9 @@ int lcgan_box3_act(const void* x, void* y, int B, int H, int W, int C, int act, 
   if (C & 7) return LCGAN_EINVAL;
   const long long n = (long long)B * H * W * (C / 8);
   ProfScope p(KID_STENCIL, 0, (double)n * 8 * 2 * (dtype == DT_BF16 ? 2 : 4), s);
+  const int BOX_RH = box_rh(n);
   const long long nthr = (long long)B * ((H + BOX_RH - 1) / BOX_RH) * W * (C / 8);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(box3_act_kernel<T>, grid1d(nthr), dim3(TPB), 0, s, (const T*)x, (T*)y, B, H, W, C, act, gain));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(box3_act_kernel<T>, grid1d(nthr), dim3(TPB), 0, s, (const T*)x, (T*)y, B, H, W, C, act, gain, BOX_RH));
   return launch_status();
 }
 
@@ -1059,8 +1064,9 @@ int lcgan_box3_act_bwd(const void* gy, const void* y, void* gx, int B, int H, in
   if (C & 7) return LCGAN_EINVAL;
   const long long n = (long long)B * H * W * (C / 8);
   ProfScope p(KID_STENCIL, 0, (double)n * 8 * 3 * (dtype == DT_BF16 ? 2 : 4), s);
+  const int BOX_RH = box_rh(n);
   const long long nthr = (long long)B * ((H + BOX_RH - 1) / BOX_RH) * W * (C / 8);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(box3_act_bwd_kernel<T>, grid1d(nthr), dim3(TPB), 0, s, (const T*)gy, (const T*)y, (T*)gx, B, H, W, C, act, gain));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(box3_act_bwd_kernel<T>, grid1d(nthr), dim3(TPB), 0, s, (const T*)gy, (const T*)y, (T*)gx, B, H, W, C, act, gain, BOX_RH));
   return launch_status();
 }
 
