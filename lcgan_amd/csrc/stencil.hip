@@ -290,12 +290,14 @@ __global__ void avgpool2_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx
 //   gdq[b,c] += sum_p gz * (ypre - bias[c]*bias_scale),  ypre = act^-1(y / gain)   (optional: demod gradient)
 // One block = P consecutive pixels of ONE sample; a thread keeps one channel vector in registers.
 // ------------------------------------------------------------------------------------------------------------
-template <typename T>
+// GDQ: the demodulation statistic is wanted as well (modulated convolutions only); the plain case carries neither its second
+// accumulator set nor its arithmetic (128 -> fewer registers, one more wave per SIMD).
+template <typename T, bool GDQ>
 __global__ void act_bwd_reduce_kernel(const T* __restrict__ gy, const T* __restrict__ y, T* __restrict__ gz,
                                       const float* __restrict__ bias, float bias_scale,
                                       float* __restrict__ gbias, float* __restrict__ gdq,
                                       int HW, int C, int Clog, int act, float gain, int P) {
-  __shared__ float red[2][TPB * 8];
+  __shared__ float red[GDQ ? 2 : 1][TPB * 8];
   const int nvec = C >> 3;
   const int groups = TPB / nvec;                       // pixel groups running in parallel (>= 1; nvec <= 256)
   const int grp = threadIdx.x / nvec, v = threadIdx.x - grp * nvec;
@@ -305,12 +307,12 @@ __global__ void act_bwd_reduce_kernel(const T* __restrict__ gy, const T* __restr
   float sb[8], sq[8], bv[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { sb[j] = 0.f; sq[j] = 0.f; bv[j] = 0.f; }
-  if (active && bias && gdq) {
+  if (GDQ && active && bias) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) bv[j] = (v * 8 + j < Clog) ? bias[v * 8 + j] * bias_scale : 0.f;
   }
   if (active) {
-    const bool need_y = act != ACT_NONE || gdq;
+    const bool need_y = act != ACT_NONE || GDQ;
     const float inv_gain = 1.f / gain;
     auto one = [&](size_t off, const F8& g, const F8& yo) {
       F8 z;
@@ -318,9 +320,11 @@ __global__ void act_bwd_reduce_kernel(const T* __restrict__ gy, const T* __restr
       for (int j = 0; j < 8; ++j) {
         z.v[j] = g.v[j] * act_grad_from_out(yo.v[j], act, gain);
         sb[j] += z.v[j];
-        float t = yo.v[j] * inv_gain;
-        if (act == ACT_LRELU && t < 0.f) t *= (1.f / LRELU_SLOPE);
-        sq[j] += z.v[j] * (t - bv[j]);
+        if (GDQ) {
+          float t = yo.v[j] * inv_gain;
+          if (act == ACT_LRELU && t < 0.f) t *= (1.f / LRELU_SLOPE);
+          sq[j] += z.v[j] * (t - bv[j]);
+        }
       }
       if (gz) Feat<T>::store(gz + off, z);
     };
@@ -344,16 +348,16 @@ __global__ void act_bwd_reduce_kernel(const T* __restrict__ gy, const T* __restr
       one(off, g, yo);
     }
   }
-  if (!gbias && !gdq) return;
+  if (!gbias && !GDQ) return;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { red[0][threadIdx.x * 8 + j] = sb[j]; red[1][threadIdx.x * 8 + j] = sq[j]; }
+  for (int j = 0; j < 8; ++j) { red[0][threadIdx.x * 8 + j] = sb[j]; if (GDQ) red[1][threadIdx.x * 8 + j] = sq[j]; }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += TPB) {
     const int vv = c >> 3, jj = c & 7;
     float tb = 0.f, tq = 0.f;
-    for (int gI = 0; gI < groups; ++gI) { const int t = gI * nvec + vv; tb += red[0][t * 8 + jj]; tq += red[1][t * 8 + jj]; }
+    for (int gI = 0; gI < groups; ++gI) { const int t = gI * nvec + vv; tb += red[0][t * 8 + jj]; if (GDQ) tq += red[1][t * 8 + jj]; }
     if (gbias && c < Clog) atomicAdd(gbias + c, tb);
-    if (gdq) atomicAdd(gdq + (size_t)b * C + c, tq);
+    if (GDQ) atomicAdd(gdq + (size_t)b * C + c, tq);
   }
 }
 
@@ -1128,8 +1132,10 @@ int lcgan_act_bwd_reduce(const void* gy, const void* y, void* gz, const float* b
   const int P = reduce_P(HW, B);
   dim3 grid(cdiv(HW, P), B);
   ProfScope p(KID_ACT_BWD, 0, (double)B * HW * C * (gz ? 3 : 2) * (dtype == DT_BF16 ? 2 : 4), s);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(act_bwd_reduce_kernel<T>, grid, dim3(TPB), 0, s, (const T*)gy, (const T*)y, (T*)gz,
-                                       bias, bias_scale, gbias, gdq, HW, C, Clog, act, gain, P));
+  if (gdq) { DISPATCH_T(dtype, hipLaunchKernelGGL((act_bwd_reduce_kernel<T, true>), grid, dim3(TPB), 0, s, (const T*)gy, (const T*)y, (T*)gz,
+                                                 bias, bias_scale, gbias, gdq, HW, C, Clog, act, gain, P)); }
+  else { DISPATCH_T(dtype, hipLaunchKernelGGL((act_bwd_reduce_kernel<T, false>), grid, dim3(TPB), 0, s, (const T*)gy, (const T*)y, (T*)gz,
+                                              bias, bias_scale, gbias, gdq, HW, C, Clog, act, gain, P)); }
   return launch_status();
 }
 
