@@ -132,14 +132,19 @@ __global__ void box3_actbwd_reduce_kernel(const T* __restrict__ gy, const T* __r
 // gx = box3(gy * act'(y))   (box3 is self-adjoint).  Same separable sliding window as box3_act_kernel: a thread owns one
 // (column, 8-channel vector), walks BOX_RH rows and keeps the last three horizontal 3-sums of gy*act'(y) in registers
 // (6 vector loads per output instead of 18: the 9-tap version ran 2.2x off the HBM roofline).
+// A wave holds 64 / nvec whole columns of one row strip (lanes [k nvec, (k+1) nvec) = column w0 + k), so for C <= 256 a thread
+// forms gy * act'(y) for its OWN column only and takes the neighbours' from the lanes nvec away; only the wave's first / last
+// column still load their outer neighbour: 2 + 2 * (2 nvec / 64) vector loads per output row instead of 6 (the kernel is bound by
+// load issue, not by HBM: 3.7 TB/s against the 5 TB/s of the 2-load activation backward).
 template <typename T>
 __global__ void box3_act_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ y, T* __restrict__ gx,
                                     int B, int H, int W, int C, int act, float gain, int BOX_RH) {
   const int nvec = C >> 3;
   const int strips = (H + BOX_RH - 1) / BOX_RH;
   const long long total = (long long)B * strips * W * nvec;
-  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
-  if (gid >= total) return;
+  const long long gid0 = (long long)blockIdx.x * TPB + threadIdx.x;
+  const bool live = gid0 < total;
+  const long long gid = live ? gid0 : total - 1;                     // (dead lanes of the last wave stay in step for the shuffles)
   const int v = (int)(gid % nvec);
   long long t = gid / nvec;
   const int w = (int)(t % W); t /= W;
@@ -148,22 +153,39 @@ __global__ void box3_act_bwd_kernel(const T* __restrict__ gy, const T* __restric
   const size_t base = (size_t)b * H * W * C + v * 8;
   const int xo[3] = {max(w - 1, 0), w, min(w + 1, W - 1)};          // branch-free column taps (see box3_act_kernel)
   const float mk[3] = {w > 0 ? 1.f : 0.f, 1.f, w + 1 < W ? 1.f : 0.f};
+  const bool share = nvec <= 32 && (64 % nvec) == 0;                // uniform
+  const int lane = threadIdx.x & 63;
+  const bool first_col = lane < nvec, last_col = lane >= 64 - nvec;
+  auto term = [&](int hc, int col, float m) {                       // gy * act'(y) * m at (hc, col)
+    const size_t off = base + ((size_t)hc * W + col) * C;
+    const F8 g = Feat<T>::load(gy + off);
+    F8 r;
+    if (act == ACT_NONE) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.v[j] = g.v[j] * (gain * m);
+    } else {
+      const F8 yo = Feat<T>::load(y + off);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.v[j] = g.v[j] * (act_grad_from_out(yo.v[j], act, gain) * m);
+    }
+    return r;
+  };
   auto rowsum = [&](int hh) {
-    F8 s = f8_zero();
     const float mh = (unsigned)hh < (unsigned)H ? 1.f : 0.f;        // branch-free rows as well (see box3_act_kernel)
     const int hc = min(max(hh, 0), H - 1);
+    const F8 c = term(hc, xo[1], mh);
+    F8 l, r, s;
+    if (share) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const size_t off = base + ((size_t)hc * W + xo[d]) * C;
-      const F8 g = Feat<T>::load(gy + off);
-      if (act == ACT_NONE) {
+      for (int j = 0; j < 8; ++j) { l.v[j] = __shfl_up(c.v[j], nvec, 64); r.v[j] = __shfl_down(c.v[j], nvec, 64); }
+      if (first_col) l = term(hc, xo[0], mh);
+      if (last_col) r = term(hc, xo[2], mh);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s.v[j] += g.v[j] * (gain * (mk[d] * mh));
-      } else {
-        const F8 yo = Feat<T>::load(y + off);
+      for (int j = 0; j < 8; ++j) s.v[j] = (mk[0] != 0.f ? l.v[j] : 0.f) + c.v[j] + (mk[2] != 0.f ? r.v[j] : 0.f);
+    } else {
+      l = term(hc, xo[0], mk[0] * mh); r = term(hc, xo[2], mk[2] * mh);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s.v[j] += g.v[j] * (act_grad_from_out(yo.v[j], act, gain) * (mk[d] * mh));
-      }
+      for (int j = 0; j < 8; ++j) s.v[j] = l.v[j] + c.v[j] + r.v[j];
     }
     return s;
   };
@@ -173,7 +195,7 @@ __global__ void box3_act_bwd_kernel(const T* __restrict__ gy, const T* __restric
     F8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o.v[j] = (r0.v[j] + r1.v[j] + r2.v[j]) * (1.f / 9.f);
-    Feat<T>::store(gx + base + ((size_t)hh * W + w) * C, o);
+    if (live) Feat<T>::store(gx + base + ((size_t)hh * W + w) * C, o);
     r0 = r1; r1 = r2;
   }
 }

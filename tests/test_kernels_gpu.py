@@ -421,7 +421,8 @@ def test_mfma_layout_asymmetric(H):
 
 # ------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [(2, 8, 8, 16), (3, 12, 20, 40), (1, 32, 32, 128)])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 16), (3, 12, 20, 40), (1, 32, 32, 128),
+                                   (1, 20, 12, 256), (1, 10, 6, 512), (1, 6, 8, 16)])   # 2 columns per wave; 1 (no lane sharing); a partial wave
 def test_stencils(H, dtype, shape):
     x = feat(shape, dtype, 31)
     for act, gain in ((0, 1.0), (1, 1.4), (2, 1.0)):
