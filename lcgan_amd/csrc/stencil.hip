@@ -69,7 +69,7 @@ __global__ void box3_act_kernel(const T* __restrict__ x, T* __restrict__ y, int 
 // pre-activation (DiscriminatorBlock conv0 -> blur, custom_layers.py:204-206): one pass instead of a box-filter pass plus an
 // activation-backward pass.  Same sliding window as box3_act_kernel, over taller strips (BOXB_RH rows) so that the per-channel
 // bias reduction ends in few global atomics (LDS float atomics inside the block).
-// Strip height: 32 rows when that still leaves >= 256K threads, else 8 (small local batches are latency-, not atomics-bound).
+// Strip height: see lcgan_box3_actbwd_reduce (taller strips = fewer same-address atomics, until too few threads are left).
 template <typename T>
 __global__ void box3_actbwd_reduce_kernel(const T* __restrict__ gy, const T* __restrict__ y, T* __restrict__ gz,
                                           float* __restrict__ gbias, int B, int H, int W, int C, int Clog, int act, float gain,
@@ -1103,7 +1103,9 @@ int lcgan_box3_actbwd_reduce(const void* gy, const void* y, void* gz, float* gbi
   if ((C & 7) || Clog > C) return LCGAN_EINVAL;
   const long long n = (long long)B * H * W * (C / 8);
   ProfScope p(KID_ACT_BWD, 0, (double)n * 8 * 3 * (dtype == DT_BF16 ? 2 : 4), s);
-  const int rh = n / 32 >= (1 << 18) ? 32 : 8;
+  // strip height: the tallest that still leaves ~128K (32 rows) / ~64K (16 rows) threads (scripts/ab_boxb.py: 77 -> 48 us at
+  // 4 x 256 x 256 x 128, 43 -> 35 us at 32 x 32 x 32 x 512; below that 8 rows win)
+  const int rh = n / 32 >= (1 << 17) ? 32 : (n / 16 >= (1 << 16) ? 16 : 8);
   const long long nthr = (long long)B * ((H + rh - 1) / rh) * W * (C / 8);
   DISPATCH_T(dtype, hipLaunchKernelGGL(box3_actbwd_reduce_kernel<T>, grid1d(nthr), dim3(TPB), C * sizeof(float), s, (const T*)gy,
                                        (const T*)y, (T*)gz, gbias, B, H, W, C, Clog, act, gain, rh));
