@@ -219,7 +219,10 @@ def main():
             K.prof_dump(a.launch_table)
             K.prof_enable(False)
     elif world > 1 and not a.no_roofline:
-        loader.train_iteration(w, args, epoch_of(a.warmup + a.steps))       # keep the ranks in lock-step
+        # keep the ranks in lock-step: every iteration rank 0 runs above carries gradient all-reduces that need their peers
+        loader.train_iteration(w, args, epoch_of(a.warmup + a.steps))
+        if a.launch_table:
+            loader.train_iteration(w, args, epoch_of(a.warmup + a.steps + 1))
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.res)
     if world > 1:

@@ -196,8 +196,11 @@ int lcgan_conv_bwd_data_fp8(const void* g, const void* wpT, const void* wscT, vo
  * normalisation :81-86), which the reference runs on the host in DataLoader workers (worker.py:37,62-69).
  * src: f32 [B][3][R][R] in [-1,1] (the resized image); params: f32 [B][32], one row of host-drawn randomness per sample
  * (layout: lcgan_amd/csrc/views.hip); outputs f32 [B][3][R][R]: the flipped image, its perspective view (bilinear, black
- * border) and its appearance view (one black rectangle, or brightness / contrast / saturation / hue jitter). */
-int lcgan_make_views(const float* src, const float* params, float* out_img, float* out_geo, float* out_app,
+ * border) and its appearance view (one black rectangle, or brightness / contrast / saturation / hue jitter).
+ * params slot 23 < 0: the contrast pivot is computed on the device (mean luma after the jitter ops that precede the contrast op,
+ * accumulated into slot 24, which must be 0 on entry and is WRITTEN); slot 25 != 0: the two augmented views are rounded to the
+ * uint8 grid k/255 (custom_dataset.py:76-79: Image.fromarray + ToTensor of albumentations' uint8 result). */
+int lcgan_make_views(const float* src, float* params, float* out_img, float* out_geo, float* out_app,
                      int B, int R, void* stream);
 
 #ifdef __cplusplus

@@ -9,8 +9,12 @@
 // params[b][32]:  0 flip | 1..9 Hinv (row-major: output pixel (x, y, 1) -> source pixel of the FLIPPED image) | 10 appearance
 // mode (0 = dropout, 1 = colour jitter) | 11..14 hole x0, y0, x1, y1 (pixels, half-open) | 15 brightness | 16 contrast |
 // 17 saturation | 18 hue shift (fraction of a turn) | 19..22 order of the four jitter ops (0 brightness, 1 contrast, 2 saturation,
-// 3 hue) | 23 contrast pivot (mean luma of the source image in [0, 1])
+// 3 hue) | 23 contrast pivot in [0, 1], or < 0: computed HERE as the mean luma of the image after the jitter ops that precede the
+// contrast op (what albumentations' adjust_contrast_torchvision takes: the mean of its input image), accumulated into slot 24 by
+// views_pivot_kernel | 24 pivot accumulator (zero on entry) | 25 != 0: the geometry / appearance views are rounded to the uint8
+// grid k / 255 (custom_dataset.py:76-79: albumentations returns uint8 arrays, Image.fromarray + ToTensor turn them back into k / 255)
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -40,6 +44,39 @@ __device__ __forceinline__ void hue_shift(float& r, float& g, float& b, float sh
     case 4: r = t; g = p; b = v; break;
     default: r = v; g = p; b = q; break;
   }
+}
+
+// one colour-jitter op on a pixel in [0, 1] (m: the contrast pivot)
+__device__ __forceinline__ void jitter_op(int op, const float* P, float m, float& r, float& g, float& bl) {
+  if (op == 0) { r = clamp01(r * P[15]); g = clamp01(g * P[15]); bl = clamp01(bl * P[15]); }
+  else if (op == 1) { const float f = P[16]; r = clamp01((r - m) * f + m); g = clamp01((g - m) * f + m); bl = clamp01((bl - m) * f + m); }
+  else if (op == 2) { const float gr = 0.299f * r + 0.587f * g + 0.114f * bl, f = P[17]; r = clamp01(gr + (r - gr) * f); g = clamp01(gr + (g - gr) * f); bl = clamp01(gr + (bl - gr) * f); }
+  else { hue_shift(r, g, bl, P[18]); }
+}
+
+// params[b][24] += sum over pixels of the luma of (image after the jitter ops in front of the contrast op); only for samples in
+// colour-jitter mode whose pivot slot asks for it (params[b][23] < 0)
+__global__ __launch_bounds__(256) void views_pivot_kernel(const float* __restrict__ src, float* __restrict__ params, int R) {
+  __shared__ float red[4];
+  const int b = blockIdx.y;
+  float* P = params + (size_t)b * 32;
+  if (P[10] == 0.f || P[23] >= 0.f) return;                    // uniform per block
+  const size_t plane = (size_t)R * R;
+  const float* s0 = src + (size_t)b * 3 * plane;
+  float acc = 0.f;
+  for (size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x; pix < plane; pix += (size_t)gridDim.x * 256) {
+    float r = (s0[pix] + 1.f) * 0.5f, g = (s0[plane + pix] + 1.f) * 0.5f, bl = (s0[2 * plane + pix] + 1.f) * 0.5f;
+    for (int k = 0; k < 4; ++k) {
+      const int op = (int)P[19 + k];
+      if (op == 1) break;
+      jitter_op(op, P, 0.f, r, g, bl);
+    }
+    acc += 0.299f * r + 0.587f * g + 0.114f * bl;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(P + 24, red[0] + red[1] + red[2] + red[3]);
 }
 
 __global__ __launch_bounds__(256) void views_kernel(const float* __restrict__ src, const float* __restrict__ params,
@@ -78,7 +115,8 @@ __global__ __launch_bounds__(256) void views_kernel(const float* __restrict__ sr
     for (int c = 0; c < 3; ++c) {
       const float v = (1.f - ay) * ((1.f - ax) * fetch(c, y0, x0) + ax * fetch(c, y0, x0 + 1)) +
                       ay * ((1.f - ax) * fetch(c, y0 + 1, x0) + ax * fetch(c, y0 + 1, x0 + 1));
-      out_geo[o + c * plane] = fminf(fmaxf(v * 2.f - 1.f, -1.f), 1.f);
+      const float vq = P[25] != 0.f ? rintf(clamp01(v) * 255.f) * (1.f / 255.f) : v;
+      out_geo[o + c * plane] = fminf(fmaxf(vq * 2.f - 1.f, -1.f), 1.f);
     }
   }
   // ---- appearance view: one black rectangle, or colour jitter --------------------------------------------------------
@@ -87,26 +125,24 @@ __global__ __launch_bounds__(256) void views_kernel(const float* __restrict__ sr
     if (P[10] == 0.f) {
       if (x >= (int)P[11] && x < (int)P[13] && y >= (int)P[12] && y < (int)P[14]) { r = 0.f; g = 0.f; bl = 0.f; }
     } else {
+      const float m = P[23] >= 0.f ? P[23] : P[24] / (float)((size_t)R * R);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int op = (int)P[19 + k];
-        if (op == 0) { r = clamp01(r * P[15]); g = clamp01(g * P[15]); bl = clamp01(bl * P[15]); }
-        else if (op == 1) { const float m = P[23], f = P[16]; r = clamp01((r - m) * f + m); g = clamp01((g - m) * f + m); bl = clamp01((bl - m) * f + m); }
-        else if (op == 2) { const float gr = 0.299f * r + 0.587f * g + 0.114f * bl, f = P[17]; r = clamp01(gr + (r - gr) * f); g = clamp01(gr + (g - gr) * f); bl = clamp01(gr + (bl - gr) * f); }
-        else { hue_shift(r, g, bl, P[18]); }
-      }
+      for (int k = 0; k < 4; ++k) jitter_op((int)P[19 + k], P, m, r, g, bl);
     }
+    if (P[25] != 0.f) { r = rintf(r * 255.f) * (1.f / 255.f); g = rintf(g * 255.f) * (1.f / 255.f); bl = rintf(bl * 255.f) * (1.f / 255.f); }
     out_app[o] = r * 2.f - 1.f; out_app[o + plane] = g * 2.f - 1.f; out_app[o + 2 * plane] = bl * 2.f - 1.f;
   }
 }
 
 }  // namespace
 
-extern "C" int lcgan_make_views(const float* src, const float* params, float* out_img, float* out_geo, float* out_app,
+// params: [B][32] floats (layout above); slot 24 of every row is WRITTEN (pivot accumulator), everything else is read only
+extern "C" int lcgan_make_views(const float* src, float* params, float* out_img, float* out_geo, float* out_app,
                                 int B, int R, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (B <= 0 || R <= 0 || (long long)B * 3 * R * R >= (1ll << 40)) return LCGAN_EINVAL;
-  ProfScope p(KID_LAYOUT, 0, (double)B * 3 * R * R * 4 * 4, s);
+  ProfScope p(KID_LAYOUT, 0, (double)B * 3 * R * R * 4 * 5, s);
+  hipLaunchKernelGGL(views_pivot_kernel, dim3(std::min(cdiv((long long)R * R, 256), 64), B), dim3(256), 0, s, src, params, R);
   hipLaunchKernelGGL(views_kernel, dim3(cdiv((long long)R * R, 256), B), dim3(256), 0, s, src, params, out_img, out_geo, out_app, B, R);
   return launch_status();
 }

@@ -1,8 +1,8 @@
 """Training data for the step: the reference's Dataset_ + DistributedSampler + DataLoader (custom_dataset.py:10-100, worker.py:44-73)
 re-cut for the MI355X: the host only decodes and resizes (PIL, LANCZOS -- custom_dataset.py:16, 64-66) and draws the per-sample
 randomness; the three views (h-flip :68, perspective :27-33, dropout / colour jitter :35-49, normalisation :81-86) are produced on the
-device by ONE kernel (`lcgan_make_views`, csrc/views.hip) from a pinned, asynchronously copied batch.  At >= 300 images/s per GPU the
-reference's 4 PIL + albumentations workers per GPU (worker.py:37) could not keep up; decode + resize of cached 256^2 JPEGs can.
+device by ONE call (`lcgan_make_views`, csrc/views.hip) from a pinned, asynchronously copied batch; decode runs in a thread pool one
+batch ahead of the training thread (`FolderTriples`).  Measured decode throughput: scripts/bench_data.py (recorded in DESIGN.md).
 
 The random draws restate albumentations 1.x (`A.Perspective(scale=(0.05, 0.1), keep_size=True, fit_output=True|False)`,
 `A.CoarseDropout(max_holes=1, 0.3..0.5)`, `A.ColorJitter(0.2, 0.2, 0.2, 0.2)`: custom_dataset.py:19-24) from its published algorithm;
@@ -71,7 +71,11 @@ def perspective_inverse(rng: np.random.Generator, size: int, fit_output: bool, s
     return Hinv / Hinv[2, 2]
 
 
-def sample_view_params(rng: np.random.Generator, size: int, mean_luma: float = 0.5) -> np.ndarray:
+def sample_view_params(rng: np.random.Generator, size: int, mean_luma: float = -1.0, quantize: bool = True) -> np.ndarray:
+    """One row of per-sample randomness (layout: csrc/views.hip).  mean_luma < 0 (default): the contrast pivot is computed on the
+    device from the image as it reaches the contrast op (after the jitter ops drawn in front of it), which is what ColorJitter's
+    contrast adjustment uses; a value in [0, 1] forces the pivot (tests).  quantize: round the two augmented views to the uint8
+    grid, as the reference's `Image.fromarray(...)` -> `ToTensor()` round trip does (custom_dataset.py:76-79)."""
     p = np.zeros(32, dtype=np.float32)
     p[0] = float(rng.random() < 0.5)                                                        # RandomHorizontalFlip, custom_dataset.py:68
     p[1:10] = perspective_inverse(rng, size, fit_output=bool(rng.random() < 0.5)).reshape(-1)   # :27-33
@@ -85,6 +89,7 @@ def sample_view_params(rng: np.random.Generator, size: int, mean_luma: float = 0
         p[18] = rng.uniform(-0.2, 0.2)
         p[19:23] = rng.permutation(4)
         p[23] = mean_luma
+    p[25] = float(quantize)
     return p
 
 
@@ -102,21 +107,31 @@ def list_image_folder(root: str) -> List[str]:
 
 class FolderTriples:
     """Endless (image, geometry_change, appearance_change) batches from `<data_dir>/train/<class>/*`: per-rank shards of an
-    epoch permutation (DistributedSampler(shuffle=True, drop_last=True), worker.py:56-60), decode + LANCZOS resize on the host, pinned
-    H2D copy on a side stream, views on the device."""
+    epoch permutation (DistributedSampler(shuffle=True, drop_last=True), worker.py:56-60); decode + LANCZOS resize + the per-sample
+    random draws run in a small thread pool ONE BATCH AHEAD of the training thread (the reference: 4 persistent DataLoader workers
+    per GPU, worker.py:37,62-69; PIL and numpy release the GIL), into one of two pinned buffers; the training thread only waits for
+    the finished batch, issues the H2D copy on a side stream and launches the view kernel.
+    Randomness is per sample: `default_rng([seed, rank, batch counter, slot])`, so the result does not depend on thread timing."""
 
-    def __init__(self, data_dir: str, res: int, batch: int, device, rank: int = 0, world: int = 1, train: bool = True, seed: int = 0):
+    def __init__(self, data_dir: str, res: int, batch: int, device, rank: int = 0, world: int = 1, train: bool = True, seed: int = 0,
+                 workers: int = 4):
+        from concurrent.futures import ThreadPoolExecutor
         from . import kernels as KM
         self.K = KM.K
         self.files = list_image_folder(os.path.join(data_dir, "train"))
         self.res, self.batch, self.device, self.rank, self.world, self.train = res, batch, torch.device(device), rank, world, train
         self.epoch, self.pos, self.order = 0, 0, None
-        self.rng = np.random.default_rng(seed * 1000003 + rank)
-        self.seed = seed
-        self.host = torch.empty((batch, 3, res, res), dtype=torch.float32).pin_memory() if self.device.type == "cuda" else \
-            torch.empty((batch, 3, res, res), dtype=torch.float32)
-        self.copy_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
-        self._copied = None                       # event: the previous batch has left the pinned buffer
+        self.seed, self.counter = seed, 0
+        cuda = self.device.type == "cuda"
+        self.hosts = [torch.empty((batch, 3, res, res), dtype=torch.float32) for _ in range(2)]
+        self.phosts = [torch.zeros((batch, 32), dtype=torch.float32) for _ in range(2)]
+        if cuda:
+            self.hosts = [t.pin_memory() for t in self.hosts]
+            self.phosts = [t.pin_memory() for t in self.phosts]
+        self.copy_stream = torch.cuda.Stream(device=self.device) if cuda else None
+        self._copied = [None, None]               # per buffer: event "the H2D copy out of this buffer has finished"
+        self.pool = ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="lcgan-data")
+        self._inflight = None                     # (buffer index, futures) of the batch being decoded
 
     def _next_indices(self):
         per_rank = len(self.files) // self.world                      # drop_last
@@ -139,29 +154,47 @@ class FolderTriples:
                 im = im.resize((self.res, self.res), Image.LANCZOS)
             return np.array(im, dtype=np.uint8)
 
-    def next(self):
+    def _load_one(self, buf: int, slot: int, path: str, counter: int) -> None:
+        a = self._decode(path)
+        self.hosts[buf][slot] = torch.from_numpy(a).permute(2, 0, 1).float().mul_(2.0 / 255.0).sub_(1.0)    # ToTensor, *2-1 (:70, :81)
+        rng = np.random.default_rng([self.seed, self.rank, counter, slot])
+        p = sample_view_params(rng, self.res)
+        if not self.train:
+            p[0] = 0.0
+        self.phosts[buf][slot] = torch.from_numpy(p)
+
+    def _submit(self) -> None:
+        buf = self.counter & 1
+        if self._copied[buf] is not None:         # the copy that last read this pinned buffer (two batches ago) must be done
+            self._copied[buf].synchronize()
+            self._copied[buf] = None
         idx = self._next_indices()
-        if self._copied is not None:
-            self._copied.synchronize()
-        params = np.zeros((self.batch, 32), dtype=np.float32)
-        for i, j in enumerate(idx):
-            a = self._decode(self.files[int(j)])
-            self.host[i] = torch.from_numpy(a).permute(2, 0, 1).float().mul_(2.0 / 255.0).sub_(1.0)    # ToTensor, *2-1 (:70, :81)
-            luma = float((a.reshape(-1, 3).astype(np.float64) @ np.array([0.299, 0.587, 0.114])).mean() / 255.0)
-            params[i] = sample_view_params(self.rng, self.res, luma)
-            if not self.train:
-                params[i, 0] = 0.0
+        futs = [self.pool.submit(self._load_one, buf, i, self.files[int(j)], self.counter) for i, j in enumerate(idx)]
+        self._inflight = (buf, futs)
+        self.counter += 1
+
+    def next(self):
+        if self._inflight is None:
+            self._submit()
+        buf, futs = self._inflight
+        for f in futs:
+            f.result()                            # (re-raises a worker's exception here)
+        host, phost = self.hosts[buf], self.phosts[buf]
         if self.copy_stream is not None:
             with torch.cuda.stream(self.copy_stream):
-                src = self.host.to(self.device, non_blocking=True)
-                par = torch.from_numpy(params).pin_memory().to(self.device, non_blocking=True)
-                self._copied = torch.cuda.Event()
-                self._copied.record(self.copy_stream)
+                src = host.to(self.device, non_blocking=True)
+                par = phost.to(self.device, non_blocking=True)
+                self._copied[buf] = torch.cuda.Event()
+                self._copied[buf].record(self.copy_stream)
             torch.cuda.current_stream().wait_stream(self.copy_stream)
             src.record_stream(torch.cuda.current_stream()); par.record_stream(torch.cuda.current_stream())
         else:
-            src, par = self.host.clone(), torch.from_numpy(params)
+            src, par = host.clone(), phost.clone()
+        self._submit()                            # the next batch decodes while this one trains
         return self.K.make_views(src, par)
+
+    def close(self) -> None:
+        self.pool.shutdown(wait=False, cancel_futures=True)
 
 
 def save_image_column(images: torch.Tensor, path: str) -> None:

@@ -90,7 +90,10 @@ class HipKernels:
     def _stream():
         # raw handle of torch's current stream on the current device; torch.cuda.current_stream() builds a Stream object through
         # several Python layers (9 us per call, ~1000 calls per iteration: 10 % of a batch-4 step, which is launch-bound)
-        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+        try:
+            return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+        except AttributeError:                                # (private torch entry points: fall back to the public, slower path)
+            return torch.cuda.current_stream().cuda_stream
 
     def _call(self, name, *args):
         _lib.check(getattr(self.lib, name)(*args), name)

@@ -24,9 +24,11 @@ from .optim import Adam, DataParallel
 class LazyLoss:
     """What train_generator / train_discriminator return: a handle on the loss scalar whose value is fetched from the device ON
     DEMAND.  The reference calls `.item()` right after the optimiser step (worker.py:177, 214), which drains the GPU queue twice
-    per iteration; here the scalar is copied asynchronously into pinned memory and `float()` / `.item()` / formatting / arithmetic
-    wait for that copy only when somebody looks (log lines every print_interval).  Deliberately NOT a float subclass: C-level
-    consumers (math.isnan, json, numpy) go through __float__ and get the real value, never a placeholder."""
+    per iteration; here the scalar is copied asynchronously into pinned memory and `float()` / `.item()` / formatting / arithmetic /
+    comparisons / `round()` / `int()` / `bool()` wait for that copy only when somebody looks (log lines every print_interval).
+    Deliberately NOT a float subclass (a subclass would have to carry a placeholder value that C-level consumers read without calling
+    back): consumers that convert through `__float__` (math.isnan, numpy, `"%f" %`, f-strings) get the real value; `json.dumps` only
+    serialises real floats, so pass `float(loss)` there."""
     __slots__ = ("_host", "_event")
 
     def __init__(self, tensor):
@@ -46,6 +48,15 @@ class LazyLoss:
 
     item = __float__
 
+    def __int__(self):
+        return int(float(self))
+
+    def __bool__(self):
+        return bool(float(self))
+
+    def __round__(self, ndigits=None):
+        return round(float(self), ndigits)
+
     def __format__(self, spec):
         return format(float(self), spec)
 
@@ -61,8 +72,14 @@ class LazyLoss:
 
 
 def _delegate(name):
+    import numbers
     op = getattr(float, name)
-    return lambda self, *o: op(float(self), *(float(v) for v in o))
+
+    def f(self, *o):
+        if not all(isinstance(v, (numbers.Real, LazyLoss)) for v in o):
+            return NotImplemented                   # e.g. `loss == None`, `loss < "x"`: let Python apply its own fallback rules
+        return op(float(self), *(float(v) for v in o))
+    return f
 
 
 for _n in ("eq", "ne", "lt", "le", "gt", "ge", "add", "radd", "sub", "rsub", "mul", "rmul", "truediv", "rtruediv", "neg", "abs"):

@@ -458,6 +458,9 @@ class EmulatedKernels:
                 v = img[:, yy.clamp(0, R - 1), xx.clamp(0, R - 1)]
                 return torch.where(ok.unsqueeze(0), v, torch.zeros_like(v))
             g = (1 - ay) * ((1 - ax) * fetch(y0, x0) + ax * fetch(y0, x0 + 1)) + ay * ((1 - ax) * fetch(y0 + 1, x0) + ax * fetch(y0 + 1, x0 + 1))
+            quant = P[25] != 0                                      # uint8 round trip of the augmented views (custom_dataset.py:76-79)
+            if quant:
+                g = torch.round(g.clamp(0, 1) * 255) / 255
             outs[1][b] = (g * 2 - 1).clamp(-1, 1)
             r, gch, bl = img[0].clone(), img[1].clone(), img[2].clone()
             if P[10] == 0:
@@ -469,13 +472,18 @@ class EmulatedKernels:
                     if op == 0:
                         r, gch, bl = ((c * P[15]).clamp(0, 1) for c in (r, gch, bl))
                     elif op == 1:
-                        r, gch, bl = (((c - P[23]) * P[16] + P[23]).clamp(0, 1) for c in (r, gch, bl))
+                        # pivot < 0: the mean luma of the image as it reaches the contrast op (views_pivot_kernel)
+                        m = P[23] if P[23] >= 0 else (0.299 * r + 0.587 * gch + 0.114 * bl).mean()
+                        r, gch, bl = (((c - m) * P[16] + m).clamp(0, 1) for c in (r, gch, bl))
                     elif op == 2:
                         gr = 0.299 * r + 0.587 * gch + 0.114 * bl
                         r, gch, bl = ((gr + (c - gr) * P[17]).clamp(0, 1) for c in (r, gch, bl))
                     else:
                         r, gch, bl = _hue_shift(r, gch, bl, float(P[18]))
-            outs[2][b] = torch.stack([r, gch, bl]) * 2 - 1
+            app = torch.stack([r, gch, bl])
+            if quant:
+                app = torch.round(app * 255) / 255
+            outs[2][b] = app * 2 - 1
         return tuple(outs)
 
     # ---- multi-tensor ---------------------------------------------------------------------------------------------------

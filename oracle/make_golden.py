@@ -203,6 +203,54 @@ def layer_fixtures(CL, LOSS, EMA):
     print("layers.npz", len(d), "arrays")
 
 
+def narrow_fixtures(CL):
+    """Backward fixtures of the NARROW octaves (C = 32 / 64: the high-resolution layers of the 512 x 512 / 1024 x 1024 networks, cnn.py:17,54):
+    a DiscriminatorBlock(32, 64) at 64 x 64 with first-order gradients and the R1-style double backward (custom_layers.py:185-217,
+    loss.py:18-34), and a SynthesisBlock(64 -> 32) at 32 x 32 -> 64 x 64 with every gradient (custom_layers.py:114-166).  Big tensors are
+    stored as strided slices / the kink-robust statistics of oracle/weights.py:grad_stats."""
+    d = {}
+
+    def stat(prefix, t, key):
+        st = grad_stats(t, key)
+        d[prefix + "/abssum"], d[prefix + "/l2"], d[prefix + "/proj"] = np.float64(st["abssum"]), np.float64(st["l2"]), st["proj"]
+
+    B, C, R = 2, 32, 64
+    m = CL.DiscriminatorBlock(C, 2 * C, skip=True)
+    load(m, module_state(m, 141))
+    x = seeded_tensor((B, C, R, R), 142).requires_grad_(True)
+    y = m(x)
+    go = seeded_tensor(tuple(y.shape), 143)
+    gx = torch.autograd.grad((y * go).sum(), x, create_graph=True)[0]
+    params = dict(m.named_parameters())
+    g2 = torch.autograd.grad(gx.square().sum(), list(params.values()), retain_graph=True, allow_unused=True)
+    g1 = torch.autograd.grad((y * go).sum(), list(params.values()), allow_unused=True)
+    d["dblock/B"], d["dblock/C"], d["dblock/R"], d["dblock/g2_scale"] = np.int64(B), np.int64(C), np.int64(R), np.float64(1.0)
+    d["dblock/y_slice"] = y.detach()[:, :, ::4, ::4].numpy().copy()
+    stat("dblock/gx", gx.detach(), "dblock/gx")
+    for (k, p), a, b in zip(params.items(), g1, g2):
+        stat(f"dblock/grad1/{k}", a, k)
+        stat(f"dblock/grad2/{k}", torch.zeros_like(p) if b is None else b, k)
+
+    B, Ci, Co, R = 2, 64, 32, 32
+    m = CL.SynthesisBlock(Ci, Co, 64, 512, 2 * R, 0.1)
+    load(m, module_state(m, 121))
+    x = seeded_tensor((B, Ci, R, R), 122).requires_grad_(True)
+    gl = seeded_tensor((B, 1, 64), 123).requires_grad_(True)
+    al = seeded_tensor((B, 2, 512), 124).requires_grad_(True)
+    y = m(x, gl, al)
+    go = seeded_tensor(tuple(y.shape), 125)
+    params = dict(m.named_parameters())
+    grads = torch.autograd.grad((y * go).sum(), [x, gl, al] + list(params.values()))
+    d["synblock/B"], d["synblock/Ci"], d["synblock/Co"], d["synblock/R"] = np.int64(B), np.int64(Ci), np.int64(Co), np.int64(R)
+    d["synblock/y_slice"] = y.detach()[:, :, ::4, ::4].numpy().copy()
+    stat("synblock/gx", grads[0], "synblock/gx")
+    d["synblock/ggl"], d["synblock/gal"] = grads[1].numpy(), grads[2].numpy()
+    for (k, _), g in zip(params.items(), grads[3:]):
+        stat(f"synblock/grad/{k}", g, k)
+    np.savez_compressed(os.path.join(OUT, "narrow.npz"), **d)
+    print("narrow.npz", len(d), "arrays")
+
+
 # ---------------------------------------------------------------------------------------------
 HP = dict(tau=0.05, l_aux=0.5, l_r1=10.0, l_s=1e-7)
 
@@ -376,13 +424,24 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     CNN, CL, LOSS, EMA = _import_reference()
     torch.set_num_threads(8)
-    layer_fixtures(CL, LOSS, EMA)
-    step_fixtures(CNN, LOSS, res=32, B=8)
-    forward_fixtures(CNN, res=256, B=1)
-    forward_fixtures(CNN, res=512, B=1, stride=32)
-    forward_fixtures(CNN, res=1024, B=1, stride=64)
-    freeze_fixtures(CNN, LOSS)
-    fid_fixture()
+    only = set(sys.argv[1:])                                     # e.g. `python -m oracle.make_golden narrow`: just that file
+
+    def want(name):
+        return not only or name in only
+    if want("layers"):
+        layer_fixtures(CL, LOSS, EMA)
+    if want("narrow"):
+        narrow_fixtures(CL)
+    if want("step"):
+        step_fixtures(CNN, LOSS, res=32, B=8)
+    if want("forward"):
+        forward_fixtures(CNN, res=256, B=1)
+        forward_fixtures(CNN, res=512, B=1, stride=32)
+        forward_fixtures(CNN, res=1024, B=1, stride=64)
+    if want("freeze"):
+        freeze_fixtures(CNN, LOSS)
+    if want("fid"):
+        fid_fixture()
 
 
 if __name__ == "__main__":

@@ -94,23 +94,59 @@ def test_save_image_column(tmp_path):
     assert np.array_equal(back, (x.permute(0, 2, 3, 1).reshape(24, 8, 3) * 255 + 0.5).clamp(0, 255).to(torch.uint8).numpy())
 
 
+def test_prefetching_loader_is_deterministic_and_overlapped(tmp_path):
+    """The thread-pool loader (one batch ahead, lcgan_amd/data.py) returns the same batches whatever the worker count, walks the
+    rank's shard in order, and has the next batch in flight when next() returns."""
+    _make_folder(str(tmp_path), n=24)
+    from oracle.hip_emulation import EmulatedKernels
+    from tests.helpers import install_backend
+    install_backend(EmulatedKernels())
+    try:
+        runs = []
+        for workers in (1, 4):
+            src = data.FolderTriples(str(tmp_path), 32, 4, "cpu", seed=9, workers=workers)
+            batches = [src.next() for _ in range(3)]
+            assert src._inflight is not None and len(src._inflight[1]) == 4        # batch 4 is already decoding
+            src.close()
+            runs.append(batches)
+        for a, b in zip(*runs):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
+        assert not torch.equal(runs[0][0][0], runs[0][1][0])
+        # the augmented views sit on the uint8 grid (custom_dataset.py:76-79), the plain image on the decoder's
+        for v in runs[0][0]:
+            k = (v + 1) * 0.5 * 255
+            assert float((k - k.round()).abs().max()) < 2e-3
+    finally:
+        install_backend(None)
+
+
 @pytest.mark.gpu
-def test_make_views_kernel_vs_emulation():
+@pytest.mark.parametrize("device_pivot,quant", [(False, False), (True, False), (True, True)])
+def test_make_views_kernel_vs_emulation(device_pivot, quant):
     from lcgan_amd import kernels as KM
     from oracle.hip_emulation import EmulatedKernels
     rng = np.random.default_rng(7)
     for R, B in ((64, 6), (256, 3)):
         src = torch.from_numpy(rng.random((B, 3, R, R), dtype=np.float32) * 2 - 1)
-        params = torch.from_numpy(np.stack([data.sample_view_params(rng, R, 0.5) for _ in range(B)]))
+        params = torch.from_numpy(np.stack([data.sample_view_params(rng, R, -1.0 if device_pivot else 0.5, quant) for _ in range(B)]))
         params[0, 10], params[1, 10] = 0.0, 1.0                              # both appearance modes in every batch
-        params[1, 15:19] = torch.tensor([1.1, 0.9, 1.15, 0.13]); params[1, 19:23] = torch.tensor([3.0, 1.0, 0.0, 2.0]); params[1, 23] = 0.5
+        params[1, 15:19] = torch.tensor([1.1, 0.9, 1.15, 0.13]); params[1, 19:23] = torch.tensor([3.0, 1.0, 0.0, 2.0])
+        params[1, 23] = -1.0 if device_pivot else 0.5                        # order hue, CONTRAST, brightness, saturation: the pivot follows the hue shift
+        params[2, 10] = 1.0
+        params[2, 15:19] = torch.tensor([0.85, 1.2, 0.8, -0.17]); params[2, 19:23] = torch.tensor([0.0, 2.0, 3.0, 1.0])
+        params[2, 23] = -1.0 if device_pivot else 0.45                       # contrast last: the pivot follows all three other ops
         params[0, 11:15] = torch.tensor([R // 4, R // 8, R // 4 + R // 3, R // 8 + R // 2], dtype=torch.float32)
-        hip = KM.K.make_views(src.cuda(), params.cuda())
-        emu = EmulatedKernels().make_views(src, params)
+        hip = KM.K.make_views(src.cuda(), params.clone().cuda())
+        emu = EmulatedKernels().make_views(src, params.clone())
         for name, h, e in zip(("image", "geometry", "appearance"), hip, emu):
             h = h.cpu()
             # bilinear taps whose source coordinate sits within rounding of an integer may pick the neighbouring texel pair
-            # (the weights then differ by ~1e-5 too): compare at 1e-4 on all but a handful of pixels, and in the mean
+            # (the weights then differ by ~1e-5 too), and with the uint8 rounding a value within ~1e-6 of a half step lands on the
+            # neighbouring level (2 / 255): compare at 2e-4 on all but a handful of pixels, and in the mean
             diff = (h - e).abs()
-            assert float((diff > 2e-4).float().mean()) < 1e-3, (name, R, float(diff.max()))
-            assert float(diff.mean()) < 1e-5, (name, R)
+            assert float((diff > 2e-4).float().mean()) < (3e-3 if quant else 1e-3), (name, R, float(diff.max()))
+            assert float(diff.mean()) < (3e-5 if quant else 1e-5), (name, R)
+            if quant and name != "image":
+                k = (h + 1) * 0.5 * 255
+                assert float((k - k.round()).abs().max()) < 2e-3

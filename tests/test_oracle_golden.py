@@ -311,3 +311,57 @@ def test_forward_full_resolution(res_):
         logit, ge, ae = O.discriminator_forward(DP, real, res, True)
         close(logit, Fw["logit"]), close(ge, Fw["geo_emb"]), close(ae, Fw["app_emb"])
         close(O.discriminator_forward(DP, img, res, False)[0], Fw["logit_fake"], what="logit_fake")
+
+
+# ---- narrow octaves (tests/golden/narrow.npz: C = 32 / 64 blocks at 64 x 64, captured from the reference) ----------------------------
+def _stat_close(N, prefix, t, key, tol=RTOL):
+    from oracle.weights import grad_stats
+    st = grad_stats(t, key)
+    l1, l2, proj = float(N[prefix + "/abssum"]), float(N[prefix + "/l2"]), N[prefix + "/proj"]
+    if l2 == 0.0:
+        assert float(t.abs().max()) == 0.0, prefix
+        return
+    err = max(abs(st["abssum"] - l1) / l1, abs(st["l2"] - l2) / l2, float(np.abs(st["proj"] - proj).max()) / l2)
+    assert err <= tol, f"{prefix}: {err:.3e}"
+
+
+def test_narrow_discriminator_block_double_backward():
+    N = np.load(os.path.join(GOLD, "narrow.npz"))
+    B, C, R = int(N["dblock/B"]), int(N["dblock/C"]), int(N["dblock/R"])
+    sh = {"conv0.weight.weight": (C, C, 3, 3), "conv0.bias": (C,), "conv1.weight.weight": (2 * C, C, 3, 3),
+          "conv1.bias": (2 * C,), "skip_layer.weight.weight": (2 * C, C, 1, 1)}
+    P = {k: v.requires_grad_(True) for k, v in _state(sh, 141, "b.").items()}
+    x = seeded_tensor((B, C, R, R), 142).requires_grad_(True)
+    y = O.discriminator_block(P, "b", x)
+    close(y[:, :, ::4, ::4], N["dblock/y_slice"], what="y")
+    go = seeded_tensor(tuple(y.shape), 143)
+    gx = torch.autograd.grad((y * go).sum(), x, create_graph=True)[0]
+    _stat_close(N, "dblock/gx", gx.detach(), "dblock/gx")
+    g2 = torch.autograd.grad(gx.square().sum(), list(P.values()), retain_graph=True, allow_unused=True)
+    g1 = torch.autograd.grad((y * go).sum(), list(P.values()), allow_unused=True)
+    for k, a, b in zip(P, g1, g2):
+        _stat_close(N, "dblock/grad1/" + k[2:], a, k[2:])
+        _stat_close(N, "dblock/grad2/" + k[2:], torch.zeros_like(P[k]) if b is None else b, k[2:])
+
+
+def test_narrow_synthesis_block():
+    N = np.load(os.path.join(GOLD, "narrow.npz"))
+    B, Ci, Co, R = int(N["synblock/B"]), int(N["synblock/Ci"]), int(N["synblock/Co"]), int(N["synblock/R"])
+    sh = {}
+    sh.update(_synth_shapes("modulated_conv0", Ci, Co, 512, 3))
+    sh.update(_synth_shapes("modulated_conv1", Co, Co, 512, 3))
+    sh["skip_layer.weight.weight"] = (Co, Ci, 1, 1)
+    sh.update(_synth_shapes("flow_layer", Ci, 2, 64, 3))
+    P = {k: v.requires_grad_(True) for k, v in _state(sh, 121, "b.").items()}
+    x = seeded_tensor((B, Ci, R, R), 122).requires_grad_(True)
+    gl = seeded_tensor((B, 1, 64), 123).requires_grad_(True)
+    al = seeded_tensor((B, 2, 512), 124).requires_grad_(True)
+    y = O.synthesis_block(P, "b", x, gl[:, 0], al[:, 0], al[:, 1], 0.1)
+    close(y[:, :, ::4, ::4], N["synblock/y_slice"], what="y")
+    go = seeded_tensor(tuple(y.shape), 125)
+    grads = torch.autograd.grad((y * go).sum(), [x, gl, al] + list(P.values()))
+    _stat_close(N, "synblock/gx", grads[0], "synblock/gx")
+    close(grads[1], N["synblock/ggl"], what="ggl")
+    close(grads[2], N["synblock/gal"], what="gal")
+    for k, g in zip(P, grads[3:]):
+        _stat_close(N, "synblock/grad/" + k[2:], g, k[2:])

@@ -254,13 +254,15 @@ def test_r1_iteration_64_vs_oracle(dtype, loss_tol, grad_l2):
     assert r1_rel <= (1e-3 if dtype == torch.float32 else 0.1 if operands == "fp8" else 1e-2), (r1, float(parts["r1"]))
 
 
-def test_full_size_properties_256():
-    """BASELINE config-2 shapes (256x256, bf16): size-independent properties of the hot path.
+@pytest.mark.parametrize("B", [4, 32])
+def test_full_size_properties_256(B):
+    """BASELINE config-2 shapes (256x256, bf16; B = 32 is config 2's REAL size: the 8 192-workgroup grids, the XCD tile order and the
+    537 MB tensors the benchmark runs; B = 4 is what one of 8 ranks runs): size-independent properties of the hot path.
     (1) repeatability of the R1 value; (2) linearity of the R1 gradient in the logit weight: scaling logit_mapper by a
     doubles d(sum logit)/d(image), so R1 quadruples; (3) a full iteration with Adam + EMA keeps everything finite and
     moves every used parameter."""
     from lcgan_amd import config, loader, loss
-    res, B = 256, 4
+    res = 256
     with config.feature_dtype_as(torch.bfloat16):
         w = seeded_worker(res, B, DEV)
         real = seeded_tensor((B, 3, res, res), 7, "uniform_pm1").to(DEV)
@@ -272,6 +274,7 @@ def test_full_size_properties_256():
             logit, _, _ = D(img, False)
             return float(loss.cal_r1_reg(logit, img))
         a = r1_of()
+        assert np.isfinite(a) and a > 0
         # repeatable up to the order of the fp32 atomics (split-K convs, linear data gradients): an ulp-level difference in an
         # fp32 partial sum can flip a bf16 rounding downstream (2^-9 relative on that element), hence a few 1e-3 on the total
         assert abs(a - r1_of()) <= 5e-3 * a
@@ -288,6 +291,58 @@ def test_full_size_properties_256():
         assert len(moved) == len(before)
         for v in list(w.generator.module.state_dict().values()) + list(w.discriminator.module.state_dict().values()):
             assert torch.isfinite(v).all()
+        # every discriminator parameter an odd iteration uses (all but the projection heads, cnn.py:38) moved too
+        record(f"bf16_full_size_256_B{B}", r1=a, r1_ratio=b / a, g_loss=float(gl), d_loss=float(dl))
+
+
+def test_checkpoint_round_trip_on_device(tmp_path):
+    """(f)2 on the HIP path (worker.py:219-253, loader.py:35-42): save -> mutate every weight -> load_model must bring back the exact
+    pre-save outputs -- i.e. `load_model` really invalidates the prepared (bf16, GEMM-layout) weight copies the kernels cache per
+    parameter, which raw-pointer writes and load_state_dict do not touch -- and a resumed training step equals an uninterrupted one
+    bit for bit (Adam moments and step counts travel in optim_state.ckpt)."""
+    from lcgan_amd import config, loader
+    res, B = 64, 4
+    run = tmp_path / "run"
+    os.makedirs(run / "model")
+    with config.feature_dtype_as(torch.bfloat16):
+        w = seeded_worker(res, B, DEV, model_name=str(run), save_dir="model")
+        FixedFeed(w, B, res, DEV)
+        for epoch in (0, 1):
+            loader.train_iteration(w, w.args, epoch)              # moves G, D, G_ema, both Adam states; fills the prepared-weight cache
+        z1, z2 = seeded_tensor((B, 64), 1).to(DEV), seeded_tensor((B, 64), 2).to(DEV)
+        real = seeded_tensor((B, 3, res, res), 3, "uniform_pm1").to(DEV)
+        with torch.no_grad():
+            img0, ema0 = w.generator(z1, z2, 0.7).clone(), w.generate(z1, z2, 0.7).clone()
+            d0 = [t.clone() for t in w.discriminator(real, True)]
+        w.save_model()
+        assert sorted(os.listdir(run / "model")) == ["disc_model.ckpt", "gen_ema_model.ckpt", "gen_model.ckpt", "optim_state.ckpt"]
+        with torch.no_grad():                                     # wreck every weight in place, run once so the caches hold the wrecked copies
+            for m in (w.generator, w.generator_ema, w.discriminator):
+                for p in m.parameters():
+                    p.mul_(1.5).add_(0.01)
+            assert not torch.equal(w.generator(z1, z2, 0.7), img0)
+            assert not torch.equal(w.discriminator(real, True)[0], d0[0])
+        w.load_model()
+        with torch.no_grad():
+            assert torch.equal(w.generator(z1, z2, 0.7), img0), "stale prepared weights after load_model (generator)"
+            assert torch.equal(w.generate(z1, z2, 0.7), ema0), "stale prepared weights after load_model (EMA generator)"
+            for a, b in zip(w.discriminator(real, True), d0):
+                assert torch.equal(a, b), "stale prepared weights after load_model (discriminator)"
+        # a fresh WORKER (different random init) resumed from the files continues exactly like the one that never stopped
+        torch.manual_seed(4)
+        from lcgan_amd import worker as worker_mod
+        w2 = worker_mod.WORKER(make_args(res, B, model_name=str(run), save_dir="model"), 0, 1, device=DEV)
+        w2.load_model()
+        assert w2.g_optimizer.steps == w.g_optimizer.steps and w2.d_optimizer.steps == w.d_optimizer.steps
+        FixedFeed(w, B, res, DEV), FixedFeed(w2, B, res, DEV)
+        la, lb = loader.train_iteration(w, w.args, 3), loader.train_iteration(w2, w2.args, 3)
+        # (bit-identical up to the order of fp32 atomics in split-K / weight-gradient partial sums: compare tightly, not bitwise)
+        assert abs(float(la[0]) - float(lb[0])) <= 1e-3 * abs(float(la[0])) and abs(float(la[1]) - float(lb[1])) <= 1e-3 * abs(float(la[1]))
+        worst = 0.0
+        for (k, va), (_, vb) in zip(w.discriminator.state_dict().items(), w2.discriminator.state_dict().items()):
+            worst = max(worst, float((va - vb).abs().max() / va.abs().max().clamp_min(1e-12)))
+        assert worst <= 2e-2, worst                               # Adam with beta1 = 0 steps by lr * sign-like g / |g|: an atomics-order flip moves an entry by ~lr
+        record("checkpoint_on_device", resumed_d_param_max_rel=worst)
 
 
 @pytest.mark.parametrize("res,B,freeze", [(512, 8, 4), (1024, 4, 5)])
