@@ -56,11 +56,15 @@ int lcgan_conv_wgrad_fused(const void* x, const void* g, float* gwp,
    epilogue of conv0's data gradient instead of a separate up-sample + add.
    xs / gs (both or neither; need post, no bias / act / residual): the style-gradient reduction of a modulated conv's backward
    (autograd of custom_layers.py:62-64) fused into its data-gradient launch: with u = the unscaled result, y = post[b,n] * u and
-   gs[b,n] += sum_pixels xs[b,p,n] * u[b,p,n]   (xs: [B,Hout,Wout,Cout] = the conv's forward input; gs: [B][Cout] f32, accumulated). */
+   gs[b,n] += sum_pixels xs[b,p,n] * u[b,p,n]   (xs: [B,Hout,Wout,Cout] = the conv's forward input; gs: [B][Cout] f32, accumulated).
+   pool_out (may be NULL; lcgan_conv_fwd only; needs even Hout / Wout): also writes avg_pool2d(y, 2) [B,Hout/2,Wout/2,Cout] -- what the
+   NEXT DiscriminatorBlock's skip branch reads (custom_layers.py:202) -- from the output tile while it is still on chip (the closing
+   1x1 + residual convolution of a block, custom_layers.py:203,209), or by the pooling kernel where the launch path has no such epilogue. */
 int lcgan_conv_fwd(const void* x, const void* wp, void* y,
                    int B, int Hin, int Win, int Cin, int Cout, int N, int k, int stride,
                    const float* pre, const float* post, const float* bias, float bias_scale,
-                   int act, float gain, const void* residual, int residual_half, const void* xs, float* gs, int dtype, void* stream);
+                   int act, float gain, const void* residual, int residual_half, const void* xs, float* gs, void* pool_out,
+                   int dtype, void* stream);
 /* adjoint of lcgan_conv_fwd w.r.t. x (weights from weight_prep(transpose=1)); stride 2 == the x2 transposed
  * convolution of ModulatedConv2d(up=2): output [B][Hg*stride][Wg*stride][Cout]. */
 int lcgan_conv_bwd_data(const void* g, const void* wpT, void* gx,
@@ -106,11 +110,23 @@ int lcgan_mbstd_bwd(const void* gy, const void* x, void* gx, int N, int G, int H
 int lcgan_mbstd_bwd2(const void* v, const void* gy, const void* x, void* ggy, void* gx2,
                      int N, int G, int HW, int C, int Cy, int dtype, void* stream);
 /* 1x1 convs touching the f32 NCHW image: fromRGB cnn.py:20-21, toRGB custom_layers.py:175,181; w f32 [Bw][3][C] */
+/* (lcgan_rgb_expand: pooled != NULL also writes avg_pool2d(y, 2) [B][HW/4][C], the first DiscriminatorBlock's skip input
+ * custom_layers.py:202, in the same pass; W = image width, used only then) */
 int lcgan_rgb_expand(const float* img, const float* w, const float* bias, float bias_scale, void* y,
-                     int B, int HW, int C, int Clog, int per_sample, int act, float gain, int dtype, void* stream);
+                     int B, int HW, int C, int Clog, int per_sample, int act, float gain, void* pooled, int W, int dtype, void* stream);
 int lcgan_rgb_reduce(const void* x, const float* w, const float* bias, float bias_scale, float* img,
                      int B, int HW, int C, int per_sample, int dtype, void* stream);
 int lcgan_rgb_wgrad(const float* img, const void* feat, float* gw, int B, int HW, int C, int per_sample, int dtype, void* stream);
+/* fused backward passes of the same two layers (autograd of cnn.py:20-21 and of custom_layers.py:177-182):
+ * lcgan_rgb_expand_bwd: gz = gy * act'(y) in registers -> gimg = sum_c gz w (written; may be NULL), gw += sum_p img gz (may be NULL),
+ *   gbias += sum gz (may be NULL): one pass instead of activation backward + rgb_reduce + rgb_wgrad;
+ * lcgan_rgb_reduce_bwd_act: image gradient -> the preceding conv's pre-activation gradient: gz = (sum_o gimg wm) * act'(y) (written),
+ *   gbias += sum gz, gdq[b,c] += sum_p gz (ypre - bias) (the demodulation statistic of ModulatedConv2d), gwm += sum_p gimg y. */
+int lcgan_rgb_expand_bwd(const void* gy, const void* y, const float* img, const float* w, float* gimg, float* gw, float* gbias,
+                         int B, int HW, int C, int Clog, int per_sample, int act, float gain, int dtype, void* stream);
+int lcgan_rgb_reduce_bwd_act(const float* gimg, const void* y, const float* wm, const float* bias, float bias_scale, void* gz,
+                             float* gbias, float* gdq, float* gwm, int B, int HW, int C, int Clog, int per_sample, int act, float gain,
+                             int dtype, void* stream);
 /* layout converts at the NCHW f32 boundary (const input cnn.py:106, flatten custom_layers.py:232 / cnn.py:39) */
 int lcgan_nchw_to_nhwc(const float* src, void* dst, int B, int HW, int C, int Clog, int bcast, int dtype, void* stream);
 int lcgan_nhwc_to_nchw(const void* src, float* dst, int B, int HW, int C, int Clog, int reduce, int dtype, void* stream);
@@ -165,7 +181,8 @@ int lcgan_multi_tensor(const void* descs, const int* chunk_tensor, const int* ch
  * kernel (0 off, 1 / 2 = taps per barrier); 11 the same record layout for convolutions with per-sample input scales; 12 LDS-DMA
  * weight-gradient kernel (0 off, 1, 2 = split for two workgroups per CU, 3 = also stride 2); 13 parity-plane stride-2 forward;
  * 14 KB of weights concurrent channel blocks of one tile may keep in an XCD's L2 (0 = one input pass per channel block);
- * 15 XCD-grouped weight-gradient workgroup order; 16 LDS-DMA staging of the generic implicit-GEMM kernel (2 = modulated low-resolution layers too, through one prescale pass).  DESIGN.md section 2 ("Switches") has the measurements behind the defaults. */
+ * 15 XCD-grouped weight-gradient workgroup order; 16 LDS-DMA staging of the generic implicit-GEMM kernel (2 = modulated low-resolution layers too, through one prescale pass);
+ * 17 MB of operands up to which a weight gradient with per-sample scales applies them by one elementwise pass and reduces the whole batch as one range (0 = never).  DESIGN.md section 2 ("Switches") has the measurements behind the defaults. */
 int lcgan_set_option(int option, int value);
 
 /* ---- per-launch HIP-event profiling (bench.py roofline) ---------------------------------------------------- */

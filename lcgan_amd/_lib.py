@@ -18,7 +18,7 @@ SIGNATURES = {
     "lcgan_conv_weight_prep": [P, I, I, I, F, I, P, I, P, P],
     "lcgan_conv_wgrad_unprep": [P, I, I, I, F, I, P, P, P, P],
     "lcgan_conv_weight_prep_group": [P, P, P, I, P, P, D, P],
-    "lcgan_conv_fwd": [P, P, P, I, I, I, I, I, I, I, I, P, P, P, F, I, F, P, I, P, P, I, P],
+    "lcgan_conv_fwd": [P, P, P, I, I, I, I, I, I, I, I, P, P, P, F, I, F, P, I, P, P, P, I, P],
     "lcgan_conv_bwd_data": [P, P, P, I, I, I, I, I, I, I, I, P, P, P, F, I, F, P, I, P, P, I, P],
     "lcgan_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P, I, P],
     "lcgan_conv_wgrad_fused": [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P, I, F, I, P, P, P, P],
@@ -37,9 +37,11 @@ SIGNATURES = {
     "lcgan_mbstd_fwd": [P, P, I, I, I, I, I, I, P],
     "lcgan_mbstd_bwd": [P, P, P, I, I, I, I, I, I, P],
     "lcgan_mbstd_bwd2": [P, P, P, P, P, I, I, I, I, I, I, P],
-    "lcgan_rgb_expand": [P, P, P, F, P, I, I, I, I, I, I, F, I, P],
+    "lcgan_rgb_expand": [P, P, P, F, P, I, I, I, I, I, I, F, P, I, I, P],
     "lcgan_rgb_reduce": [P, P, P, F, P, I, I, I, I, I, P],
     "lcgan_rgb_wgrad": [P, P, P, I, I, I, I, I, P],
+    "lcgan_rgb_expand_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, F, I, P],
+    "lcgan_rgb_reduce_bwd_act": [P, P, P, P, F, P, P, P, P, I, I, I, I, I, I, F, I, P],
     "lcgan_nchw_to_nhwc": [P, P, I, I, I, I, I, I, P],
     "lcgan_nhwc_to_nchw": [P, P, I, I, I, I, I, I, P],
     "lcgan_linear_fwd": [P, P, P, P, I, I, I, F, F, I, F, P],

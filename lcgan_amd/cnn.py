@@ -46,9 +46,15 @@ class Discriminator(torch.nn.Module):
 
     def forward(self, image, get_embedding_features=False):
         mods = list(self.shared_model)
-        h = mods[0].forward_rgb(image.float(), ACT_LRELU, 1.0)          # 1x1 conv + LeakyReLU fused (cnn.py:20-21)
-        for blk in mods[2:]:
-            h = blk(h)
+        blocks = mods[2:]
+        # every block's input arrives with its 2 x 2 average (the skip branch's input, custom_layers.py:202) already made by the kernel
+        # that produced it: fromRGB here, then each block's closing convolution
+        h, pooled = mods[0].forward_rgb(image.float(), ACT_LRELU, 1.0, pool=True)          # 1x1 conv + LeakyReLU fused (cnn.py:20-21)
+        for i, blk in enumerate(blocks):
+            if i + 1 < len(blocks):
+                h, pooled = blk(h, pooled, want_pool=True)
+            else:
+                h = blk(h, pooled)
         logit = self.logit_mapper(self.discriminator_epilogue(h))
         geometry_embedding = None
         appearance_embedding = None

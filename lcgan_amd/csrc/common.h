@@ -39,6 +39,7 @@ template <> struct Feat<float> {
   }
   static __device__ __forceinline__ float ld1(const float* p) { return *p; }
   static __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ float rnd(float v) { return v; }          // the value a stored element reads back as
 };
 template <> struct Feat<__bf16> {
   static __device__ __forceinline__ F8 load(const __bf16* p) {
@@ -55,6 +56,7 @@ template <> struct Feat<__bf16> {
   }
   static __device__ __forceinline__ float ld1(const __bf16* p) { return (float)*p; }
   static __device__ __forceinline__ void st1(__bf16* p, float v) { *p = (__bf16)v; }
+  static __device__ __forceinline__ float rnd(float v) { return (float)(__bf16)v; }
 };
 
 __device__ __forceinline__ F8 f8_zero() { F8 r;

@@ -25,9 +25,11 @@
 #include <cstdio>
 
 extern "C" int lcgan_scale_reduce(void* u, const void* x, const float* sc, float* gs, int B, int HW, int C, int dtype, void* stream);
+extern "C" int lcgan_avgpool2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
 
 namespace {
 
+bool g_pool_written = false;              // set by the launch path that wrote ConvArgs::pool_out in its epilogue (else lcgan_conv_fwd runs the pooling kernel)
 int g_use_halo = 1;                       // lcgan_set_option(0, ...): bf16 halo-tile fast path on/off (A/B testing)
 int g_use_splitk = 1;                     // lcgan_set_option(1, ...): split-K for small-M convolutions
 int g_mfma16 = 0;                         // lcgan_set_option(4, ...): halo kernel uses v_mfma_f32_16x16x32_bf16 (1) or 32x32x16 (0, default:
@@ -46,6 +48,8 @@ int g_halo_s2dma = 4;                     // lcgan_set_option(13, ...): stride-2
 int g_halo_nb_group_kb = 8192;               // lcgan_set_option(14, ...): KB of weights (all taps x 128 rows x Cin) that concurrent channel blocks of one tile may hold in an XCD's L2; 0 = channel blocks slowest (one pass over the input per block)
 int g_wgrad_xcd = 0;                      // lcgan_set_option(15, ...): row-segment wgrad workgroups of one split share an XCD (1-D grid)
 int g_igemm_dma = 2;                      // lcgan_set_option(16, ...): LDS-DMA staging in the generic implicit-GEMM kernel (bf16, no input scales, Cin % 32 == 0)
+int g_wgrad_prescale_mb = 180;            // lcgan_set_option(17, ...): weight gradients with per-sample operand scales whose two operands together are at most this many MB
+                                          // get the scales applied ONCE by an elementwise pass (bf16) and then run as ONE batch-wide reduction; 0 = never
 int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): experiments, bit mask (the wgrad3 no-atomics switch is gone: it sat in the epilogue);
                                           // halo kernel: 8 = linear tile order (the store / emit / main-loop skipping switches used for the
                                           // fixed-cost analysis in DESIGN.md were removed again: they sat in the hot epilogue)
@@ -68,6 +72,7 @@ struct ConvArgs {
   float bias_scale, gain; int act;
   const void* xs; float* gs;                 // fused style-gradient reduction: gs[b,n] += sum_pixels xs[b,p,n] * acc  (xs: [B,Hout,Wout,Cout]; y = post * acc)
   int res_half;                              // residual is [B,Hout/2,Wout/2,Cout]: add 0.25 * residual[oy/2][ox/2] (avg_pool2d adjoint)
+  void* pool_out;                            // optional by-product [B,Hout/2,Wout/2,Cout] = avg_pool2d(y, 2) (the next DiscriminatorBlock's skip input)
   int nsplit; float* ws;                     // split-K: blockIdx.z = phase * nsplit + split; raw fp32 partials are atomically added to ws [M_out pixels][Cout]
   TapTable taps[4];
 };
@@ -386,6 +391,7 @@ constexpr int HROW = 40;                      // bf16 per staged pixel row (32 c
 struct HaloArgs {
   const __bf16* x; const __bf16* w; __bf16* y;
   const float* pre; const float* post; const float* bias; const __bf16* residual; int res_half;
+  __bf16* pool_out;                          // see ConvArgs (written by the EPI == 1 epilogue)
   const __bf16* xs; float* gs;               // see ConvArgs
   int B, Hin, Win, Cin, Hout, Wout, Cout, Hm, Wm, N, Kpad, kc_per_tap;
   int out_mul, tiles_x, tiles_y;
@@ -1205,6 +1211,27 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
     const int oy = py * a.out_mul + (phase >> 1), ox = px * a.out_mul + (phase & 1);
     *(bf16x8*)(a.y + ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n) = *(const bf16x8*)(ot + row * OROW + vv * 8);
   }
+  if constexpr (EPI == 1) {
+    // by-product of a DiscriminatorBlock's closing 1x1 convolution (custom_layers.py:203,209): avg_pool2d(out, 2), which the NEXT
+    // block's skip branch reads (custom_layers.py:202), from the finished bf16 tile in LDS -- the same values, summation and
+    // rounding as the avgpool2 kernel that otherwise re-reads the whole output from HBM.  (launcher: even Hout / Wout, out_mul 1)
+    if (a.pool_out) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int idx = tid + k * 512;                             // 64 pooled pixels x 16 vectors
+        const int q = idx >> 4, vv = idx & 15;
+        const int qy = q >> 3, qx = q & 7;
+        const int py = ty * HT + 2 * qy, px = tx * HT + 2 * qx, n = n0 + vv * 8;
+        if (py >= a.Hm || px >= a.Wm || n >= a.Cout) continue;
+        const __bf16* r0 = ot + ((2 * qy) * 16 + 2 * qx) * OROW + vv * 8;
+        const bf16x8 t00 = *(const bf16x8*)r0, t01 = *(const bf16x8*)(r0 + OROW), t10 = *(const bf16x8*)(r0 + 16 * OROW), t11 = *(const bf16x8*)(r0 + 17 * OROW);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)(((((float)t00[j] + (float)t01[j]) + (float)t10[j]) + (float)t11[j]) * 0.25f);   // (the pooling kernel's order)
+        *(bf16x8*)(a.pool_out + ((size_t)(b * (a.Hout >> 1) + (py >> 1)) * (a.Wout >> 1) + (px >> 1)) * a.Cout + n) = o;
+      }
+    }
+  }
 }
 
 // =========================================================================================================
@@ -1503,7 +1530,7 @@ constexpr size_t HALO_EPI_SMEM = (size_t)256 * (BN + 8) * sizeof(__bf16) + 3 * B
 bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   if (c.Hm < HT || c.Wm < HT || c.act == ACT_TANH) return false;
   if ((long long)c.B * c.Hin * c.Win * c.Cin >= (1ll << 31) || (long long)c.B * c.Hout * c.Wout * c.Cout >= (1ll << 31)) return false;
-  if (in_mul == 1 && g_halo_narrow_min_wgs > 0 && try_launch_halo_narrow(c, nphase, s)) return true;
+  if (in_mul == 1 && g_halo_narrow_min_wgs > 0 && try_launch_halo_narrow(c, nphase, s)) return true;   // (writes no pooled by-product: g_pool_written stays false)
   HaloArgs a = {};
   a.x = (const __bf16*)c.x; a.w = c.w; a.y = (__bf16*)c.y; a.pre = c.pre; a.post = c.post; a.bias = c.bias;
   a.residual = (const __bf16*)c.residual; a.res_half = c.res_half; a.dbg = g_dbg_no_atomics;
@@ -1511,6 +1538,8 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   a.B = c.B; a.Hin = c.Hin; a.Win = c.Win; a.Cin = c.Cin; a.Hout = c.Hout; a.Wout = c.Wout; a.Cout = c.Cout;
   a.Hm = c.Hm; a.Wm = c.Wm; a.N = c.N; a.Kpad = c.Kpad; a.kc_per_tap = c.kc_per_tap; a.out_mul = c.out_mul;
   a.tiles_x = cdiv(c.Wm, HT); a.tiles_y = cdiv(c.Hm, HT);
+  // pooled by-product: the full-resolution-residual epilogue (EPI == 1) of this kernel writes it (every variant below shares that epilogue)
+  a.pool_out = (c.pool_out && c.residual && !c.res_half && !c.xs && nphase == 1 && c.out_mul == 1 && !((c.Hout | c.Wout) & 1)) ? (__bf16*)c.pool_out : nullptr;
   a.bias_scale = c.bias_scale; a.gain = c.gain; a.act = c.act;
   int max_halo = 0, max_halo_elems = 0;
   for (int p = 0; p < nphase; ++p) {
@@ -1531,6 +1560,7 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   const int halo_wgs = c.B * a.tiles_x * a.tiles_y * cdiv(c.Cout, BN) * nphase;
   if (g_use_splitk && halo_wgs < g_halo_min_wgs && c.taps[0].n * c.kc_per_tap >= 8) return false;
   a.halo_elems = max_halo_elems;
+  g_pool_written = a.pool_out != nullptr;                         // (no `return false` below this line)
   const int NBT = (in_mul == 2 && g_mfma16 != 1) ? 4 : 2;             // stride-2 forward stages the weight tiles of two taps per step
   const size_t smem = std::max(((size_t)a.halo_elems + NBT * TILE) * sizeof(__bf16) + (size_t)c.Kpad * sizeof(float),
                                HALO_EPI_SMEM);
@@ -2447,6 +2477,7 @@ __bf16* prescale_scratch(size_t bytes) {               // grow-only, per device;
 int dispatch_igemm(const ConvArgs& a_in, int nphase, int dtype, hipStream_t s) {
   ConvArgs a = a_in;
   a.nsplit = 1; a.ws = nullptr;
+  g_pool_written = false;
   if (dtype == DT_BF16 && g_use_halo && try_launch_halo(a, nphase, a.in_mul, s)) return launch_status();
   if (g_igemm_dma >= 2 && dtype == DT_BF16 && a.pre && a.Cin % 32 == 0 && a.Kpad == a.Cin && a.M >= 2048) {   // (below that the extra launch costs what the faster main loop gains: measured at local batch 4)
     const size_t elems = (size_t)a.B * a.Hin * a.Win * a.Cin;
@@ -2506,6 +2537,7 @@ int lcgan_set_option(int option, int value) {
   if (option == 14) { const int old = g_halo_nb_group_kb; g_halo_nb_group_kb = value; return old; }
   if (option == 15) { const int old = g_wgrad_xcd; g_wgrad_xcd = value; return old; }
   if (option == 16) { const int old = g_igemm_dma; g_igemm_dma = value; return old; }
+  if (option == 17) { const int old = g_wgrad_prescale_mb; g_wgrad_prescale_mb = value; return old; }
   return LCGAN_EINVAL;
 }
 
@@ -2563,12 +2595,14 @@ int lcgan_conv_wgrad_unprep(const float* gwp, int A, int Bc, int k, float scale,
 int lcgan_conv_fwd(const void* x, const void* wp, void* y,
                    int B, int Hin, int Win, int Cin, int Cout, int N, int k, int stride,
                    const float* pre, const float* post, const float* bias, float bias_scale,
-                   int act, float gain, const void* residual, int residual_half, const void* xs, float* gs, int dtype, void* stream) {
+                   int act, float gain, const void* residual, int residual_half, const void* xs, float* gs, void* pool_out,
+                   int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || (Cin & 7) || (Cout & 7) || N > Cout) return LCGAN_EINVAL;
   if (xs && (!gs || !post || residual || bias || act != ACT_NONE || gain != 1.f)) return LCGAN_EINVAL;
   ConvArgs a = {};
   a.xs = xs; a.gs = xs ? gs : nullptr;
+  a.pool_out = pool_out;
   a.x = x; a.w = (const __bf16*)wp; a.y = y;
   a.pre = pre; a.post = post; a.bias = bias; a.residual = residual; a.res_half = residual ? residual_half : 0;
   a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin;
@@ -2586,10 +2620,17 @@ int lcgan_conv_fwd(const void* x, const void* wp, void* y,
   t.n = k * k;
   for (int ky = 0; ky < k; ++ky)
     for (int kx = 0; kx < k; ++kx) { const int i = ky * k + kx; t.dy[i] = ky - pad; t.dx[i] = kx - pad; t.wt[i] = i; }
+  if (pool_out && ((a.Hout | a.Wout) & 1)) return LCGAN_EINVAL;
   char tag[96] = "";
-  if (lcgan_prof_active()) snprintf(tag, sizeof(tag), "fwd B%d %dx%d C%d->%d k%d s%d%s%s", B, Hin, Win, Cin, N, k, stride, pre ? " mod" : "", xs ? " +gs" : residual ? " +res" : "");
-  ProfScope p(KID_CONV_IGEMM, 2.0 * M * N * Cin * k * k, 0, s, tag);
-  return dispatch_igemm(a, 1, dtype, s);
+  if (lcgan_prof_active()) snprintf(tag, sizeof(tag), "fwd B%d %dx%d C%d->%d k%d s%d%s%s%s", B, Hin, Win, Cin, N, k, stride, pre ? " mod" : "", xs ? " +gs" : residual ? " +res" : "", pool_out ? " +pool" : "");
+  int rc;
+  {
+    ProfScope p(KID_CONV_IGEMM, 2.0 * M * N * Cin * k * k, 0, s, tag);
+    rc = dispatch_igemm(a, 1, dtype, s);
+  }
+  // the by-product avg_pool2d(y, 2): written by the epilogue where the launch path has one for it, by the pooling kernel otherwise
+  if (rc == LCGAN_OK && pool_out && !g_pool_written) rc = lcgan_avgpool2(y, pool_out, B, a.Hout, a.Wout, Cout, dtype, stream);
+  return rc;
 }
 
 // Data gradient of the convolution above == transposed convolution:
@@ -2673,6 +2714,31 @@ static int conv_wgrad_impl(const void* x, const void* g, float* gwp,
   char tag[96] = "";
   if (lcgan_prof_active()) snprintf(tag, sizeof(tag), "wgrad B%d %dx%d A%d Bc%d k%d s%d%s", B, Hg, Wg, A, Bc, k, stride, (pre_x || pre_g) ? " mod" : "");
   ProfScope p(KID_CONV_WGRAD, 2.0 * M * A * Bc * k * k, 0, s, tag);
+  // Per-sample operand scales (modulated convolutions: style on the input side, demodulation on the output side) pin every split of
+  // the row-segment kernel to ONE sample -- the scales are applied to the fp32 accumulator, once per sample -- which costs the
+  // low-resolution layers 115-170 us per launch at batch 32 (B x more, B x smaller workgroups; slabs of B x parts partial tiles).
+  // Where both operands are small the scales are applied once by an elementwise pass instead (fp32 product, one bf16 rounding, as
+  // the generic kernel's staging does) and the whole batch is one reduction range.
+  if (dtype == DT_BF16 && (pre_x || pre_g) && g_wgrad_prescale_mb > 0) {
+    const size_t bx = (size_t)B * Hx * Wx * Cx * sizeof(__bf16), bg = (size_t)B * Hg * Wg * Cg * sizeof(__bf16);
+    const size_t ox = (bx + 255) & ~(size_t)255;
+    if (bx + bg <= ((size_t)g_wgrad_prescale_mb << 20)) {
+      __bf16* buf = prescale_scratch(ox + bg);
+      if (buf) {
+        if (pre_x) {
+          const long long nvec = (long long)(bx / 16);
+          hipLaunchKernelGGL(prescale_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, s, (const __bf16*)x, pre_x, buf, nvec, Hx * Wx, Cx, Cx);
+          a.x = buf; a.pre_x = nullptr; pre_x = nullptr;
+        }
+        if (pre_g) {
+          __bf16* gb = (__bf16*)((char*)buf + ox);
+          const long long nvec = (long long)(bg / 16);
+          hipLaunchKernelGGL(prescale_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, s, (const __bf16*)g, pre_g, gb, nvec, Hg * Wg, Cg, Cg);
+          a.g = gb; a.pre_g = nullptr; pre_g = nullptr;
+        }
+      }
+    }
+  }
   int segw = (Wg & 63) == 0 ? 64 : (Wg & 31) == 0 ? 32 : (Wg == 16 ? 16 : (Wg == 8 ? 8 : 0));
   // LDS-DMA kernel: 64-position chunks at stride 1; 32-position chunks at stride 2 (two workgroups per CU either way)
   const bool dma_geom = dtype == DT_BF16 && k == 3 && Cg % 8 == 0 && Cx % 8 == 0 && !(g_wgrad3_pack && Cg <= 64 && Cx <= 64);

@@ -961,6 +961,53 @@ __global__ void rgb_expand_kernel(const float* __restrict__ img, const float* __
   }
 }
 
+// rgb_expand that also leaves pooled = avg_pool2d(y, 2) (the first DiscriminatorBlock's skip input, custom_layers.py:202): a thread walks
+// POOLED pixels and produces the four outputs under each, so the pooled tensor costs a quarter-size store instead of the pooling
+// kernel's re-read of the whole 128-channel map.  Same per-element arithmetic as rgb_expand_kernel; pooled sums the values as STORED
+// (rounded to T), in the pooling kernel's order.
+template <typename T>
+__global__ void rgb_expand_pool_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
+                                       float bias_scale, T* __restrict__ y, T* __restrict__ pooled, int H, int W, int C, int Clog,
+                                       int per_sample, int act, float gain, int PB) {
+  const int nvec = C >> 3;
+  const int groups = TPB / nvec;
+  const int grp = threadIdx.x / nvec, v = threadIdx.x - grp * nvec;
+  if (grp >= groups) return;
+  const int b = blockIdx.y, HW = H * W, Wq = W >> 1, HWq = (H >> 1) * Wq;
+  const float* wb = w + (per_sample ? (size_t)b * 3 * C : 0);
+  float w0[8], w1[8], w2[8], bv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = v * 8 + j;
+    w0[j] = wb[c]; w1[j] = wb[C + c]; w2[j] = wb[2 * C + c];
+    bv[j] = (bias && c < Clog) ? bias[c] * bias_scale : 0.f;
+  }
+  const int q0 = blockIdx.x * PB, q1 = min(q0 + PB, HWq);
+  const float* ib = img + (size_t)b * 3 * HW;
+  for (int q = q0 + grp; q < q1; q += groups) {
+    const int qy = q / Wq, qx = q - qy * Wq;
+    F8 acc = f8_zero();
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        const int p = (2 * qy + a) * W + 2 * qx + c2;
+        const float i0 = ib[p], i1 = ib[HW + p], i2 = ib[2 * HW + p];
+        F8 s;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float t = i0 * w0[j] + i1 * w1[j] + i2 * w2[j] + bv[j];
+          s.v[j] = (v * 8 + j < Clog) ? act_fwd(t, act) * gain : 0.f;
+          acc.v[j] += Feat<T>::rnd(s.v[j]);
+        }
+        Feat<T>::store(y + ((size_t)b * HW + p) * C + v * 8, s);
+      }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc.v[j] *= 0.25f;
+    Feat<T>::store(pooled + ((size_t)b * HWq + q) * C + v * 8, acc);
+  }
+}
+
 // One block = PB consecutive pixels of ONE sample; a thread keeps its 3 x 8 weights in registers and walks the pixels (the first
 // version re-read the 24 weights from L1 for every 16-byte feature vector: 2.9 TB/s).
 template <typename T>
@@ -1022,6 +1069,171 @@ __global__ void rgb_wgrad_kernel(const float* __restrict__ img, const T* __restr
       t0 += red[0][t]; t1 += red[1][t]; t2 += red[2][t];
     }
     atomicAdd(gwb + c, t0); atomicAdd(gwb + C + c, t1); atomicAdd(gwb + 2 * C + c, t2);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Fused backward passes of the two layers that touch the 3-channel image.  Unfused, each is three passes over a full-resolution
+// 128-channel tensor (activation backward -> gz, then rgb_reduce / rgb_wgrad re-reading gz): 2.7 GB of traffic per call at
+// 256 x 256, batch 32, against 1.1 GB here -- gz of the fromRGB layer never reaches memory at all.
+// ------------------------------------------------------------------------------------------------------------
+// Backward of rgb_expand (fromRGB: y = act(1x1 conv(img) + bias) * gain, cnn.py:20-21):  gz = gy * act'(y) in registers,
+//   gimg[b,o,p]  = sum_c gz[b,p,c] w[bw,o,c]            (optional: the image gradient of the R1 / generator paths)
+//   gw[bw,o,c]  += sum_p img[b,o,p] gz[b,p,c]           (optional)
+//   gbias[c]    += sum_{b,p} gz[b,p,c]                   (optional)
+// One block = P consecutive pixels of one sample; a pixel's channel vectors sit in adjacent lanes of one wave.
+template <typename T>
+__global__ void rgb_expand_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ y, const float* __restrict__ img,
+                                      const float* __restrict__ w, float* __restrict__ gimg, float* __restrict__ gw,
+                                      float* __restrict__ gbias, int HW, int C, int Clog, int per_sample, int act, float gain, int P) {
+  __shared__ float red[4][TPB * 8];
+  const int nvec = C >> 3;                                   // power of two <= 64
+  const int groups = TPB / nvec;
+  const int grp = threadIdx.x / nvec, v = threadIdx.x - grp * nvec;
+  const int b = blockIdx.y;
+  const float* wb = w + (per_sample ? (size_t)b * 3 * C : 0);
+  float w0[8], w1[8], w2[8], a0[8], a1[8], a2[8], sb[8], cm[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = v * 8 + j;
+    w0[j] = wb[c]; w1[j] = wb[C + c]; w2[j] = wb[2 * C + c];
+    a0[j] = 0.f; a1[j] = 0.f; a2[j] = 0.f; sb[j] = 0.f;
+    cm[j] = c < Clog ? 1.f : 0.f;                            // padding channels carry no gradient
+  }
+  const int p0 = blockIdx.x * P, p1 = min(p0 + P, HW);
+  const float* ib = img + (size_t)b * 3 * HW;
+  float* gib = gimg ? gimg + (size_t)b * 3 * HW : nullptr;
+  const bool need_img = gw != nullptr;
+  for (int pb = p0; pb < p1; pb += 2 * groups) {             // two pixels per trip: their loads are issued together
+    F8 g[2], yo[2];
+    float im[2][3];
+    bool live[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int p = pb + u * groups + grp;
+      live[u] = p < p1;
+      const size_t off = ((size_t)b * HW + (live[u] ? p : p0)) * C + v * 8;
+      g[u] = Feat<T>::load(gy + off);
+      yo[u] = act != ACT_NONE ? Feat<T>::load(y + off) : f8_zero();
+      const int pc = live[u] ? p : p0;
+      im[u][0] = need_img ? ib[pc] : 0.f; im[u][1] = need_img ? ib[HW + pc] : 0.f; im[u][2] = need_img ? ib[2 * HW + pc] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float lv = live[u] ? 1.f : 0.f;
+      float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float z = g[u].v[j] * act_grad_from_out(yo[u].v[j], act, gain) * cm[j] * lv;
+        o0 += z * w0[j]; o1 += z * w1[j]; o2 += z * w2[j];
+        a0[j] += im[u][0] * z; a1[j] += im[u][1] * z; a2[j] += im[u][2] * z;
+        sb[j] += z;
+      }
+      if (gib) {                                             // (every lane runs the shuffles; dead pixels contribute zeros)
+        for (int o = nvec >> 1; o > 0; o >>= 1) { o0 += __shfl_xor(o0, o, 64); o1 += __shfl_xor(o1, o, 64); o2 += __shfl_xor(o2, o, 64); }
+        const int p = pb + u * groups + grp;
+        if (live[u] && v == 0) { gib[p] = o0; gib[HW + p] = o1; gib[2 * HW + p] = o2; }
+      }
+    }
+  }
+  if (!gw && !gbias) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    red[0][threadIdx.x * 8 + j] = a0[j]; red[1][threadIdx.x * 8 + j] = a1[j]; red[2][threadIdx.x * 8 + j] = a2[j];
+    red[3][threadIdx.x * 8 + j] = sb[j];
+  }
+  __syncthreads();
+  float* gwb = gw ? gw + (per_sample ? (size_t)b * 3 * C : 0) : nullptr;
+  for (int c = threadIdx.x; c < C; c += TPB) {
+    const int vv = c >> 3, jj = c & 7;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    for (int gI = 0; gI < groups; ++gI) {
+      const int t = (gI * nvec + vv) * 8 + jj;
+      t0 += red[0][t]; t1 += red[1][t]; t2 += red[2][t]; t3 += red[3][t];
+    }
+    if (gwb) { atomicAdd(gwb + c, t0); atomicAdd(gwb + C + c, t1); atomicAdd(gwb + 2 * C + c, t2); }
+    if (gbias && c < Clog) atomicAdd(gbias + c, t3);
+  }
+}
+
+// Backward of  y = act(modulated conv + bias) * gain  ->  img = rgb_reduce(y, wm) + rgb bias  (ToRGBBlock, custom_layers.py:177-182),
+// from the image gradient down to the conv's pre-activation gradient in ONE pass over y:
+//   gfeat[b,p,c] = sum_o gimg[b,o,p] wm[bw,o,c]                        (never stored)
+//   gz           = gfeat * act'(y)                                      (written: the conv's data / weight gradients read it)
+//   gbias[c]    += sum_{b,p} gz ;  gdq[b,c] += sum_p gz * (ypre - bias[c] * bias_scale),  ypre = act^-1(y / gain)
+//   gwm[bw,o,c] += sum_p gimg[b,o,p] y[b,p,c]
+template <typename T>
+__global__ void rgb_reduce_bwd_act_kernel(const float* __restrict__ gimg, const T* __restrict__ y, const float* __restrict__ wm,
+                                          const float* __restrict__ bias, float bias_scale, T* __restrict__ gz,
+                                          float* __restrict__ gbias, float* __restrict__ gdq, float* __restrict__ gwm,
+                                          int HW, int C, int Clog, int per_sample, int act, float gain, int P) {
+  __shared__ float red[5][TPB * 8];
+  const int nvec = C >> 3;
+  const int groups = TPB / nvec;
+  const int grp = threadIdx.x / nvec, v = threadIdx.x - grp * nvec;
+  const int b = blockIdx.y;
+  const bool active = grp < groups;
+  const float* wb = wm + (per_sample ? (size_t)b * 3 * C : 0);
+  float w0[8], w1[8], w2[8], a0[8], a1[8], a2[8], sb[8], sq[8], bv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = v * 8 + j;
+    const bool ok = active && c < Clog;
+    w0[j] = ok ? wb[c] : 0.f; w1[j] = ok ? wb[C + c] : 0.f; w2[j] = ok ? wb[2 * C + c] : 0.f;
+    bv[j] = (ok && bias) ? bias[c] * bias_scale : 0.f;
+    a0[j] = 0.f; a1[j] = 0.f; a2[j] = 0.f; sb[j] = 0.f; sq[j] = 0.f;
+  }
+  const int p0 = blockIdx.x * P, p1 = min(p0 + P, HW);
+  const float* ib = gimg + (size_t)b * 3 * HW;
+  const float inv_gain = 1.f / gain;
+  if (active) {
+    for (int pb = p0 + grp; pb < p1; pb += 2 * groups) {
+      F8 yo[2];
+      float im[2][3];
+      bool live[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int p = pb + u * groups;
+        live[u] = p < p1;
+        const int pc = live[u] ? p : p0;
+        yo[u] = Feat<T>::load(y + ((size_t)b * HW + pc) * C + v * 8);
+        im[u][0] = ib[pc]; im[u][1] = ib[HW + pc]; im[u][2] = ib[2 * HW + pc];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (!live[u]) continue;
+        F8 z;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float gf = im[u][0] * w0[j] + im[u][1] * w1[j] + im[u][2] * w2[j];
+          z.v[j] = gf * act_grad_from_out(yo[u].v[j], act, gain);
+          sb[j] += z.v[j];
+          float t = yo[u].v[j] * inv_gain;
+          if (act == ACT_LRELU && t < 0.f) t *= (1.f / LRELU_SLOPE);
+          sq[j] += z.v[j] * (t - bv[j]);
+          a0[j] += im[u][0] * yo[u].v[j]; a1[j] += im[u][1] * yo[u].v[j]; a2[j] += im[u][2] * yo[u].v[j];
+        }
+        Feat<T>::store(gz + ((size_t)b * HW + pb + u * groups) * C + v * 8, z);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    red[0][threadIdx.x * 8 + j] = a0[j]; red[1][threadIdx.x * 8 + j] = a1[j]; red[2][threadIdx.x * 8 + j] = a2[j];
+    red[3][threadIdx.x * 8 + j] = sb[j]; red[4][threadIdx.x * 8 + j] = sq[j];
+  }
+  __syncthreads();
+  float* gwb = gwm + (per_sample ? (size_t)b * 3 * C : 0);
+  for (int c = threadIdx.x; c < C; c += TPB) {
+    const int vv = c >> 3, jj = c & 7;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = 0.f;
+    for (int gI = 0; gI < groups; ++gI) {
+      const int t = (gI * nvec + vv) * 8 + jj;
+      t0 += red[0][t]; t1 += red[1][t]; t2 += red[2][t]; t3 += red[3][t]; t4 += red[4][t];
+    }
+    if (c < Clog) { atomicAdd(gwb + c, t0); atomicAdd(gwb + C + c, t1); atomicAdd(gwb + 2 * C + c, t2); }
+    if (gbias && c < Clog) atomicAdd(gbias + c, t3);
+    if (gdq) atomicAdd(gdq + (size_t)b * C + c, t4);
   }
 }
 
@@ -1244,12 +1456,20 @@ int lcgan_mbstd_bwd2(const void* v, const void* gy, const void* x, void* ggy, vo
 }
 
 // y[b,p,c] = act(sum_o img[b,o,p] w[bw,o,c] + bias[c]*bias_scale) * gain   (channels >= Clog are written as zero)
+// pooled (may be NULL; then W is unused): also writes avg_pool2d(y, 2) as [B][HW/4][C]; needs the image width W (even, HW / W even)
 int lcgan_rgb_expand(const float* img, const float* w, const float* bias, float bias_scale, void* y,
-                     int B, int HW, int C, int Clog, int per_sample, int act, float gain, int dtype, void* stream) {
+                     int B, int HW, int C, int Clog, int per_sample, int act, float gain, void* pooled, int W, int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if ((C & 7) || C / 8 > TPB) return LCGAN_EINVAL;
   const long long n = (long long)B * HW * (C / 8);
-  ProfScope p(KID_RGB, 0, (double)n * 8 * (dtype == DT_BF16 ? 2 : 4), s);
+  ProfScope p(KID_RGB, 0, (double)n * 8 * (pooled ? 1.25 : 1.0) * (dtype == DT_BF16 ? 2 : 4), s);
+  if (pooled) {
+    if (W <= 0 || (W & 1) || HW % W || ((HW / W) & 1)) return LCGAN_EINVAL;
+    const int PBq = 64;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(rgb_expand_pool_kernel<T>, dim3(cdiv(HW / 4, PBq), B), dim3(TPB), 0, s, img, w, bias, bias_scale, (T*)y,
+                                         (T*)pooled, HW / W, W, C, Clog, per_sample, act, gain, PBq));
+    return launch_status();
+  }
   const int PB = 256;
   DISPATCH_T(dtype, hipLaunchKernelGGL(rgb_expand_kernel<T>, dim3(cdiv(HW, PB), B), dim3(TPB), 0, s, img, w, bias, bias_scale, (T*)y,
                                        HW, C, Clog, per_sample, act, gain, PB));
@@ -1275,6 +1495,35 @@ int lcgan_rgb_wgrad(const float* img, const void* feat, float* gw, int B, int HW
   dim3 grid(cdiv(HW, P), B);
   ProfScope p(KID_RGB, 0, (double)B * HW * C * (dtype == DT_BF16 ? 2 : 4), s);
   DISPATCH_T(dtype, hipLaunchKernelGGL(rgb_wgrad_kernel<T>, grid, dim3(TPB), 0, s, img, (const T*)feat, gw, HW, C, per_sample, P));
+  return launch_status();
+}
+
+// Backward of lcgan_rgb_expand in one pass (gz = gy * act'(y) stays in registers).  gimg [B][3][HW] (written), gw [Bw][3][C] and
+// gbias [Clog] (accumulated: zeroed by the caller); each may be NULL.  y: the saved OUTPUT of lcgan_rgb_expand (ignored for act 0).
+int lcgan_rgb_expand_bwd(const void* gy, const void* y, const float* img, const float* w, float* gimg, float* gw, float* gbias,
+                         int B, int HW, int C, int Clog, int per_sample, int act, float gain, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if ((C & 7) || !pow2_le64(C / 8) || Clog > C || (gw && !img)) return LCGAN_EINVAL;
+  const int P = reduce_P(HW, B);
+  dim3 grid(cdiv(HW, P), B);
+  ProfScope p(KID_RGB, 0, (double)B * HW * C * (act != ACT_NONE ? 2 : 1) * (dtype == DT_BF16 ? 2 : 4), s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(rgb_expand_bwd_kernel<T>, grid, dim3(TPB), 0, s, (const T*)gy, (const T*)y, img, w, gimg, gw, gbias,
+                                       HW, C, Clog, per_sample, act, gain, P));
+  return launch_status();
+}
+// Backward of  act(conv) -> lcgan_rgb_reduce  down to the conv's pre-activation gradient (see rgb_reduce_bwd_act_kernel).
+// gimg f32 [B][3][HW]; y: the conv's saved activation OUTPUT [B][HW][C]; wm f32 [Bw][3][C]; bias: the CONV's bias (may be NULL).
+// gz [B][HW][C] written; gbias [Clog] / gdq [B][C] (either may be NULL) and gwm [Bw][3][C] accumulated (zeroed by the caller).
+int lcgan_rgb_reduce_bwd_act(const float* gimg, const void* y, const float* wm, const float* bias, float bias_scale, void* gz,
+                             float* gbias, float* gdq, float* gwm, int B, int HW, int C, int Clog, int per_sample, int act, float gain,
+                             int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if ((C & 7) || C / 8 > TPB || Clog > C || !gwm || !gz) return LCGAN_EINVAL;
+  const int P = reduce_P(HW, B);
+  dim3 grid(cdiv(HW, P), B);
+  ProfScope p(KID_RGB, 0, (double)B * HW * C * 2 * (dtype == DT_BF16 ? 2 : 4), s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(rgb_reduce_bwd_act_kernel<T>, grid, dim3(TPB), 0, s, gimg, (const T*)y, wm, bias, bias_scale, (T*)gz,
+                                       gbias, gdq, gwm, HW, C, Clog, per_sample, act, gain, P));
   return launch_status();
 }
 

@@ -65,28 +65,30 @@ class EqualizedConv2d(nn.Module):
         self.stride = stride
         self.lr_mul = lr_mul
 
-    def forward(self, x, act=ACT_NONE, gain=1.0, residual=None):
+    def forward(self, x, act=ACT_NONE, gain=1.0, residual=None, pool=False):
+        """pool: returns (y, avg_pool2d(y, 2)); the pooled copy is a non-differentiable by-product (ops.Conv2dPoolFn)"""
         bias = None if self.no_bias else self.bias
         wscale = self.weight.c
         if act == ACT_NONE and gain != 1.0:          # a linear conv: fold the gain into the weight scale
             assert bias is None
             wscale, gain = wscale * gain, 1.0
-        return ops.Conv2dFn.apply(x, self.weight.weight, bias, residual, self.kernel_size, self.stride, act, gain, wscale,
-                                  self.lr_mul)
+        fn = ops.Conv2dPoolFn if pool else ops.Conv2dFn
+        return fn.apply(x, self.weight.weight, bias, residual, self.kernel_size, self.stride, act, gain, wscale, self.lr_mul)
 
-    def forward_with_pool(self, x, act=ACT_NONE, gain=1.0, box=False):
-        """(box3?(self(x, act, gain)), avg_pool2d(x, 2)) as ONE autograd node (see ops.ConvPoolFn)"""
+    def forward_with_pool(self, x, act=ACT_NONE, gain=1.0, box=False, pooled_hint=None):
+        """(box3?(self(x, act, gain)), avg_pool2d(x, 2)) as ONE autograd node (see ops.ConvPoolFn); pooled_hint: avg_pool2d(x, 2) where
+        the producer of x already wrote it"""
         assert self.stride == 1 and act != ACT_NONE
         bias = None if self.no_bias else self.bias
-        return ops.ConvPoolFn.apply(x, self.weight.weight, bias, self.kernel_size, act, gain, self.weight.c, self.lr_mul, box)
+        return ops.ConvPoolFn.apply(x, self.weight.weight, bias, self.kernel_size, act, gain, self.weight.c, self.lr_mul, box, pooled_hint)
 
-    def forward_rgb(self, img, act=ACT_NONE, gain=1.0):
+    def forward_rgb(self, img, act=ACT_NONE, gain=1.0, pool=False):
         w = self.weight.weight
         C = w.shape[0]
         assert self.kernel_size == 1 and w.shape[1] == 3 and C % 8 == 0
         wt = (w.view(C, 3).t() * self.weight.c).unsqueeze(0).contiguous()            # [1,3,C] torch glue (384 values)
         bias = None if self.no_bias else self.bias
-        return ops.RGBExpandFn.apply(img.contiguous(), wt, bias, self.lr_mul, C, act, gain, config.feature_dtype())
+        return ops.RGBExpandFn.apply(img.contiguous(), wt, bias, self.lr_mul, C, act, gain, config.feature_dtype(), pool)
 
 
 class ModulatedConv2d(nn.Module):
@@ -111,11 +113,15 @@ class ModulatedConv2d(nn.Module):
     def forward_to_rgb(self, x, s):
         """kernel_size 1, out_features 3 (ToRGBBlock.modulated_conv1, custom_layers.py:175,181): per-sample 3xC weights
         (modulate + demodulate: a few hundred values of torch glue) feed the HIP reduce kernel; output is the f32 NCHW image."""
+        return ops.RGBReduceFn.apply(x, self.rgb_weights(s), self.bias, self.lr_mul)
+
+    def rgb_weights(self, s):
+        """[B,3,C] modulated + demodulated 1x1 weights of the to-RGB layer (custom_layers.py:62-68)"""
         assert self.kernel_size == 1 and self.out_features == 3
         w = self.weight.weight.view(3, self.in_features) * self.weight.c                # [3,C]
         wm = w.unsqueeze(0) * s.unsqueeze(1)                                              # [B,3,C]   custom_layers.py:62-64
         wm = wm * torch.rsqrt(wm.square().sum(dim=2, keepdim=True) + self.eps)            # custom_layers.py:67-68
-        return ops.RGBReduceFn.apply(x, wm.contiguous(), self.bias, self.lr_mul)
+        return wm.contiguous()
 
 
 class SynthesisLayer(nn.Module):
@@ -192,8 +198,13 @@ class ToRGBBlock(nn.Module):
 
     def forward(self, x, a_latent, styles=(None, None)):
         a0, a1 = _split_latents(a_latent, 2)
-        x = self.modulated_conv0(x, a0, ACT_LRELU, 1.0, style=styles[0])
-        return self.modulated_conv1(x, a1, style=styles[1])
+        l0, l1 = self.modulated_conv0, self.modulated_conv1
+        s0 = l0.linear(a0) if styles[0] is None else styles[0]
+        s1 = l1.linear(a1) if styles[1] is None else styles[1]
+        m0, m1 = l0.modulated_conv, l1.modulated_conv
+        assert m0.kernel_size == 3 and m0.up == 1 and m1.kernel_size == 1 and m1.out_features == 3
+        # both layers as one autograd node (ops.ModConvRGBFn): the backward needs one pass over the 3x3 conv's activation
+        return ops.ModConvRGBFn.apply(x, m0.weight.weight, m0.bias, s0, m1.rgb_weights(s1), m1.bias, m1.lr_mul, ACT_LRELU, 1.0)
 
 
 class DiscriminatorBlock(nn.Module):
@@ -209,15 +220,17 @@ class DiscriminatorBlock(nn.Module):
             self.gain = np.sqrt(2)
             self.skip_gain = np.sqrt(0.5)
 
-    def forward(self, x):
+    def forward(self, x, pooled=None, want_pool=False):
+        """pooled: avg_pool2d(x, 2) when the producer of x left it as a by-product; want_pool: return (out, avg_pool2d(out, 2)) for the
+        next block (the pooled copy then comes out of the closing convolution's epilogue instead of a pooling pass over `out`)"""
         if self.skip:
-            h, pooled = self.conv0.forward_with_pool(x, ACT_LRELU, SQRT2, box=True)   # :202, :204-206 (one node: see ops.ConvPoolFn)
+            h, pooled = self.conv0.forward_with_pool(x, ACT_LRELU, SQRT2, box=True, pooled_hint=pooled)   # :202, :204-206 (one node: see ops.ConvPoolFn)
         else:
             h = ops.Box3Fn.apply(self.conv0(x, ACT_LRELU, 1.0))                 # :212-214
         h = self.conv1(h, ACT_LRELU, 1.0)                                       # :207-208
         if not self.skip:
-            return h
-        return self.skip_layer(pooled, ACT_NONE, SQRT_HALF, residual=h)         # :203, :209 (add fused in the epilogue)
+            return (h, None) if want_pool else h
+        return self.skip_layer(pooled, ACT_NONE, SQRT_HALF, residual=h, pool=want_pool)   # :203, :209 (add fused in the epilogue)
 
 
 class MinibatchStdLayer(nn.Module):

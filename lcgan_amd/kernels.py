@@ -181,17 +181,22 @@ class HipKernels:
 
     def conv_fwd(self, x: Tensor, pw: PreparedWeight, N: int, k: int, stride: int, pre=None, post=None, bias=None,
                  bias_scale: float = 1.0, act: int = ACT_NONE, gain: float = 1.0, residual=None, residual_half: bool = False,
-                 xs: Optional[Tensor] = None):
-        """xs given (needs post, no bias/act/residual): returns (y = post * u, gs[b,n] = sum_pixels xs * u), u = the unscaled result"""
+                 xs: Optional[Tensor] = None, pool: bool = False):
+        """xs given (needs post, no bias/act/residual): returns (y = post * u, gs[b,n] = sum_pixels xs * u), u = the unscaled result;
+        pool: returns (y, avg_pool2d(y, 2)) -- the by-product a DiscriminatorBlock's closing convolution leaves for the next block"""
         self._chk(x, pre, post, bias, residual, xs)
         B, H, W, Cin = x.shape
         Cout = ceil8(N)
-        y = torch.empty((B, (H + stride - 1) // stride, (W + stride - 1) // stride, Cout), dtype=x.dtype, device=x.device)
+        Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+        y = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
         gs = self._zeros.take((B, Cout), x.device) if xs is not None else None
-        assert pw.parts == (3 if x.dtype == torch.float32 else 1)
+        pooled = torch.empty((B, Ho // 2, Wo // 2, Cout), dtype=x.dtype, device=x.device) if pool else None
+        assert pw.parts == (3 if x.dtype == torch.float32 else 1) and not (pool and xs is not None)
         self._call("lcgan_conv_fwd", x.data_ptr(), pw.buf.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, N, k, stride,
                    _p(pre), _p(post), _p(bias), float(bias_scale), act, float(gain), _p(residual), int(residual_half), _p(xs), _p(gs),
-                   dt_code(x.dtype), self._stream())
+                   _p(pooled), dt_code(x.dtype), self._stream())
+        if pool:
+            return y, pooled
         return y if xs is None else (y, gs)
 
     def conv_bwd_data(self, g: Tensor, pw: PreparedWeight, N: int, k: int, stride: int, pre=None, post=None, bias=None,
@@ -389,14 +394,16 @@ class HipKernels:
 
     # ---- RGB 1x1 convs (image is f32 NCHW, w is f32 [Bw,3,C]) ----------------------------------------------
     def rgb_expand(self, img: Tensor, w: Tensor, bias: Optional[Tensor], bias_scale: float, clog: int, act: int, gain: float,
-                   dtype: torch.dtype) -> Tensor:
+                   dtype: torch.dtype, pool: bool = False):
+        """pool: -> (y, avg_pool2d(y, 2)) from one pass"""
         self._chk(img, w, bias)
         B, _, H, W = img.shape
         Cc = w.shape[-1]
         y = torch.empty((B, H, W, Cc), dtype=dtype, device=img.device)
+        pooled = torch.empty((B, H // 2, W // 2, Cc), dtype=dtype, device=img.device) if pool else None
         self._call("lcgan_rgb_expand", img.data_ptr(), w.data_ptr(), _p(bias), float(bias_scale), y.data_ptr(), B, H * W, Cc, clog,
-                   int(w.shape[0] > 1), act, float(gain), dt_code(dtype), self._stream())
-        return y
+                   int(w.shape[0] > 1), act, float(gain), _p(pooled), W, dt_code(dtype), self._stream())
+        return (y, pooled) if pool else y
 
     def rgb_reduce(self, x: Tensor, w: Tensor, bias: Optional[Tensor], bias_scale: float) -> Tensor:
         self._chk(x, w, bias)
@@ -413,6 +420,33 @@ class HipKernels:
         self._call("lcgan_rgb_wgrad", img.data_ptr(), feat.data_ptr(), gw.data_ptr(), B, H * W, Cc, int(per_sample),
                    dt_code(feat.dtype), self._stream())
         return gw
+
+    def rgb_expand_bwd(self, gy: Tensor, y: Optional[Tensor], img: Optional[Tensor], w: Tensor, act: int, gain: float, clog: int,
+                       want_gimg: bool, want_gw: bool, want_gbias: bool):
+        """fused backward of rgb_expand -> (gimg [B,3,H,W] | None, gw [Bw,3,C] | None, gbias [clog] | None); gz = gy * act'(y) is never stored"""
+        self._chk(gy, y, img, w)
+        B, H, W, Cc = gy.shape
+        per_sample = w.shape[0] > 1
+        gimg = torch.empty((B, 3, H, W), dtype=torch.float32, device=gy.device) if want_gimg else None
+        gw = self._zeros.take((B if per_sample else 1, 3, Cc), gy.device) if want_gw else None
+        gbias = self._zeros.take((clog,), gy.device) if want_gbias else None
+        self._call("lcgan_rgb_expand_bwd", gy.data_ptr(), _p(y), _p(img), w.data_ptr(), _p(gimg), _p(gw), _p(gbias), B, H * W, Cc, clog,
+                   int(per_sample), act, float(gain), dt_code(gy.dtype), self._stream())
+        return gimg, gw, gbias
+
+    def rgb_reduce_bwd_act(self, gimg: Tensor, y: Tensor, wm: Tensor, bias: Optional[Tensor], bias_scale: float, act: int, gain: float,
+                           clog: int, want_gbias: bool = True, want_gdq: bool = True):
+        """image gradient -> pre-activation gradient of the conv in front of rgb_reduce: (gz, gbias [clog] | None, gdq [B,C] | None, gwm [Bw,3,C])"""
+        self._chk(gimg, y, wm, bias)
+        B, H, W, Cc = y.shape
+        per_sample = wm.shape[0] > 1
+        gz = torch.empty_like(y)
+        gbias = self._zeros.take((clog,), y.device) if want_gbias else None
+        gdq = self._zeros.take((B, Cc), y.device) if want_gdq else None
+        gwm = self._zeros.take((B if per_sample else 1, 3, Cc), y.device)
+        self._call("lcgan_rgb_reduce_bwd_act", gimg.data_ptr(), y.data_ptr(), wm.data_ptr(), _p(bias), float(bias_scale), gz.data_ptr(),
+                   _p(gbias), _p(gdq), gwm.data_ptr(), B, H * W, Cc, clog, int(per_sample), act, float(gain), dt_code(y.dtype), self._stream())
+        return gz, gbias, gdq, gwm
 
     # ---- layout ---------------------------------------------------------------------------------------------
     def nchw_to_nhwc(self, src: Tensor, B: int, calloc: int, dtype: torch.dtype) -> Tensor:

@@ -230,6 +230,28 @@ class Conv2dFn(Function):
         return gx, gw, (gb if want_gb else None), gres, None, None, None, None, None, None
 
 
+class Conv2dPoolFn(Function):
+    """Conv2dFn that also returns avg_pool2d(y, 2) as a NON-DIFFERENTIABLE by-product: the closing 1x1 + residual convolution of a
+    DiscriminatorBlock (custom_layers.py:203,209) leaves the pooled copy of its output that the next block's skip branch reads
+    (custom_layers.py:202) while the output tile is still on chip.  The next block's ops.ConvPoolFn takes it as a hint in place of its own
+    pooling pass; the autograd graph is the one without the hint (ConvPoolFn still owns d pooled / d x)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, residual, k, stride, act, gain, wscale, bias_scale):
+        assert not (act != ACT_NONE and residual is not None) and (act != ACT_NONE or gain == 1.0)
+        K = _K()
+        pw, _ = _prep(w, wscale, False, _need_lo(x))
+        y, pooled = K.conv_fwd(x, pw, w.shape[0], k, stride, bias=bias, bias_scale=bias_scale, act=act, gain=gain, residual=residual, pool=True)
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.cfg = (k, stride, act, gain, wscale, bias_scale, bias is not None, residual is not None)
+        ctx.mark_non_differentiable(pooled)
+        return y, pooled
+
+    @staticmethod
+    def backward(ctx, gy, _gpooled):
+        return Conv2dFn.backward(ctx, gy)
+
+
 class ConvTransposeFn(Function):
     """gx = adjoint of conv_{k,stride}(., w*wscale) applied to g  (stride 2: the 4-phase transposed convolution)
     (+ 0.25 * nearest-x2(res_half): the adjoint of avg_pool2d, fused into the epilogue)."""
@@ -267,7 +289,8 @@ class ConvPoolFn(Function):
     backward and the activation backward are one pass (BoxActBwdFn)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, k, act, gain, wscale, bias_scale, box):
+    def forward(ctx, x, w, bias, k, act, gain, wscale, bias_scale, box, pooled_hint=None):
+        """pooled_hint: avg_pool2d(x, 2) where the producer of x already left it (Conv2dPoolFn, RGBExpandFn(pool=True)): the pooling pass is skipped"""
         K = _K()
         if _use_fp8(x, k, 1):
             pw, _ = _prep(w, wscale, False, False, fp8=True)
@@ -277,7 +300,8 @@ class ConvPoolFn(Function):
             y = K.conv_fwd(x, pw, w.shape[0], k, 1, bias=bias, bias_scale=bias_scale, act=act, gain=gain)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.cfg = (k, act, gain, wscale, bias_scale, bias is not None, box)
-        return (K.box3_act(y, ACT_NONE, 1.0) if box else y), K.avgpool2(x)
+        pooled = K.avgpool2(x) if pooled_hint is None else pooled_hint.detach().view_as(pooled_hint)
+        return (K.box3_act(y, ACT_NONE, 1.0) if box else y), pooled
 
     @staticmethod
     def backward(ctx, gy, gpooled):
@@ -287,7 +311,7 @@ class ConvPoolFn(Function):
         want_gb = has_bias and _wants(ctx, 2)
         if gy is None:                                                   # only the pooled branch was used
             gx = _ap(AvgPool2TFn, gpooled.contiguous()) if ctx.needs_input_grad[0] else None
-            return gx, None, None, None, None, None, None, None, None
+            return gx, None, None, None, None, None, None, None, None, None
         gy = gy.contiguous()
         if box and act != ACT_NONE:
             gz, gb = _ap(BoxActBwdFn, gy, y, act, gain, A, want_gb, bias_scale)
@@ -302,7 +326,7 @@ class ConvPoolFn(Function):
         if ctx.needs_input_grad[0]:
             gx = _ap(ConvTransposeFn, gz, w, k, 1, wscale, x.shape[-1], None if gpooled is None else gpooled.contiguous())
         gw = _ap(ConvWeightGradFn, x, gz, k, 1, wscale, w.shape[0], w.shape[1]) if _wants(ctx, 1) else None
-        return gx, gw, (gb if want_gb else None), None, None, None, None, None, None
+        return gx, gw, (gb if want_gb else None), None, None, None, None, None, None, None
 
 
 class BoxActBwdFn(Function):
@@ -418,25 +442,39 @@ class RGBExpandFn(Function):
     """feat[b,p,c] = act(sum_o img[b,o,p] wt[bw,o,c] + bias[c]*bias_scale) * gain     (fromRGB: cnn.py:20-21)"""
 
     @staticmethod
-    def forward(ctx, img, wt, bias, bias_scale, clog, act, gain, dtype):
-        y = _K().rgb_expand(img, wt, bias, bias_scale, clog, act, gain, dtype)
+    def forward(ctx, img, wt, bias, bias_scale, clog, act, gain, dtype, pool=False):
+        """pool: also returns avg_pool2d(feat, 2) as a non-differentiable by-product (see Conv2dPoolFn)"""
+        out = _K().rgb_expand(img, wt, bias, bias_scale, clog, act, gain, dtype, pool=pool)
+        y = out[0] if pool else out
         ctx.save_for_backward(img, wt, y if act != ACT_NONE else None)
         ctx.cfg = (bias_scale, clog, act, gain, bias is not None)
+        if pool:
+            ctx.mark_non_differentiable(out[1])
+            return y, out[1]
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gpooled=None):
         img, wt, y = ctx.saved_tensors
         bias_scale, clog, act, gain, has_bias = ctx.cfg
         gy = gy.contiguous()
         want_gb = has_bias and _wants(ctx, 2)
+        if not torch.is_grad_enabled():
+            # ordinary (first-order) backward: ONE pass forms gz = gy * act'(y) in registers and leaves the image gradient, the weight
+            # gradient and the bias gradient (1.1 GB instead of 2.7 GB of traffic at 256 x 256, batch 32).  Under create_graph (R1,
+            # loss.py:28-33) the composition below records the graph the second backward walks.
+            want_gw = _wants(ctx, 1)
+            gimg, gwt, gb = _K().rgb_expand_bwd(gy, y, img if want_gw else None, wt, act, gain, clog, ctx.needs_input_grad[0], want_gw, want_gb)
+            if gb is not None and bias_scale != 1.0:
+                gb = gb * bias_scale
+            return gimg, gwt, gb, None, None, None, None, None, None
         if act != ACT_NONE or want_gb:
             gz, gb = _ap(ActBwdFn, gy, y, act, gain, clog, want_gb, bias_scale)
         else:
             gz, gb = gy, None
         gimg = _ap(RGBReduceFn, gz, wt, None, 0.0) if ctx.needs_input_grad[0] else None
         gwt = _ap(RGBWeightGradFn, img, gz, wt.shape[0] > 1) if _wants(ctx, 1) else None
-        return gimg, gwt, (gb if want_gb else None), None, None, None, None, None
+        return gimg, gwt, (gb if want_gb else None), None, None, None, None, None, None
 
 
 class RGBReduceFn(Function):
@@ -691,25 +729,71 @@ class ModConvFn(Function):
         K = _K()
         x, w, bias, s, d, wsq, y = ctx.saved_tensors
         up, act, gain, c_eq = ctx.cfg
-        O, Cin, k, _ = w.shape
+        O = w.shape[0]
         gy = gy.contiguous()
         # activation backward + bias gradient + demod statistic  gdq[b,o] = sum_p gz * (ypre - bias)
         gz, gb, gdq = K.act_bwd_reduce(gy, y, act, gain, O, want_gz=(act != ACT_NONE), bias=bias, bias_scale=1.0,
                                        want_gbias=True, want_gdq=True)
         if gz is None:
             gz = gy
-        pwT, _ = _prep(w, c_eq, True, _need_lo(x))                               # [t][Cin][O]
-        # data gradient u = conv^T(d * gz); gx = s * u and gs = sum_p x * u leave the same launch (epilogue of the conv kernel)
-        if up == 2:
-            gx, gs = K.conv_fwd(gz, pwT, Cin, k, 2, pre=d, post=s, xs=x)         # adjoint of the transposed conv
-        else:
-            gx, gs = K.conv_bwd_data(gz, pwT, Cin, k, 1, pre=d, post=s, xs=x)
-        gwsq = K.demod_bwd(gdq, d, s, wsq, gs)                                   # gs += demod path
-        if up == 2:
-            gw = K.conv_wgrad_unprep(gz, x, Cin, O, k, 2, c_eq, transposed=True, pre_x=d, pre_g=s, w=w, gwsq=gwsq)    # gwp [t][Cin][O]
-        else:
-            gw = K.conv_wgrad_unprep(x, gz, O, Cin, k, 1, c_eq, transposed=False, pre_x=s, pre_g=d, w=w, gwsq=gwsq)   # gwp [t][O][Cin]
+        gx, gw, gs = _modconv_bwd_tail(x, w, s, d, wsq, gz, gdq, up, c_eq)
         return gx, gw, gb, gs, None, None, None
+
+
+def _modconv_bwd_tail(x, w, s, d, wsq, gz, gdq, up, c_eq):
+    """from the pre-activation gradient gz of a modulated convolution to (gx, gw, gs)"""
+    K = _K()
+    O, Cin, k, _ = w.shape
+    pwT, _ = _prep(w, c_eq, True, _need_lo(x))                               # [t][Cin][O]
+    # data gradient u = conv^T(d * gz); gx = s * u and gs = sum_p x * u leave the same launch (epilogue of the conv kernel)
+    if up == 2:
+        gx, gs = K.conv_fwd(gz, pwT, Cin, k, 2, pre=d, post=s, xs=x)         # adjoint of the transposed conv
+    else:
+        gx, gs = K.conv_bwd_data(gz, pwT, Cin, k, 1, pre=d, post=s, xs=x)
+    gwsq = K.demod_bwd(gdq, d, s, wsq, gs)                                   # gs += demod path
+    if up == 2:
+        gw = K.conv_wgrad_unprep(gz, x, Cin, O, k, 2, c_eq, transposed=True, pre_x=d, pre_g=s, w=w, gwsq=gwsq)    # gwp [t][Cin][O]
+    else:
+        gw = K.conv_wgrad_unprep(x, gz, O, Cin, k, 1, c_eq, transposed=False, pre_x=s, pre_g=d, w=w, gwsq=gwsq)   # gwp [t][O][Cin]
+    return gx, gw, gs
+
+
+class ModConvRGBFn(Function):
+    """ToRGBBlock as ONE node (custom_layers.py:177-182): img = rgb_reduce(lrelu(modconv3x3(x, s)), wm) + rgb_bias * rgb_bias_scale,
+    wm [B,3,C] the modulated + demodulated 1x1 weights (torch glue on a few hundred values, custom_layers.py:62-68).  Owning both layers
+    lets the backward go from the image gradient to the 3x3 conv's pre-activation gradient in one pass over its activation
+    (lcgan_rgb_reduce_bwd_act) instead of rgb_expand + rgb_wgrad + act_bwd_reduce: 1.1 GB instead of 2.7 GB at 256 x 256, batch 32."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, s, wm, rgb_bias, rgb_bias_scale, act, gain):
+        K = _K()
+        O, Cin, k, _ = w.shape
+        c_eq = 1.0 / math.sqrt(Cin * k * k)
+        s = s.contiguous()
+        pw, wsq = _prep(w, c_eq, False, _need_lo(x), want_wsq=True)
+        d = K.demod_fwd(s, wsq, ceil8(O))
+        if _use_fp8(x, k, 1):
+            pw8, _ = _prep(w, c_eq, False, False, fp8=True)
+            y = K.conv_fwd_fp8(x, pw8, O, k, 1, pre=s, post=d, bias=bias, bias_scale=1.0, act=act, gain=gain)
+        else:
+            y = K.conv_fwd(x, pw, O, k, 1, pre=s, post=d, bias=bias, bias_scale=1.0, act=act, gain=gain)
+        wm = wm.contiguous()
+        img = K.rgb_reduce(y, wm, rgb_bias, rgb_bias_scale)
+        ctx.save_for_backward(x, w, bias, s, d, wsq, y, wm)
+        ctx.cfg = (act, gain, c_eq, rgb_bias_scale, rgb_bias is not None)
+        return img
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gimg):
+        K = _K()
+        x, w, bias, s, d, wsq, y, wm = ctx.saved_tensors
+        act, gain, c_eq, rgb_bias_scale, has_rgb_bias = ctx.cfg
+        gimg = gimg.contiguous()
+        gz, gb, gdq, gwm = K.rgb_reduce_bwd_act(gimg, y, wm, bias, 1.0, act, gain, w.shape[0])
+        gx, gw, gs = _modconv_bwd_tail(x, w, s, d, wsq, gz, gdq, 1, c_eq)
+        grb = gimg.sum(dim=(0, 2, 3)) * rgb_bias_scale if (has_rgb_bias and ctx.needs_input_grad[5]) else None     # 3 numbers
+        return gx, gw, gb, gs, gwm, grb, None, None, None
 
 
 class Box3ActFn(Function):

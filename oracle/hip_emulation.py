@@ -138,7 +138,10 @@ class EmulatedKernels:
         return (u * post[:, None, None, :u.shape[-1]]).to(dtype), gs
 
     def conv_fwd(self, x, pw, N, k, stride, pre=None, post=None, bias=None, bias_scale=1.0, act=ACT_NONE, gain=1.0, residual=None,
-                 residual_half=False, xs=None):
+                 residual_half=False, xs=None, pool=False):
+        if pool:                                              # by-product avg_pool2d(y, 2) of the values as stored
+            y = self.conv_fwd(x, pw, N, k, stride, pre, post, bias, bias_scale, act, gain, residual, residual_half, xs)
+            return y, self.avgpool2(y)
         residual = self._res(residual, residual_half)
         Kc = pw.P4.shape[1]
         xin = nchw(x)[:, :Kc]
@@ -322,7 +325,10 @@ class EmulatedKernels:
         return ggy.to(gy.dtype), gx2.to(x.dtype)
 
     # ---- RGB ----------------------------------------------------------------------------------------------
-    def rgb_expand(self, img, w, bias, bias_scale, clog, act, gain, dtype):
+    def rgb_expand(self, img, w, bias, bias_scale, clog, act, gain, dtype, pool=False):
+        if pool:
+            y = self.rgb_expand(img, w, bias, bias_scale, clog, act, gain, dtype)
+            return y, self.avgpool2(y)
         B = img.shape[0]
         wb = w.detach() if w.shape[0] > 1 else w.detach().expand(B, -1, -1)
         v = torch.einsum("bohw,boc->bhwc", img.float(), wb)
@@ -343,6 +349,44 @@ class EmulatedKernels:
     def rgb_wgrad(self, img, feat, per_sample):
         gw = torch.einsum("bohw,bhwc->boc", img.float(), feat.float())
         return gw.contiguous() if per_sample else gw.sum(0, keepdim=True).contiguous()
+
+    def rgb_expand_bwd(self, gy, y, img, w, act, gain, clog, want_gimg, want_gw, want_gbias):
+        """lcgan_rgb_expand_bwd: gz = gy * act'(y) stays fp32 (never rounded to the feature dtype)"""
+        B = gy.shape[0]
+        z = gy.float() * (act_grad_from_out(y.float(), act, gain) if act != ACT_NONE else gain)
+        z[..., clog:] = 0
+        wb = w.detach() if w.shape[0] > 1 else w.detach().expand(B, -1, -1)
+        gimg = torch.einsum("bhwc,boc->bohw", z, wb).contiguous() if want_gimg else None
+        gw = None
+        if want_gw:
+            gw = torch.einsum("bohw,bhwc->boc", img.float(), z)
+            gw = gw.contiguous() if w.shape[0] > 1 else gw.sum(0, keepdim=True).contiguous()
+        gbias = z.sum(dim=(0, 1, 2))[:clog].contiguous() if want_gbias else None
+        return gimg, gw, gbias
+
+    def rgb_reduce_bwd_act(self, gimg, y, wm, bias, bias_scale, act, gain, clog, want_gbias=True, want_gdq=True):
+        """lcgan_rgb_reduce_bwd_act"""
+        B, H, W, Cc = y.shape
+        per_sample = wm.shape[0] > 1
+        wb = (wm.detach() if per_sample else wm.detach().expand(B, -1, -1)).clone()
+        wb[..., clog:] = 0
+        yo = y.float()
+        gf = torch.einsum("bohw,boc->bhwc", gimg.float(), wb)
+        z = gf * act_grad_from_out(yo, act, gain)
+        gbias = z.sum(dim=(0, 1, 2))[:clog].contiguous() if want_gbias else None
+        gdq = None
+        if want_gdq:
+            t = yo / gain
+            if act == ACT_LRELU:
+                t = torch.where(t < 0, t / SLOPE, t)
+            bv = torch.zeros(Cc)
+            if bias is not None:
+                bv[:clog] = bias.detach() * bias_scale
+            gdq = (z * (t - bv)).sum(dim=(1, 2)).contiguous()
+        gwm = torch.einsum("bohw,bhwc->boc", gimg.float(), yo)
+        gwm[..., clog:] = 0
+        gwm = gwm.contiguous() if per_sample else gwm.sum(0, keepdim=True).contiguous()
+        return z.to(y.dtype), gbias, gdq, gwm
 
     # ---- layout ---------------------------------------------------------------------------------------------
     def nchw_to_nhwc(self, src, B, calloc, dtype):

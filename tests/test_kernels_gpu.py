@@ -111,6 +111,59 @@ def test_prep_weight_group(H):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 32, 32, 128, 256, 1), (3, 16, 16, 64, 128, 1), (2, 64, 64, 64, 64, 1), (4, 8, 8, 128, 256, 1), (2, 32, 32, 64, 96, 3),
+                                  (32, 16, 16, 512, 512, 1)])
+def test_conv_fwd_pooled_byproduct(H, dtype, case):
+    """lcgan_conv_fwd(pool_out): avg_pool2d(y, 2) out of the closing convolution of a DiscriminatorBlock (1x1 + residual; the epilogue
+    of the halo kernel on the fast path, the pooling kernel elsewhere) == the pooling kernel on the stored y, bit for bit."""
+    B, Hh, W, Ci, Co, k = case
+    x = feat((B, Hh, W, ceil8(Ci)), dtype, 1, Ci)
+    w = torch.randn(Co, Ci, k, k, generator=torch.Generator().manual_seed(2))
+    pw_h, _ = H.prep_weight(w.cuda(), 0.7 / math.sqrt(Ci * k * k), False, dtype == torch.float32)
+    res = feat((B, Hh, W, ceil8(Co)), dtype, 6, Co)
+    for residual in (res.cuda(), None):
+        y, pooled = H.conv_fwd(x.cuda(), pw_h, Co, k, 1, residual=residual, pool=True)
+        y0 = H.conv_fwd(x.cuda(), pw_h, Co, k, 1, residual=residual)
+        if dtype == torch.float32:
+            assert torch.equal(y, y0)
+        else:                                               # (split-K partials of small grids meet through atomics: not bit-reproducible)
+            check(y, y0.cpu(), dtype, "y")
+        assert torch.equal(pooled, H.avgpool2(y)), "pooled by-product differs from avg_pool2d of the stored output"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_rgb_expand_pooled_byproduct(H, dtype):
+    B, Hh, W, C = 3, 16, 24, 128
+    img = torch.randn(B, 3, Hh, W, generator=torch.Generator().manual_seed(71))
+    w = torch.randn(1, 3, C, generator=torch.Generator().manual_seed(72)) * 0.3
+    bias = torch.randn(C, generator=torch.Generator().manual_seed(73))
+    y, pooled = H.rgb_expand(img.cuda(), w.cuda(), bias.cuda(), 0.5, C, 1, 1.2, dtype, pool=True)
+    assert torch.equal(y, H.rgb_expand(img.cuda(), w.cuda(), bias.cuda(), 0.5, C, 1, 1.2, dtype))
+    assert torch.equal(pooled, H.avgpool2(y))
+
+
+@pytest.mark.parametrize("case", [(8, 32, 32, 64, 64, 3, 1), (8, 16, 16, 128, 96, 3, 1), (4, 32, 32, 64, 128, 3, 2), (8, 8, 8, 128, 128, 3, 1)])
+def test_conv_wgrad_prescaled_path(H, case):
+    """weight gradient with per-sample scales on small operands: scales applied by one elementwise pass + batch-wide reduction (option 17)
+    against the per-sample-range path (option 17 = 0) and the emulation"""
+    B, Hh, W, Cx, A, k, stride = case
+    dtype = torch.bfloat16
+    x = feat((B, Hh, W, ceil8(Cx)), dtype, 11, Cx)
+    g = feat((B, Hh // stride, W // stride, ceil8(A)), dtype, 12, A)
+    px, pg = vec((B, ceil8(Cx)), 13), vec((B, ceil8(A)), 14)
+    ref = E.conv_wgrad(x, g, A, Cx, k, stride, pre_x=px, pre_g=pg)
+    new = H.conv_wgrad(x.cuda(), g.cuda(), A, Cx, k, stride, pre_x=px.cuda(), pre_g=pg.cuda())
+    old_opt = H.lib.lcgan_set_option(17, 0)
+    try:
+        old = H.conv_wgrad(x.cuda(), g.cuda(), A, Cx, k, stride, pre_x=px.cuda(), pre_g=pg.cuda())
+    finally:
+        H.lib.lcgan_set_option(17, old_opt)
+    check(new, ref, dtype, "prescaled vs emulation", l2_scale=2.0)
+    check(old, ref, dtype, "per-sample ranges vs emulation")
+    check(new, old.cpu(), dtype, "prescaled vs per-sample ranges", l2_scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd(H, dtype, case):
     B, Hh, W, Ci, Co, k, stride = case
@@ -535,6 +588,47 @@ def test_rgb(H, dtype, per_sample):
     b3 = torch.randn(3, generator=torch.Generator().manual_seed(75))
     check(H.rgb_reduce(x.cuda(), w.cuda(), b3.cuda(), 1.0), E.rgb_reduce(x, w, b3, 1.0), torch.float32 if dtype == torch.float32 else dtype, "reduce")
     check(H.rgb_wgrad(img.cuda(), x.cuda(), per_sample), E.rgb_wgrad(img, x, per_sample), torch.float32 if dtype == torch.float32 else dtype, "wgrad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("per_sample", [False, True])
+@pytest.mark.parametrize("shape", [(3, 16, 16, 128), (2, 9, 7, 64), (1, 40, 40, 32)])
+def test_rgb_fused_backward(H, dtype, per_sample, shape):
+    """lcgan_rgb_expand_bwd / lcgan_rgb_reduce_bwd_act: the one-pass backward of the two layers that touch the image, against the
+    emulation AND against the three-pass composition they replace (activation backward -> rgb_reduce / rgb_wgrad)."""
+    B, Hh, W, C = shape
+    clog = C
+    f32ish = torch.float32 if dtype == torch.float32 else dtype
+    img = torch.randn(B, 3, Hh, W, generator=torch.Generator().manual_seed(71))
+    w = torch.randn(B if per_sample else 1, 3, C, generator=torch.Generator().manual_seed(72)) * 0.3
+    gy, y = feat((B, Hh, W, C), dtype, 76), feat((B, Hh, W, C), dtype, 77)
+    for flags in ((True, True, True), (True, False, False), (False, True, True)):
+        got = H.rgb_expand_bwd(gy.cuda(), y.cuda(), img.cuda() if flags[1] else None, w.cuda(), 1, 1.2, clog, *flags)
+        ref = E.rgb_expand_bwd(gy, y, img, w, 1, 1.2, clog, *flags)
+        for name, g, r in zip(("gimg", "gw", "gbias"), got, ref):
+            assert (g is None) == (r is None), name
+            if g is not None:
+                check(g, r, f32ish, f"expand_bwd {name} {flags}")
+    # the composition: gz rounded to the feature dtype in between (hence the looser bf16 tolerance is the right one)
+    gz, gb, _ = H.act_bwd_reduce(gy.cuda(), y.cuda(), 1, 1.2, clog, want_gz=True, want_gbias=True)
+    gimg, gw, gbias = H.rgb_expand_bwd(gy.cuda(), y.cuda(), img.cuda(), w.cuda(), 1, 1.2, clog, True, True, True)
+    check(gimg, H.rgb_reduce(gz, w.cuda(), None, 0.0).cpu(), f32ish, "expand_bwd vs composition: gimg", l2_scale=2.0)
+    check(gw, H.rgb_wgrad(img.cuda(), gz, per_sample).cpu(), f32ish, "expand_bwd vs composition: gw", l2_scale=2.0)
+    check(gbias, gb.cpu(), f32ish, "expand_bwd vs composition: gbias")
+
+    gimg_in = torch.randn(B, 3, Hh, W, generator=torch.Generator().manual_seed(78))
+    bias = torch.randn(C, generator=torch.Generator().manual_seed(79)) * 0.2
+    got = H.rgb_reduce_bwd_act(gimg_in.cuda(), y.cuda(), w.cuda(), bias.cuda(), 1.0, 1, 1.3, clog)
+    ref = E.rgb_reduce_bwd_act(gimg_in, y, w, bias, 1.0, 1, 1.3, clog)
+    check(got[0], ref[0], dtype, "reduce_bwd_act gz")
+    for name, g, r in zip(("gbias", "gdq", "gwm"), got[1:], ref[1:]):
+        check(g, r, f32ish, f"reduce_bwd_act {name}")
+    gfeat = H.rgb_expand(gimg_in.cuda(), w.cuda(), None, 0.0, clog, 0, 1.0, dtype)
+    gz2, gb2, gdq2 = H.act_bwd_reduce(gfeat, y.cuda(), 1, 1.3, clog, want_gz=True, bias=bias.cuda(), bias_scale=1.0, want_gbias=True, want_gdq=True)
+    check(got[0], gz2.cpu(), dtype, "reduce_bwd_act vs composition: gz", l2_scale=2.0)     # (the composition rounds gfeat to bf16 in between)
+    check(got[1], gb2.cpu(), f32ish, "reduce_bwd_act vs composition: gbias")
+    check(got[2], gdq2.cpu(), f32ish, "reduce_bwd_act vs composition: gdq")
+    check(got[3], H.rgb_wgrad(gimg_in.cuda(), y.cuda(), per_sample).cpu(), f32ish, "reduce_bwd_act vs composition: gwm")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -311,23 +311,30 @@ def test_checkpoint_round_trip_on_device(tmp_path):
             loader.train_iteration(w, w.args, epoch)              # moves G, D, G_ema, both Adam states; fills the prepared-weight cache
         z1, z2 = seeded_tensor((B, 64), 1).to(DEV), seeded_tensor((B, 64), 2).to(DEV)
         real = seeded_tensor((B, 3, res, res), 3, "uniform_pm1").to(DEV)
+        def relmax(a, b):
+            return float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-12))
         with torch.no_grad():
             img0, ema0 = w.generator(z1, z2, 0.7).clone(), w.generate(z1, z2, 0.7).clone()
             d0 = [t.clone() for t in w.discriminator(real, True)]
+            # run-to-run noise of the SAME weights: the split-K convolutions of the low-resolution layers meet through fp32 atomics, so
+            # two forwards agree to a bf16 rounding of a few elements, not bit for bit; stale (wrecked) weights are off by O(1)
+            noise = max(relmax(w.generator(z1, z2, 0.7), img0), relmax(w.discriminator(real, True)[0], d0[0]), 1e-6)
+        assert noise <= 2e-2, noise
         w.save_model()
         assert sorted(os.listdir(run / "model")) == ["disc_model.ckpt", "gen_ema_model.ckpt", "gen_model.ckpt", "optim_state.ckpt"]
         with torch.no_grad():                                     # wreck every weight in place, run once so the caches hold the wrecked copies
             for m in (w.generator, w.generator_ema, w.discriminator):
                 for p in m.parameters():
                     p.mul_(1.5).add_(0.01)
-            assert not torch.equal(w.generator(z1, z2, 0.7), img0)
-            assert not torch.equal(w.discriminator(real, True)[0], d0[0])
+            wrecked = min(relmax(w.generator(z1, z2, 0.7), img0), relmax(w.generate(z1, z2, 0.7), ema0), relmax(w.discriminator(real, True)[0], d0[0]))
+            assert wrecked >= 0.1, wrecked                        # what a stale prepared copy would look like
         w.load_model()
+        tol = max(4 * noise, 1e-3)
         with torch.no_grad():
-            assert torch.equal(w.generator(z1, z2, 0.7), img0), "stale prepared weights after load_model (generator)"
-            assert torch.equal(w.generate(z1, z2, 0.7), ema0), "stale prepared weights after load_model (EMA generator)"
+            assert relmax(w.generator(z1, z2, 0.7), img0) <= tol, "stale prepared weights after load_model (generator)"
+            assert relmax(w.generate(z1, z2, 0.7), ema0) <= tol, "stale prepared weights after load_model (EMA generator)"
             for a, b in zip(w.discriminator(real, True), d0):
-                assert torch.equal(a, b), "stale prepared weights after load_model (discriminator)"
+                assert relmax(a, b) <= tol, "stale prepared weights after load_model (discriminator)"
         # a fresh WORKER (different random init) resumed from the files continues exactly like the one that never stopped
         torch.manual_seed(4)
         from lcgan_amd import worker as worker_mod
@@ -342,7 +349,7 @@ def test_checkpoint_round_trip_on_device(tmp_path):
         for (k, va), (_, vb) in zip(w.discriminator.state_dict().items(), w2.discriminator.state_dict().items()):
             worst = max(worst, float((va - vb).abs().max() / va.abs().max().clamp_min(1e-12)))
         assert worst <= 2e-2, worst                               # Adam with beta1 = 0 steps by lr * sign-like g / |g|: an atomics-order flip moves an entry by ~lr
-        record("checkpoint_on_device", resumed_d_param_max_rel=worst)
+        record("checkpoint_on_device", resumed_d_param_max_rel=worst, forward_repeat_noise=noise, wrecked_weights_error=wrecked)
 
 
 @pytest.mark.parametrize("res,B,freeze", [(512, 8, 4), (1024, 4, 5)])
