@@ -127,6 +127,12 @@ int lcgan_rgb_expand_bwd(const void* gy, const void* y, const float* img, const 
 int lcgan_rgb_reduce_bwd_act(const float* gimg, const void* y, const float* wm, const float* bias, float bias_scale, void* gz,
                              float* gbias, float* gdq, float* gwm, int B, int HW, int C, int Clog, int per_sample, int act, float gain,
                              int dtype, void* stream);
+/* the 2-channel flow layer of a SynthesisBlock (ModulatedConv2d(Cin -> 2, k 3, up 2), custom_layers.py:123,149-151; F.conv_transpose2d
+ * :73-80) as a 1x1 convolution Cin -> 18 on the low-resolution grid (lcgan_conv_fwd with the [18][Cin] weight (ky*3+kx)*2+o) followed by
+ * lcgan_flow_col2im: u[b,2i-1+ky,2j-1+kx,o] += d[b,o] * t[b,i,j,(ky*3+kx)*2+o] (+ bias[o]); lcgan_flow_im2col is its adjoint
+ * (gt = d * gather(gu)) for the backward.  t / gt: [B,H,W,24]; u / gu: [B,2H,2W,8]; d: f32 [B][dstride]. */
+int lcgan_flow_col2im(const void* t, const float* d, const float* bias, void* u, int B, int H, int W, int dstride, int dtype, void* stream);
+int lcgan_flow_im2col(const void* gu, const float* d, void* gt, int B, int H, int W, int dstride, int dtype, void* stream);
 /* layout converts at the NCHW f32 boundary (const input cnn.py:106, flatten custom_layers.py:232 / cnn.py:39) */
 int lcgan_nchw_to_nhwc(const float* src, void* dst, int B, int HW, int C, int Clog, int bcast, int dtype, void* stream);
 int lcgan_nhwc_to_nchw(const void* src, float* dst, int B, int HW, int C, int Clog, int reduce, int dtype, void* stream);

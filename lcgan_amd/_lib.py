@@ -42,6 +42,8 @@ SIGNATURES = {
     "lcgan_rgb_wgrad": [P, P, P, I, I, I, I, I, P],
     "lcgan_rgb_expand_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, F, I, P],
     "lcgan_rgb_reduce_bwd_act": [P, P, P, P, F, P, P, P, P, I, I, I, I, I, I, F, I, P],
+    "lcgan_flow_col2im": [P, P, P, P, I, I, I, I, I, P],
+    "lcgan_flow_im2col": [P, P, P, I, I, I, I, I, P],
     "lcgan_nchw_to_nhwc": [P, P, I, I, I, I, I, I, P],
     "lcgan_nhwc_to_nchw": [P, P, I, I, I, I, I, I, P],
     "lcgan_linear_fwd": [P, P, P, P, I, I, I, F, F, I, F, P],

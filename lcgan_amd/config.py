@@ -19,6 +19,19 @@ def feature_dtype() -> torch.dtype:
     return _feature_dtype
 
 
+import os as _os
+_flow_gemm = _os.environ.get("LCGAN_FLOW_GEMM", "1") != "0"     # A/B switch: the flow layer as 1x1 GEMM + scatter (ops.FlowConvFn) or the generic up-conv
+
+
+def flow_gemm() -> bool:
+    return _flow_gemm
+
+
+def set_flow_gemm(on: bool) -> None:
+    global _flow_gemm
+    _flow_gemm = bool(on)
+
+
 def set_feature_dtype(dtype: torch.dtype) -> None:
     global _feature_dtype
     if dtype not in (torch.bfloat16, torch.float32):

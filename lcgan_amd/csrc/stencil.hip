@@ -1073,6 +1073,69 @@ __global__ void rgb_wgrad_kernel(const float* __restrict__ img, const T* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The 2-channel flow layer of a SynthesisBlock (custom_layers.py:123,149-151: ModulatedConv2d(Cin -> 2, k 3, up 2)) as a GEMM + a
+// scatter: the x2 transposed convolution out[2i-1+ky, 2j-1+kx, o] += x[i,j,:] . w[o,:,ky,kx] (custom_layers.py:73-80) is
+//   t[b,i,j,(ky*3+kx)*2+o] = sum_c s[b,c] x[b,i,j,c] w[o,c,ky,kx]      a 1x1 convolution Cin -> 18 on the LOW-resolution grid (lcgan_conv_fwd), then
+//   u[b,Y,X,o] = d[b,o] * sum over the (<= 4) taps that land on (Y, X) + bias[o]                                (flow_col2im_kernel)
+// so the input is read once at the HBM rate instead of by a 128-output-channel MFMA tile per phase that keeps 2 of its 128 columns
+// (257 us -> the time of one pass over x at 128 x 128 x 256, batch 32).  flow_im2col_kernel is the adjoint gather for the backward.
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void flow_col2im_kernel(const T* __restrict__ t, const float* __restrict__ d, const float* __restrict__ bias,
+                                   T* __restrict__ u, int B, int H, int W, int Ct, int dstride) {
+  const long long total = (long long)B * 4 * H * W;
+  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (gid >= total) return;
+  const int W2 = 2 * W, H2 = 2 * H;
+  const int X = (int)(gid % W2), Y = (int)((gid / W2) % H2), b = (int)(gid / ((long long)W2 * H2));
+  // rows: Y even -> (ky 1, i Y/2); Y odd -> (ky 0, i (Y+1)/2 if inside) and (ky 2, i (Y-1)/2); columns alike
+  int kys[2], is[2], ny = 0, kxs[2], js[2], nx = 0;
+  if (Y & 1) { if ((Y + 1) / 2 < H) { kys[ny] = 0; is[ny++] = (Y + 1) / 2; } kys[ny] = 2; is[ny++] = (Y - 1) / 2; }
+  else { kys[ny] = 1; is[ny++] = Y / 2; }
+  if (X & 1) { if ((X + 1) / 2 < W) { kxs[nx] = 0; js[nx++] = (X + 1) / 2; } kxs[nx] = 2; js[nx++] = (X - 1) / 2; }
+  else { kxs[nx] = 1; js[nx++] = X / 2; }
+  float a0 = 0.f, a1 = 0.f;
+  for (int p = 0; p < ny; ++p)
+    for (int q = 0; q < nx; ++q) {
+      const T* src = t + (((size_t)b * H + is[p]) * W + js[q]) * Ct + (kys[p] * 3 + kxs[q]) * 2;
+      a0 += Feat<T>::ld1(src); a1 += Feat<T>::ld1(src + 1);
+    }
+  F8 o = f8_zero();
+  o.v[0] = a0 * d[(size_t)b * dstride] + (bias ? bias[0] : 0.f);
+  o.v[1] = a1 * d[(size_t)b * dstride + 1] + (bias ? bias[1] : 0.f);
+  Feat<T>::store(u + (size_t)gid * 8, o);
+}
+
+// gt[b,i,j,(ky*3+kx)*2+o] = d[b,o] * gu[b,2i-1+ky,2j-1+kx,o]   (zero outside the image; columns 18 .. Ct-1 zero)
+template <typename T>
+__global__ void flow_im2col_kernel(const T* __restrict__ gu, const float* __restrict__ d, T* __restrict__ gt,
+                                   int B, int H, int W, int Ct, int dstride) {
+  const long long total = (long long)B * H * W;
+  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (gid >= total) return;
+  const int j = (int)(gid % W), i = (int)((gid / W) % H), b = (int)(gid / ((long long)W * H));
+  const float d0 = d[(size_t)b * dstride], d1 = d[(size_t)b * dstride + 1];
+  F8 o[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) o[k] = f8_zero();
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int Y = 2 * i - 1 + ky, X = 2 * j - 1 + kx, r = (ky * 3 + kx) * 2;
+      float g0 = 0.f, g1 = 0.f;
+      if ((unsigned)Y < (unsigned)(2 * H) && (unsigned)X < (unsigned)(2 * W)) {
+        const T* src = gu + (((size_t)b * 2 * H + Y) * 2 * W + X) * 8;
+        g0 = Feat<T>::ld1(src) * d0; g1 = Feat<T>::ld1(src + 1) * d1;
+      }
+      o[r >> 3].v[r & 7] = g0; o[(r + 1) >> 3].v[(r + 1) & 7] = g1;
+    }
+  T* dst = gt + (size_t)gid * Ct;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) Feat<T>::store(dst + 8 * k, o[k]);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Fused backward passes of the two layers that touch the 3-channel image.  Unfused, each is three passes over a full-resolution
 // 128-channel tensor (activation backward -> gz, then rgb_reduce / rgb_wgrad re-reading gz): 2.7 GB of traffic per call at
 // 256 x 256, batch 32, against 1.1 GB here -- gz of the fromRGB layer never reaches memory at all.
@@ -1495,6 +1558,26 @@ int lcgan_rgb_wgrad(const float* img, const void* feat, float* gw, int B, int HW
   dim3 grid(cdiv(HW, P), B);
   ProfScope p(KID_RGB, 0, (double)B * HW * C * (dtype == DT_BF16 ? 2 : 4), s);
   DISPATCH_T(dtype, hipLaunchKernelGGL(rgb_wgrad_kernel<T>, grid, dim3(TPB), 0, s, img, (const T*)feat, gw, HW, C, per_sample, P));
+  return launch_status();
+}
+
+// u [B,2H,2W,8] = d[b,o] * col2im(t) + bias[o]: the scatter half of the flow layer's x2 transposed convolution (see the kernels).
+// t: [B,H,W,24] (18 used: (ky*3+kx)*2+o), d: f32 [B][dstride] (demodulation), bias f32 [2] or NULL
+int lcgan_flow_col2im(const void* t, const float* d, const float* bias, void* u, int B, int H, int W, int dstride, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (B <= 0 || H <= 0 || W <= 0 || dstride < 2) return LCGAN_EINVAL;
+  const long long n = (long long)B * 4 * H * W;
+  ProfScope p(KID_STENCIL, 0, (double)n * (8 + 6) * (dtype == DT_BF16 ? 2 : 4), s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(flow_col2im_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)t, d, bias, (T*)u, B, H, W, 24, dstride));
+  return launch_status();
+}
+// gt [B,H,W,24] = d[b,o] * im2col(gu): the adjoint gather (backward of lcgan_flow_col2im up to the bias / demodulation reductions)
+int lcgan_flow_im2col(const void* gu, const float* d, void* gt, int B, int H, int W, int dstride, int dtype, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (B <= 0 || H <= 0 || W <= 0 || dstride < 2) return LCGAN_EINVAL;
+  const long long n = (long long)B * H * W;
+  ProfScope p(KID_STENCIL, 0, (double)n * (24 + 32) * (dtype == DT_BF16 ? 2 : 4), s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(flow_im2col_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)gu, d, (T*)gt, B, H, W, 24, dstride));
   return launch_status();
 }
 

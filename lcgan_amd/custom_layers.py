@@ -108,6 +108,8 @@ class ModulatedConv2d(nn.Module):
 
     def forward(self, x, s, act=ACT_NONE, gain=1.0):
         assert self.kernel_size == 3 and self.lr_mul == 1.0
+        if self.up == 2 and self.out_features == 2 and act == ACT_NONE and gain == 1.0 and config.flow_gemm():
+            return ops.FlowConvFn.apply(x, self.weight.weight, self.bias, s)     # the 2-channel flow layer: 1x1 GEMM + scatter
         return ops.ModConvFn.apply(x, self.weight.weight, self.bias, s, self.up, act, gain)
 
     def forward_to_rgb(self, x, s):

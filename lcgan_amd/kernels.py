@@ -448,6 +448,25 @@ class HipKernels:
                    _p(gbias), _p(gdq), gwm.data_ptr(), B, H * W, Cc, clog, int(per_sample), act, float(gain), dt_code(y.dtype), self._stream())
         return gz, gbias, gdq, gwm
 
+    # ---- flow layer (ModulatedConv2d(Cin -> 2, up 2)) as 1x1 GEMM + scatter ---------------------------------------------
+    def flow_col2im(self, t: Tensor, d: Tensor, bias: Optional[Tensor]) -> Tensor:
+        """t [B,H,W,24] (18 used) -> u [B,2H,2W,8] = d * col2im(t) + bias"""
+        self._chk(t, d, bias)
+        B, H, W, Ct = t.shape
+        assert Ct == 24 and d.dtype == torch.float32
+        u = torch.empty((B, 2 * H, 2 * W, 8), dtype=t.dtype, device=t.device)
+        self._call("lcgan_flow_col2im", t.data_ptr(), d.data_ptr(), _p(bias), u.data_ptr(), B, H, W, d.shape[1], dt_code(t.dtype), self._stream())
+        return u
+
+    def flow_im2col(self, gu: Tensor, d: Tensor) -> Tensor:
+        """gu [B,2H,2W,8] -> gt [B,H,W,24] = d * im2col(gu) (adjoint of flow_col2im)"""
+        self._chk(gu, d)
+        B, H2, W2, Cc = gu.shape
+        assert Cc == 8 and d.dtype == torch.float32
+        gt = torch.empty((B, H2 // 2, W2 // 2, 24), dtype=gu.dtype, device=gu.device)
+        self._call("lcgan_flow_im2col", gu.data_ptr(), d.data_ptr(), gt.data_ptr(), B, H2 // 2, W2 // 2, d.shape[1], dt_code(gu.dtype), self._stream())
+        return gt
+
     # ---- layout ---------------------------------------------------------------------------------------------
     def nchw_to_nhwc(self, src: Tensor, B: int, calloc: int, dtype: torch.dtype) -> Tensor:
         """src f32 [Bs,Clog,H,W] (Bs == B or 1 = broadcast) -> [B,H,W,calloc]"""

@@ -796,6 +796,69 @@ class ModConvRGBFn(Function):
         return gx, gw, gb, gs, gwm, grb, None, None, None
 
 
+_flow_cache: dict = {}      # id(param) -> [weakref(param), version, epoch, (pw18, pw18T, wsq) per need_lo]
+
+
+def _flow_prep(w: Tensor, c_eq: float, need_lo: bool):
+    """Prepared copies of a flow layer's weight [2, Cin, 3, 3] for FlowConvFn: the [18][Cin] 1x1 weight (row (ky*3+kx)*2+o) in forward and
+    transposed GEMM layout, and the demodulation statistic wsq [2, Cin]; valid for (parameter object, version counter, weight epoch)."""
+    import weakref
+    ent = _flow_cache.get(id(w)) if isinstance(w, torch.nn.Parameter) else None
+    if ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == _weight_epoch and need_lo in ent[3]:
+        return ent[3][need_lo]
+    K = _K()
+    wd = w.detach()
+    w18 = wd.permute(2, 3, 0, 1).reshape(18, wd.shape[1], 1, 1).contiguous()          # torch glue on 9 K values
+    out = (K.prep_weight(w18, c_eq, False, need_lo)[0], K.prep_weight(w18, c_eq, True, need_lo)[0], (wd * c_eq).square().sum(dim=(2, 3)))
+    if isinstance(w, torch.nn.Parameter):
+        if ent is None or ent[0]() is not w or ent[1] != w._version or ent[2] != _weight_epoch:
+            if len(_flow_cache) > 256:
+                _flow_cache.clear()
+            ent = [weakref.ref(w), w._version, _weight_epoch, {}]
+            _flow_cache[id(w)] = ent
+        ent[3][need_lo] = out
+    return out
+
+
+class FlowConvFn(Function):
+    """The flow layer of a SynthesisBlock -- ModulatedConv2d(Cin -> 2, k 3, up 2) with demodulation and bias, no activation
+    (custom_layers.py:123,149; :62-80,85) -- as a 1x1 convolution Cin -> 18 on the LOW-resolution grid followed by the col2im scatter of
+    the transposed convolution (csrc/stencil.hip: flow_col2im): x is read once at the HBM rate; the generic path ran four
+    128-output-channel MFMA phases for 2 useful columns (0.5 ms per generator forward, 0.6 + 0.7 ms in its backward).  First order only."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, s):
+        K = _K()
+        O, Cin, k, _ = w.shape
+        assert O == 2 and k == 3
+        c_eq = 1.0 / math.sqrt(Cin * k * k)
+        s = s.contiguous()
+        pw18, _, wsq = _flow_prep(w, c_eq, _need_lo(x))
+        d = K.demod_fwd(s, wsq, 8)
+        t = K.conv_fwd(x, pw18, 18, 1, 1, pre=s)                                 # [B,H,W,24]
+        u = K.flow_col2im(t, d, bias)                                            # [B,2H,2W,8]
+        ctx.save_for_backward(x, w, bias, s, d, wsq, u)
+        ctx.c_eq = c_eq
+        return u
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gu):
+        K = _K()
+        x, w, bias, s, d, wsq, u = ctx.saved_tensors
+        c_eq = ctx.c_eq
+        Cin = w.shape[1]
+        gu = gu.contiguous()
+        _, gb, gdq = K.act_bwd_reduce(gu, u, ACT_NONE, 1.0, 2, want_gz=False, bias=bias, bias_scale=1.0, want_gbias=True, want_gdq=True)
+        _, pw18T, _ = _flow_prep(w, c_eq, _need_lo(x))
+        gt = K.flow_im2col(gu, d)                                                # [B,H,W,24], demodulation folded in
+        gx, gs = K.conv_bwd_data(gt, pw18T, Cin, 1, 1, post=s, xs=x)             # gx = s * (gt @ W18), gs = sum_p x * (gt @ W18)
+        gwsq = K.demod_bwd(gdq, d, s, wsq, gs)                                   # gs += demod path
+        gw18 = K.conv_wgrad(x, gt, 18, Cin, 1, 1, pre_x=s)                       # [1][18][Cin]
+        gw = gw18.view(3, 3, 2, Cin).permute(2, 3, 0, 1) * c_eq + (2.0 * c_eq * c_eq) * w.detach() * gwsq[:, :, None, None]
+        return gx, gw.contiguous(), gb, gs
+
+
 class Box3ActFn(Function):
     """y = act(box3(x)) * gain  (custom_layers.py:150-151, 154-155)"""
 

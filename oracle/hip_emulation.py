@@ -388,6 +388,28 @@ class EmulatedKernels:
         gwm = gwm.contiguous() if per_sample else gwm.sum(0, keepdim=True).contiguous()
         return z.to(y.dtype), gbias, gdq, gwm
 
+    # ---- flow layer as 1x1 GEMM + scatter (csrc/stencil.hip: flow_col2im / flow_im2col) ---------------------------------
+    @staticmethod
+    def _flow_onehot():
+        w = torch.zeros(18, 2, 3, 3)                       # [(ky*3+kx)*2+o][o'][ky'][kx'] = 1 where all three match
+        for ky in range(3):
+            for kx in range(3):
+                for o in range(2):
+                    w[(ky * 3 + kx) * 2 + o, o, ky, kx] = 1.0
+        return w
+
+    def flow_col2im(self, t, d, bias):
+        up = F.conv_transpose2d(nchw(t)[:, :18], self._flow_onehot(), stride=2, padding=1, output_padding=1)     # out[2i-1+ky] += in * w[ky]
+        u = up * d[:, :2, None, None]
+        if bias is not None:
+            u = u + bias.detach().view(1, 2, 1, 1)
+        return nhwc(u, t.dtype, 8)
+
+    def flow_im2col(self, gu, d):
+        g = nchw(gu)[:, :2] * d[:, :2, None, None]
+        gt = F.conv2d(g, self._flow_onehot(), stride=2, padding=1)                                                # gt[(ky,kx,o)][i] = g[o][2i-1+ky]
+        return nhwc(gt, gu.dtype, 24)
+
     # ---- layout ---------------------------------------------------------------------------------------------
     def nchw_to_nhwc(self, src, B, calloc, dtype):
         s = src.float()

@@ -632,6 +632,55 @@ def test_rgb_fused_backward(H, dtype, per_sample, shape):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 4, 4), (3, 16, 24), (1, 5, 7)])
+def test_flow_col2im_im2col(H, dtype, shape):
+    """the scatter / gather halves of the flow layer's x2 transposed convolution against the emulation, and their adjointness"""
+    B, Hh, W = shape
+    t = feat((B, Hh, W, 24), dtype, 31, 18)
+    d = vec((B, 8), 32)
+    bias = torch.randn(2, generator=torch.Generator().manual_seed(33))
+    u_h, u_e = H.flow_col2im(t.cuda(), d.cuda(), bias.cuda()), E.flow_col2im(t, d, bias)
+    check(u_h, u_e, dtype, "col2im")
+    assert float(u_h[..., 2:].abs().max()) == 0.0
+    gu = feat((B, 2 * Hh, 2 * W, 8), dtype, 34, 2)
+    gt_h, gt_e = H.flow_im2col(gu.cuda(), d.cuda()), E.flow_im2col(gu, d)
+    check(gt_h, gt_e, dtype, "im2col")
+    assert float(gt_h[..., 18:].abs().max()) == 0.0
+    # <col2im(t) - bias, gu> == <t, im2col(gu)>  (d enters both)
+    u0 = E.flow_col2im(t, d, None).double()
+    lhs, rhs = float((u0 * gu.double()).sum()), float((t.double() * gt_e.double()).sum())
+    assert abs(lhs - rhs) <= (2e-2 if dtype == torch.bfloat16 else 1e-5) * max(abs(lhs), 1.0), (lhs, rhs)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 8, 8, 64), (2, 32, 32, 128), (3, 16, 32, 256), (8, 64, 64, 64)])
+def test_flow_layer_gemm_vs_generic(dtype, shape):
+    """ops.FlowConvFn (1x1 GEMM + scatter) against ops.ModConvFn (the generic x2 transposed convolution) on the flow layer's shapes:
+    forward and every gradient, both on the HIP kernels."""
+    from lcgan_amd import config, ops
+    from tests.helpers import install_backend
+    install_backend(None)
+    B, Hh, W, Cin = shape
+    g = torch.Generator().manual_seed(41)
+    x = feat((B, Hh, W, Cin), dtype, 42).cuda()
+    w = torch.nn.Parameter(torch.randn(2, Cin, 3, 3, generator=g).cuda())
+    bias = torch.nn.Parameter((torch.randn(2, generator=g) * 0.1).cuda())
+    s0 = (torch.rand(B, Cin, generator=g) + 0.5).cuda()
+    go = feat((B, 2 * Hh, 2 * W, 8), dtype, 43, 2).cuda()
+    outs = []
+    with config.feature_dtype_as(dtype):
+        for fn in (lambda xx, ss: ops.FlowConvFn.apply(xx, w, bias, ss), lambda xx, ss: ops.ModConvFn.apply(xx, w, bias, ss, 2, 0, 1.0)):
+            xx, ss = x.clone().requires_grad_(True), s0.clone().requires_grad_(True)
+            w.grad = bias.grad = None
+            y = fn(xx, ss)
+            (y.float() * go.float()).sum().backward()
+            outs.append((y.detach(), xx.grad, ss.grad, w.grad.clone(), bias.grad.clone()))
+    for name, a, b in zip(("u", "gx", "gs", "gw", "gb"), *outs):
+        # two different roundings of the same sums in bf16 (t is stored per tap before the scatter): twice the single-kernel tolerance
+        check(a, b.cpu(), dtype if name in ("u", "gx") else (torch.float32 if dtype == torch.float32 else dtype), f"flow {name}", l2_scale=3.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_layout(H, dtype):
     src = torch.randn(3, 13, 4, 4, generator=torch.Generator().manual_seed(81))
     check(H.nchw_to_nhwc(src.cuda(), 3, 16, dtype), E.nchw_to_nhwc(src, 3, 16, dtype), dtype, "to nhwc")
