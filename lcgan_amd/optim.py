@@ -23,13 +23,38 @@ assert _DESC.itemsize == 48
 
 class TensorTable:
     """Device-side table for lcgan_multi_tensor: 48-byte descriptors + (tensor, chunk) index arrays.
-    rows: sequence of (t0, t1, t2, t3, f0, f1) with t* fp32 contiguous tensors of equal numel (or None)."""
+    rows: sequence of (t0, t1, t2, t3, f0, f1) with t* fp32 contiguous tensors of equal numel (or None).
+    The chunk arrays depend only on the tensors' sizes and are uploaded once; `refresh()` re-uploads the descriptors (pointers of
+    the second operand and the two per-row scalars change from step to step: Adam's gradients and bias corrections) through pinned
+    memory, one small asynchronous copy."""
 
     def __init__(self, rows: Sequence[tuple], device):
-        self.entries = list(rows)            # keeps the tensors alive (and feeds the CPU emulation in tests)
-        arr = np.zeros(len(rows), dtype=_DESC)
+        self.device = device
         ct, ci = [], []
         total = 0
+        for i, row in enumerate(rows):
+            n = row[0].numel()
+            nch = (n + MT_CHUNK - 1) // MT_CHUNK
+            ct += [i] * nch
+            ci += list(range(nch))
+            total += n
+        self.total = total
+        self.n_chunks = len(ct)
+        self.chunk_tensor = self._upload(np.asarray(ct, dtype=np.int32))
+        self.chunk_index = self._upload(np.asarray(ci, dtype=np.int32))
+        self._arr = np.zeros(len(rows), dtype=_DESC)
+        self.refresh(rows)
+
+    def _upload(self, a: np.ndarray) -> torch.Tensor:
+        t = torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).copy())
+        if torch.device(self.device).type == "cuda":
+            t = t.pin_memory()                    # (caching host allocator: the block is not reused before the copy below has run)
+        t = t.to(self.device, non_blocking=True)
+        return t.view(torch.int32) if a.dtype == np.int32 else t
+
+    def refresh(self, rows: Sequence[tuple]) -> "TensorTable":
+        self.entries = list(rows)            # keeps the tensors alive (and feeds the CPU emulation in tests)
+        arr = self._arr
         for i, (t0, t1, t2, t3, f0, f1) in enumerate(rows):
             n = t0.numel()
             for t in (t0, t1, t2, t3):
@@ -37,15 +62,8 @@ class TensorTable:
                     assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n
             arr[i] = (t0.data_ptr(), t1.data_ptr() if t1 is not None else 0, t2.data_ptr() if t2 is not None else 0,
                       t3.data_ptr() if t3 is not None else 0, n, f0, f1)
-            nch = (n + MT_CHUNK - 1) // MT_CHUNK
-            ct += [i] * nch
-            ci += list(range(nch))
-            total += n
-        self.total = total
-        self.n_chunks = len(ct)
-        self.descs = torch.from_numpy(arr.view(np.uint8).copy()).to(device, non_blocking=True)
-        self.chunk_tensor = torch.tensor(ct, dtype=torch.int32).to(device, non_blocking=True)
-        self.chunk_index = torch.tensor(ci, dtype=torch.int32).to(device, non_blocking=True)
+        self.descs = self._upload(arr)
+        return self
 
 
 class Adam:
@@ -57,6 +75,7 @@ class Adam:
         self.exp_avg = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
         self.steps = [0] * len(self.params)
+        self._tables = {}                     # which parameters have a gradient (structural: a few sets per run) -> TensorTable
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.params:
@@ -64,7 +83,7 @@ class Adam:
 
     @torch.no_grad()
     def step(self):
-        rows = []
+        rows, key = [], []
         for i, p in enumerate(self.params):
             if p.grad is None:
                 continue                                     # unused / frozen parameter: skipped like torch.optim.Adam does
@@ -74,8 +93,17 @@ class Adam:
             bc2 = 1.0 - self.beta2 ** t
             g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
             rows.append((p.data, g, self.exp_avg[i], self.exp_avg_sq[i], self.lr / bc1, 1.0 / math.sqrt(bc2)))
+            key.append(i)
         if rows:
-            KM.K.multi_tensor(TensorTable(rows, self.params[0].device), MT_ADAM, self.beta1, self.beta2, self.eps)
+            key = tuple(key)
+            tab = self._tables.get(key)
+            if tab is None:
+                if len(self._tables) > 16:
+                    self._tables.clear()
+                tab = self._tables[key] = TensorTable(rows, self.params[0].device)
+            else:
+                tab.refresh(rows)                            # same chunk arrays; new gradient pointers + bias corrections
+            KM.K.multi_tensor(tab, MT_ADAM, self.beta1, self.beta2, self.eps)
             from . import ops
             ops.invalidate_weights(p for p in self.params if p.grad is not None)   # changed behind torch's version counters
 
@@ -90,24 +118,43 @@ class Adam:
             a.copy_(b)
 
 
+class _Bucket:
+    __slots__ = ("params", "views", "flat", "expected", "fired", "launched", "tables")
+
+    def __init__(self, params, views, flat):
+        self.params, self.views, self.flat = params, views, flat
+        self.expected, self.fired, self.launched, self.tables = 0, 0, False, {}
+
+
 class DataParallel(torch.nn.Module):
     """Single-node data parallelism: one process per GPU, full replicas, gradient mean over ranks (what the reference gets
     from DistributedDataParallel, worker.py:88-96).  Exposes `.module` and the `module.`-prefixed state_dict the reference's
-    checkpoints carry.  `sync_gradients()` packs every present gradient into one flat fp32 bucket (one multi-tensor kernel,
-    pre-scaled by 1/world), all-reduces the bucket over RCCL and re-points `.grad` at the bucket so Adam reads it in place.
-    Parameters whose grad is None on this rank are treated as unused (the flag sets are structural in LC-GAN -- projection
-    heads on odd iterations, frozen layers -- hence identical on every rank)."""
+    checkpoints carry.
+
+    Gradients are reduced in BUCKETS (DDP's default 25 MB, walked in reverse registration order = roughly the order in which
+    autograd finishes them) from inside the backward pass: a post-accumulate hook on every parameter counts its bucket down, and the
+    bucket whose last gradient has arrived is packed (one multi-tensor kernel, pre-scaled by 1/world, into its fixed slice of one flat
+    fp32 buffer) and all-reduced asynchronously over RCCL while the backward pass goes on; `.grad` is re-pointed at the slice so Adam
+    reads the reduced values in place.  `sync_gradients()` after the backward launches what is left (buckets that hold parameters the
+    iteration did not use never count down to zero) and returns a handle on all reductions.  Parameters whose grad is None on this rank
+    are treated as unused -- the sets are structural in LC-GAN (projection heads on odd iterations, frozen layers), hence identical on
+    every rank; a bucket without any gradient is not reduced at all."""
+
+    BUCKET_BYTES = 25 << 20
 
     def __init__(self, module: torch.nn.Module, process_group=None, broadcast: bool = True):
         super().__init__()
         self.module = module
         self._pg = process_group
-        self._bucket: Optional[torch.Tensor] = None
-        self._comm_stream = None
+        self._buckets: Optional[List[_Bucket]] = None
+        self._works: list = []
+        self._armed = False                    # counts of the running backward pass are initialised
         if broadcast and self.world_size > 1:
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):     # DDP ctor broadcast of rank-0 state
                     dist.broadcast(t.data, src=0, group=self._pg)
+        if self.world_size > 1:
+            self._build_buckets()
 
     @property
     def world_size(self) -> int:
@@ -121,37 +168,103 @@ class DataParallel(torch.nn.Module):
         new = DataParallel.__new__(DataParallel)
         torch.nn.Module.__init__(new)
         new.module = copy.deepcopy(self.module, memo)
-        new._pg, new._bucket, new._comm_stream = self._pg, None, None
+        new._pg, new._buckets, new._works, new._armed = self._pg, None, [], False     # (the EMA copy never runs a backward pass)
         return new
+
+    # ---- buckets ----------------------------------------------------------------------------------------------------------
+    def _build_buckets(self) -> None:
+        params = list(self.module.parameters())
+        total = sum(p.numel() for p in params)
+        flat = torch.zeros(total, dtype=torch.float32, device=params[0].device)      # holes (unused parameters) stay finite
+        cap = self.BUCKET_BYTES // 4
+        self._buckets, self._bucket_of = [], {}
+        cur, cur_n, off = [], 0, 0
+        groups = []
+        for p in reversed(params):                                # the last layers' gradients arrive first
+            if cur and cur_n + p.numel() > cap:
+                groups.append(cur)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            groups.append(cur)
+        for g in groups:
+            n = sum(p.numel() for p in g)
+            sl, views, o = flat[off:off + n], [], 0
+            for p in g:
+                views.append(sl[o:o + p.numel()].view_as(p))
+                o += p.numel()
+            b = _Bucket(g, views, sl)
+            for p in g:
+                self._bucket_of[id(p)] = b
+                p.register_post_accumulate_grad_hook(self._on_grad)
+            self._buckets.append(b)
+            off += n
+
+    def _arm(self) -> None:
+        for b in self._buckets:
+            b.expected = sum(1 for p in b.params if p.requires_grad)
+            b.fired, b.launched = 0, False
+        self._armed = True
+
+    def _on_grad(self, p: torch.nn.Parameter) -> None:
+        if not self._armed:
+            self._arm()
+        b = self._bucket_of[id(p)]
+        b.fired += 1
+        if b.fired >= b.expected and not b.launched:
+            self._launch(b)
+
+    @torch.no_grad()
+    def _launch(self, b: _Bucket) -> None:
+        b.launched = True
+        rows, key = [], []
+        for i, (p, v) in enumerate(zip(b.params, b.views)):
+            if p.grad is None:
+                continue
+            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            rows.append((v.view(-1), g.view(-1), None, None, 0.0, 0.0))
+            key.append(i)
+        if not rows:
+            return                                              # nothing of this bucket was used: no reduction (heads on odd iterations)
+        key = tuple(key)
+        tab = b.tables.get(key)
+        if tab is None:
+            tab = b.tables[key] = TensorTable(rows, b.flat.device)
+        else:
+            tab.refresh(rows)
+        KM.K.multi_tensor(tab, MT_PACK, 1.0 / self.world_size)
+        self._works.append(dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self._pg, async_op=True))
+        for i in key:
+            b.params[i].grad = b.views[i]
 
     @torch.no_grad()
     def sync_gradients(self, async_op: bool = False):
-        """Mean-all-reduce of the gradients; returns a handle with .wait() (no-op handle for one rank)."""
-        ws = self.world_size
-        if ws == 1:
+        """Mean-all-reduce of the gradients; returns a handle with .wait() (no-op handle for one rank).  Buckets that completed during
+        the backward pass are already in flight; the rest are launched here."""
+        if self.world_size == 1:
             return _Done()
-        used = [p for p in self.module.parameters() if p.grad is not None]
-        if not used:
-            return _Done()
-        total = sum(p.numel() for p in used)
-        if self._bucket is None or self._bucket.numel() < total:
-            self._bucket = torch.empty(sum(p.numel() for p in self.module.parameters()), dtype=torch.float32, device=used[0].device)
-        flat = self._bucket[:total]
-        rows, off, views = [], 0, []
-        for p in used:
-            v = flat[off:off + p.numel()]
-            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-            rows.append((v, g.view(-1), None, None, 0.0, 0.0))
-            views.append(v.view_as(p))
-            off += p.numel()
-        KM.K.multi_tensor(TensorTable(rows, flat.device), MT_PACK, 1.0 / ws)
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self._pg, async_op=True)
-        for p, v in zip(used, views):
-            p.grad = v
+        if not self._armed:
+            self._arm()                                         # (a backward pass that touched no parameter of this network)
+        for b in self._buckets:
+            if not b.launched:
+                self._launch(b)
+        works, self._works, self._armed = self._works, [], False
+        handle = _Works(works)
         if async_op:
-            return work
-        work.wait()
+            return handle
+        handle.wait()
         return _Done()
+
+
+class _Works:
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        return True
 
 
 class _Done:
