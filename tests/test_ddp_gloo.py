@@ -27,6 +27,8 @@ def _rank_main(rank, world, port, out_dir):
     install_backend(EmulatedKernels())
     config.set_feature_dtype(torch.float32)
     res, Bl = 16, 2
+    from lcgan_amd.optim import DataParallel
+    DataParallel.BUCKET_BYTES = 1 << 20                   # this 16 x 16 network is small: 1 MB buckets give the shared layers several
     w = seeded_worker(res, Bl, "cpu", gpus=world)
     assert w.local_batch_size == Bl
     feed = FixedFeed(w, Bl, res, "cpu")
@@ -40,8 +42,30 @@ def _rank_main(rank, world, port, out_dir):
         captured.update({k: (None if p.grad is None else p.grad.clone()) for k, p in w.discriminator.module.named_parameters()})
         real_step()
     w.d_optimizer.step = step
+    # the reduction is bucketed and starts INSIDE the backward pass (post-accumulate hooks): record where each bucket was launched
+    D = w.discriminator
+    launches, in_sync = [], [False]
+    real_launch, real_sync = D._launch, D.sync_gradients
+
+    def launch(b):
+        launches.append((D._buckets.index(b), "sync" if in_sync[0] else "hook", any(p.grad is not None for p in b.params)))
+        real_launch(b)
+
+    def sync(async_op=False):
+        in_sync[0] = True
+        try:
+            return real_sync(async_op=async_op)
+        finally:
+            in_sync[0] = False
+    D._launch, D.sync_gradients = launch, sync
     loss_v = w.train_discriminator(1)                     # odd + R1: projection heads unused -> grad None
     w.flush()                                             # the all-reduce wait + Adam are postponed when N > 1
+    assert len(D._buckets) >= 4, len(D._buckets)
+    assert sorted(i for i, _, _ in launches) == list(range(len(D._buckets)))          # every bucket exactly once
+    hooked = [i for i, where, used in launches if where == "hook" and used]
+    assert len(hooked) >= 3, launches                     # reductions were issued while the backward pass was still running
+    assert hooked == sorted(hooked), launches             # ... in bucket (= reverse registration) order
+    assert any(not used for _, _, used in launches), launches     # the projection heads' buckets carried nothing and were skipped
     torch.save({"grads": captured, "params": {k: v.clone() for k, v in w.discriminator.module.state_dict().items()}, "loss": float(loss_v)},
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
