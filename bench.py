@@ -57,11 +57,12 @@ def flops_per_image(res: int, epoch: int) -> float:
     return 4 * g + (11 if epoch % 8 == 1 else 8) * d
 
 
-def cpu_baseline(res: int, batch: int = 2):
-    """The CPU oracle (oracle/lcgan_ref.py, a port of the reference's fp32 PyTorch path) timed on the host cores.  SURVEY 8(d) asks
-    for a warmed 8-iteration cycle at batch 4 (~5 minutes of CPU); the bounded sample here is ONE warmed iteration of each type
-    (even / odd+R1 / odd: G step + D step, fp32, no optimiser -- Adam + EMA are < 1 % of the CPU step) at `batch` images, from which
-    the cycle mean (4 even + 1 R1 + 3 odd) follows.  `value` is the R1 iteration, the one the GPU line reports."""
+def cpu_baseline(res: int, batch: int = 4, full_cycle: bool = False):
+    """The CPU oracle (oracle/lcgan_ref.py, a port of the reference's fp32 PyTorch path) timed on the host cores at BASELINE
+    configs[0]'s shape (256 x 256, batch 4; SURVEY 8(d) / BASELINE.md section 4).  Default: the bounded sample -- ONE warmed iteration of
+    each type (even / odd+R1 / odd: G step + D step, fp32, no optimiser -- Adam + EMA are < 1 % of the CPU step), ~35 s of CPU work,
+    from which the cycle mean (4 even + 1 R1 + 3 odd) follows.  full_cycle (`--cpu-baseline-cycle`, ~4 minutes): one warm-up cycle of
+    8 iterations, then one timed cycle, as BASELINE.md section 4 words it.  `value` is the R1 iteration, the one the GPU line reports."""
     from oracle import lcgan_ref as O
     from oracle.weights import seeded_state, seeded_tensor
     torch.set_num_threads(min(os.cpu_count() or 1, 16))        # the CPU share of a one-GPU box
@@ -74,13 +75,36 @@ def cpu_baseline(res: int, batch: int = 2):
         O.g_step(GP, DP, res, epoch, z)
         O.d_step(GP, DP, res, epoch, z[:2], real)
         return time.perf_counter() - t0
-    one(1, 1)                                                  # warm-up: thread pool, oneDNN primitives, allocator
-    t = {"even": one(0, batch), "r1": one(1, batch), "odd": one(3, batch)}
-    cycle = (4 * t["even"] + t["r1"] + 3 * t["odd"]) / 8
+    if full_cycle:
+        for e in range(8):
+            one(e, batch)                                      # warm-up cycle
+        per = [one(8 + e, batch) for e in range(8)]            # epoch 8..15: 4 even, 1 odd+R1 (9), 3 odd
+        t = {"even": sum(per[0::2]) / 4, "r1": per[1], "odd": (per[3] + per[5] + per[7]) / 3}
+        cycle = sum(per) / 8
+        sample = f"one warm-up cycle, then one timed 8-iteration cycle (epoch 8..15) at {res}x{res}, batch {batch}"
+    else:
+        one(1, 1)                                              # warm-up: thread pool, oneDNN primitives, allocator
+        t = {"even": one(0, batch), "r1": one(1, batch), "odd": one(3, batch)}
+        cycle = (4 * t["even"] + t["r1"] + 3 * t["odd"]) / 8
+        sample = f"one warmed iteration per type at {res}x{res}, batch {batch}"
     return {"value": batch / t["r1"], "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"one warmed iteration per type (G step + D step, fp32, no optimiser) at {res}x{res}, batch {batch}: "
-                      f"even {t['even']:.1f} s, odd+R1 {t['r1']:.1f} s, odd {t['odd']:.1f} s",
+            "sample": f"{sample} (G step + D step, fp32, no optimiser): even {t['even']:.1f} s, odd+R1 {t['r1']:.1f} s, odd {t['odd']:.1f} s",
             "cycle_mean_value": batch / cycle, "seconds_per_type": {k: round(v, 2) for k, v in t.items()}}
+
+
+def committed_traffic():
+    """HBM bytes per launch of the dominant kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate runs, FETCH_SIZE x 2 on gfx950: scripts/pmc_traffic.py -> profiles/r03_pmc_traffic.json).  PMC counters cannot be read
+    inside a timed run, so the bench line quotes the profiled figure with the commit it was taken at; None when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        fam = d.get("conv_halo")
+        return {"bytes_per_launch": fam["bytes_per_launch"], "kernel": "conv_halo_kernel", "launches": fam["launches"],
+                "source": "profiles/r03_pmc_traffic.json", "commit": d.get("_commit")}
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def main():
@@ -96,6 +120,7 @@ def main():
     ap.add_argument("--freezeD-layer", type=int, default=-1,
                     help="BASELINE config 4: freeze the first discriminator layers (main.py --freezeD_layer, with freezeD_start 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-cycle", action="store_true", help="time a full warmed 8-iteration cycle of the CPU oracle at batch 4 (~4 minutes) instead of one iteration per type")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--launch-table", default="", help="write the per-launch table (HIP events, conv geometry tags) of one more iteration here")
     ap.add_argument("--no-cycle", action="store_true", help="skip the extra 8-iteration cycle (epoch 8..15) reported beside the R1 line")
@@ -196,11 +221,14 @@ def main():
         K.prof_enable(False)
         ig, wg = prof["conv_igemm"], prof["conv_wgrad"]
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
-        # `traffic` (HBM bytes per launch) needs PMC passes under rocprofv3 and cannot be measured inside this run: null here; the
-        # separately profiled figure (scripts/pmc_traffic.py -> profiles/*_pmc_traffic.json, FETCH_SIZE x2 on gfx950) is in DESIGN.md
+        # `traffic` (HBM bytes per launch) needs PMC passes under rocprofv3 and cannot be measured inside this run: the separately
+        # profiled figure of the same command (scripts/pmc_traffic.py -> profiles/r03_pmc_traffic.json, FETCH_SIZE x2 on gfx950) is quoted
+        # with its commit; only for the configuration it was profiled on (256 x 256, batch 32, bf16)
+        tr = committed_traffic() if (a.res == 256 and a.batch == 32 and a.dtype == "bf16" and world == 1) else None
         out["roofline"] = {"bound": "mfma", "kernel": "conv_halo_kernel + conv_igemm_kernel (forward / data-gradient convolutions)",
                            "achieved": ach, "peak": PEAK_BF16_DENSE / 1e12,
-                           "unit": "TFLOP/s", "frac": ach / (PEAK_BF16_DENSE / 1e12), "traffic": None,
+                           "unit": "TFLOP/s", "frac": ach / (PEAK_BF16_DENSE / 1e12), "traffic": tr["bytes_per_launch"] if tr else None,
+                           "traffic_source": tr,
                            "launches": ig["count"], "avg_launch_ms": ig["ms"] / max(ig["count"], 1),
                            "flops_per_launch": ig["flops"] / max(ig["count"], 1)}
         out["kernel_ms"] = {k: round(v["ms"], 3) for k, v in prof.items()}
@@ -224,7 +252,7 @@ def main():
         if a.launch_table:
             loader.train_iteration(w, args, epoch_of(a.warmup + a.steps + 1))
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.res)
+        out["cpu_baseline"] = cpu_baseline(a.res, full_cycle=a.cpu_baseline_cycle)
     if world > 1:
         w.flush()                                          # the roofline iteration's postponed all-reduce wait + Adam
         torch.cuda.synchronize()

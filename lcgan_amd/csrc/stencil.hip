@@ -12,12 +12,22 @@
 //   mbstd           MinibatchStdLayer                                  custom_layers.py:243-256
 //   rgb_*           1x1 convs touching the 3-channel NCHW image        cnn.py:20 ; custom_layers.py:175,181
 #include "common.h"
+#include <cstdio>
 
 namespace {
 
 constexpr int TPB = 256;
 
 static inline dim3 grid1d(long long n) { return dim3((unsigned)((n + TPB - 1) / TPB)); }
+
+// per-launch tag of the profiling table (bench.py --launch-table): kernel name + shape; formatted only while profiling is on
+struct Tag {
+  char s[96];
+  Tag(const char* name, int B, int H, int W, int C) {
+    s[0] = 0;
+    if (lcgan_prof_active()) snprintf(s, sizeof(s), "%s B%d %dx%d C%d", name, B, H, W, C);
+  }
+};
 
 // ------------------------------------------------------------------------------------------------------------
 // box filter (3x3 mean, zero padding, always /9) fused with activation
@@ -1353,7 +1363,8 @@ int lcgan_box3_act(const void* x, void* y, int B, int H, int W, int C, int act, 
   hipStream_t s = (hipStream_t)stream;
   if (C & 7) return LCGAN_EINVAL;
   const long long n = (long long)B * H * W * (C / 8);
-  ProfScope p(KID_STENCIL, 0, (double)n * 8 * 2 * (dtype == DT_BF16 ? 2 : 4), s);
+  Tag tg("box3_act", B, H, W, C);
+  ProfScope p(KID_STENCIL, 0, (double)n * 8 * 2 * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
   const int BOX_RH = box_rh(n);
   const long long nthr = (long long)B * ((H + BOX_RH - 1) / BOX_RH) * W * (C / 8);
   DISPATCH_T(dtype, hipLaunchKernelGGL(box3_act_kernel<T>, grid1d(nthr), dim3(TPB), 0, s, (const T*)x, (T*)y, B, H, W, C, act, gain, BOX_RH));
@@ -1364,7 +1375,8 @@ int lcgan_box3_act_bwd(const void* gy, const void* y, void* gx, int B, int H, in
   hipStream_t s = (hipStream_t)stream;
   if (C & 7) return LCGAN_EINVAL;
   const long long n = (long long)B * H * W * (C / 8);
-  ProfScope p(KID_STENCIL, 0, (double)n * 8 * 3 * (dtype == DT_BF16 ? 2 : 4), s);
+  Tag tg("box3_act_bwd", B, H, W, C);
+  ProfScope p(KID_STENCIL, 0, (double)n * 8 * 3 * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
   const int BOX_RH = box_rh(n);
   const long long nthr = (long long)B * ((H + BOX_RH - 1) / BOX_RH) * W * (C / 8);
   DISPATCH_T(dtype, hipLaunchKernelGGL(box3_act_bwd_kernel<T>, grid1d(nthr), dim3(TPB), 0, s, (const T*)gy, (const T*)y, (T*)gx, B, H, W, C, act, gain, BOX_RH));
@@ -1377,7 +1389,8 @@ int lcgan_box3_actbwd_reduce(const void* gy, const void* y, void* gz, float* gbi
   hipStream_t s = (hipStream_t)stream;
   if ((C & 7) || Clog > C) return LCGAN_EINVAL;
   const long long n = (long long)B * H * W * (C / 8);
-  ProfScope p(KID_ACT_BWD, 0, (double)n * 8 * 3 * (dtype == DT_BF16 ? 2 : 4), s);
+  Tag tg("box3_actbwd_reduce", B, H, W, C);
+  ProfScope p(KID_ACT_BWD, 0, (double)n * 8 * 3 * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
   // strip height: the tallest that still leaves ~128K (32 rows) / ~64K (16 rows) threads (scripts/ab_boxb.py: 77 -> 48 us at
   // 4 x 256 x 256 x 128, 43 -> 35 us at 32 x 32 x 32 x 512; below that 8 rows win)
   const int rh = n / 32 >= (1 << 17) ? 32 : (n / 16 >= (1 << 16) ? 16 : 8);
@@ -1391,7 +1404,8 @@ int lcgan_up2box(const void* x, const void* residual, void* y, int B, int H, int
   hipStream_t s = (hipStream_t)stream;
   if (C & 7) return LCGAN_EINVAL;
   const long long n = (long long)B * H * W * 4 * (C / 8);
-  ProfScope p(KID_STENCIL, 0, (double)n * 8 * (residual ? 2.25 : 1.25) * (dtype == DT_BF16 ? 2 : 4), s);
+  Tag tg("up2box", B, 2 * H, 2 * W, C);
+  ProfScope p(KID_STENCIL, 0, (double)n * 8 * (residual ? 2.25 : 1.25) * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
   DISPATCH_T(dtype, hipLaunchKernelGGL(up2box_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)x, (const T*)residual, (T*)y, B, H, W, C));
   return launch_status();
 }
@@ -1400,7 +1414,8 @@ int lcgan_up2box_bwd(const void* gy, void* gx, int B, int H, int W, int C, int d
   hipStream_t s = (hipStream_t)stream;
   if (C & 7) return LCGAN_EINVAL;
   const long long n = (long long)B * H * W * (C / 8);
-  ProfScope p(KID_STENCIL, 0, (double)n * 8 * 5 * (dtype == DT_BF16 ? 2 : 4), s);
+  Tag tg("up2box_bwd", B, 2 * H, 2 * W, C);
+  ProfScope p(KID_STENCIL, 0, (double)n * 8 * 5 * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
   DISPATCH_T(dtype, hipLaunchKernelGGL(up2box_bwd_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)gy, (T*)gx, B, H, W, C));
   return launch_status();
 }
@@ -1409,7 +1424,8 @@ int lcgan_avgpool2(const void* x, void* y, int B, int H, int W, int C, int dtype
   hipStream_t s = (hipStream_t)stream;
   if ((C & 7) || (H & 1) || (W & 1)) return LCGAN_EINVAL;
   const long long n = (long long)B * (H / 2) * (W / 2) * (C / 8);
-  ProfScope p(KID_STENCIL, 0, (double)n * 8 * 5 * (dtype == DT_BF16 ? 2 : 4), s);
+  Tag tg("avgpool2", B, H, W, C);
+  ProfScope p(KID_STENCIL, 0, (double)n * 8 * 5 * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
   DISPATCH_T(dtype, hipLaunchKernelGGL(avgpool2_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)x, (T*)y, B, H, W, C));
   return launch_status();
 }
@@ -1418,7 +1434,8 @@ int lcgan_avgpool2_bwd(const void* gy, void* gx, int B, int H, int W, int C, int
   hipStream_t s = (hipStream_t)stream;
   if ((C & 7) || (H & 1) || (W & 1)) return LCGAN_EINVAL;
   const long long n = (long long)B * H * W * (C / 8);
-  ProfScope p(KID_STENCIL, 0, (double)n * 8 * 1.25 * (dtype == DT_BF16 ? 2 : 4), s);
+  Tag tg("avgpool2_bwd", B, H, W, C);
+  ProfScope p(KID_STENCIL, 0, (double)n * 8 * 1.25 * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
   DISPATCH_T(dtype, hipLaunchKernelGGL(avgpool2_bwd_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)gy, (T*)gx, B, H, W, C));
   return launch_status();
 }
@@ -1430,7 +1447,8 @@ int lcgan_act_bwd_reduce(const void* gy, const void* y, void* gz, const float* b
   if ((C & 7) || C / 8 > TPB || Clog > C) return LCGAN_EINVAL;
   const int P = reduce_P(HW, B);
   dim3 grid(cdiv(HW, P), B);
-  ProfScope p(KID_ACT_BWD, 0, (double)B * HW * C * (gz ? 3 : 2) * (dtype == DT_BF16 ? 2 : 4), s);
+  Tag tg(gdq ? (gz ? "act_bwd_reduce+gdq" : "act_reduce+gdq") : (gz ? "act_bwd_reduce" : "act_reduce"), B, HW, 1, C);
+  ProfScope p(KID_ACT_BWD, 0, (double)B * HW * C * (gz ? 3 : 2) * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
   if (gdq) { DISPATCH_T(dtype, hipLaunchKernelGGL((act_bwd_reduce_kernel<T, true>), grid, dim3(TPB), 0, s, (const T*)gy, (const T*)y, (T*)gz,
                                                  bias, bias_scale, gbias, gdq, HW, C, Clog, act, gain, P)); }
   else { DISPATCH_T(dtype, hipLaunchKernelGGL((act_bwd_reduce_kernel<T, false>), grid, dim3(TPB), 0, s, (const T*)gy, (const T*)y, (T*)gz,
@@ -1454,7 +1472,8 @@ int lcgan_warp_fwd(const void* x, const void* flow, void* y, int B, int H, int W
   hipStream_t s = (hipStream_t)stream;
   if ((C & 7) || H < 2 || W < 2) return LCGAN_EINVAL;
   const long long n = (long long)B * H * W * (C / 8);
-  ProfScope p(KID_WARP_FWD, 0, (double)n * 8 * 2 * (dtype == DT_BF16 ? 2 : 4), s);
+  Tag tg("warp_fwd", B, H, W, C);
+  ProfScope p(KID_WARP_FWD, 0, (double)n * 8 * 2 * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
   DISPATCH_T(dtype, hipLaunchKernelGGL(warp_fwd_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)x, (const T*)flow, (T*)y, B, H, W, C, scale));
   return launch_status();
 }
@@ -1471,7 +1490,8 @@ int lcgan_warp_bwd(const void* gy, const void* x, const void* flow, void* gx, vo
   if ((C & 7) || !pow2_le64(C / 8) || H < 2 || W < 2 || (long long)B * H * W * 16 >= (1ll << 31)) return LCGAN_EINVAL;
   const long long npix = (long long)B * H * W, n = npix * (C / 8);
   const double eb = dtype == DT_BF16 ? 2 : 4;
-  ProfScope p(KID_WARP_BWD, 0, (double)n * 8 * 4 * eb + (double)npix * 16 * 8 * 2, s);
+  Tag tg("warp_bwd", B, H, W, C);
+  ProfScope p(KID_WARP_BWD, 0, (double)n * 8 * 4 * eb + (double)npix * 16 * 8 * 2, s, tg.s);
   hipMemsetAsync(ws_cnt, 0, (size_t)(npix + 1) * sizeof(int), s);
   const int ntiles = cdiv(npix + 1, SCAN_TILE);
   DISPATCH_T(dtype, {
@@ -1525,7 +1545,8 @@ int lcgan_rgb_expand(const float* img, const float* w, const float* bias, float 
   hipStream_t s = (hipStream_t)stream;
   if ((C & 7) || C / 8 > TPB) return LCGAN_EINVAL;
   const long long n = (long long)B * HW * (C / 8);
-  ProfScope p(KID_RGB, 0, (double)n * 8 * (pooled ? 1.25 : 1.0) * (dtype == DT_BF16 ? 2 : 4), s);
+  Tag tg(pooled ? "rgb_expand+pool" : "rgb_expand", B, HW, 1, C);
+  ProfScope p(KID_RGB, 0, (double)n * 8 * (pooled ? 1.25 : 1.0) * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
   if (pooled) {
     if (W <= 0 || (W & 1) || HW % W || ((HW / W) & 1)) return LCGAN_EINVAL;
     const int PBq = 64;
@@ -1544,7 +1565,8 @@ int lcgan_rgb_reduce(const void* x, const float* w, const float* bias, float bia
   hipStream_t s = (hipStream_t)stream;
   if ((C & 7) || !pow2_le64(C / 8)) return LCGAN_EINVAL;
   const long long n = (long long)B * HW * (C / 8);
-  ProfScope p(KID_RGB, 0, (double)n * 8 * (dtype == DT_BF16 ? 2 : 4), s);
+  Tag tg("rgb_reduce", B, HW, 1, C);
+  ProfScope p(KID_RGB, 0, (double)n * 8 * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
   const int PB = 256;
   DISPATCH_T(dtype, hipLaunchKernelGGL(rgb_reduce_kernel<T>, dim3(cdiv(HW, PB), B), dim3(TPB), 0, s, (const T*)x, w, bias, bias_scale, img,
                                        HW, C, per_sample, PB));
@@ -1556,7 +1578,8 @@ int lcgan_rgb_wgrad(const float* img, const void* feat, float* gw, int B, int HW
   if ((C & 7) || C / 8 > TPB) return LCGAN_EINVAL;
   const int P = reduce_P(HW, B);
   dim3 grid(cdiv(HW, P), B);
-  ProfScope p(KID_RGB, 0, (double)B * HW * C * (dtype == DT_BF16 ? 2 : 4), s);
+  Tag tg("rgb_wgrad", B, HW, 1, C);
+  ProfScope p(KID_RGB, 0, (double)B * HW * C * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
   DISPATCH_T(dtype, hipLaunchKernelGGL(rgb_wgrad_kernel<T>, grid, dim3(TPB), 0, s, img, (const T*)feat, gw, HW, C, per_sample, P));
   return launch_status();
 }
@@ -1589,7 +1612,8 @@ int lcgan_rgb_expand_bwd(const void* gy, const void* y, const float* img, const 
   if ((C & 7) || !pow2_le64(C / 8) || Clog > C || (gw && !img)) return LCGAN_EINVAL;
   const int P = reduce_P(HW, B);
   dim3 grid(cdiv(HW, P), B);
-  ProfScope p(KID_RGB, 0, (double)B * HW * C * (act != ACT_NONE ? 2 : 1) * (dtype == DT_BF16 ? 2 : 4), s);
+  Tag tg("rgb_expand_bwd", B, HW, 1, C);
+  ProfScope p(KID_RGB, 0, (double)B * HW * C * (act != ACT_NONE ? 2 : 1) * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
   DISPATCH_T(dtype, hipLaunchKernelGGL(rgb_expand_bwd_kernel<T>, grid, dim3(TPB), 0, s, (const T*)gy, (const T*)y, img, w, gimg, gw, gbias,
                                        HW, C, Clog, per_sample, act, gain, P));
   return launch_status();
@@ -1604,7 +1628,8 @@ int lcgan_rgb_reduce_bwd_act(const float* gimg, const void* y, const float* wm, 
   if ((C & 7) || C / 8 > TPB || Clog > C || !gwm || !gz) return LCGAN_EINVAL;
   const int P = reduce_P(HW, B);
   dim3 grid(cdiv(HW, P), B);
-  ProfScope p(KID_RGB, 0, (double)B * HW * C * 2 * (dtype == DT_BF16 ? 2 : 4), s);
+  Tag tg("rgb_reduce_bwd_act", B, HW, 1, C);
+  ProfScope p(KID_RGB, 0, (double)B * HW * C * 2 * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
   DISPATCH_T(dtype, hipLaunchKernelGGL(rgb_reduce_bwd_act_kernel<T>, grid, dim3(TPB), 0, s, gimg, (const T*)y, wm, bias, bias_scale, (T*)gz,
                                        gbias, gdq, gwm, HW, C, Clog, per_sample, act, gain, P));
   return launch_status();

@@ -43,7 +43,10 @@ def parse_args(argv=None):
         parser.add_argument("--" + name, type=typ, default=default, help=help_)
     parser.add_argument("--best", default=False, action="store_true", help="load the *_best checkpoints")
     parser.add_argument("--feature_dtype", choices=["bf16", "f32", "fp8"], default="bf16",
-                        help="feature-map dtype of the HIP path (fp8: bf16 feature maps, MX-fp8 operands on the eligible convolutions)")
+                        help="feature-map dtype of the HIP path.  bf16: the benchmark configuration; f32: parity mode (matches the reference's fp32 "
+                             "results within 1e-3, ~7x slower); fp8: EXPERIMENTAL (BASELINE configs[4]) -- bf16 feature maps with MX-fp8 operands on the "
+                             "stride-1 forward / data-gradient convolutions; not faster than bf16 and ~0.15 relative L2 off the fp32 gradients "
+                             "(DESIGN.md section 2); the R1 penalty's create_graph pass stays bf16")
     return check_args(parser.parse_args(argv))
 
 

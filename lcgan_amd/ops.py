@@ -40,16 +40,36 @@ def _need_lo(x: Tensor) -> bool:
 # input) is untouched, so the second backward still reaches the parameters.  The autograd engine runs these backward()s on its own
 # device thread, hence a plain module global (autograd.grad blocks until they are done).
 _inputs_only = False
+_inputs_only_task = None     # id of the autograd graph task that runs under the flag (torch._C._current_graph_task_id)
 
 
 class inputs_only:
     def __enter__(self):
-        global _inputs_only
-        self.prev, _inputs_only = _inputs_only, True
+        global _inputs_only, _inputs_only_task
+        self.prev, _inputs_only = (_inputs_only, _inputs_only_task), True
+        _inputs_only_task = None
 
     def __exit__(self, *exc):
-        global _inputs_only
-        _inputs_only = self.prev
+        global _inputs_only, _inputs_only_task
+        _inputs_only, _inputs_only_task = self.prev
+
+
+def _inputs_only_here() -> bool:
+    """The flag, as seen from inside a backward function.  It is a process global read on the autograd engine's thread: correct while ONE
+    backward pass runs at a time (autograd.grad blocks; a WORKER is driven by one thread).  Two passes that overlap -- a second
+    thread calling backward() while loss.cal_derivative is inside autograd.grad -- would silently lose parameter gradients, so the
+    first backward function that sees the flag pins the graph task it belongs to and any other graph task that sees it fails loudly."""
+    global _inputs_only_task
+    if not _inputs_only:
+        return False
+    tid = getattr(torch._C, "_current_graph_task_id", lambda: -1)()
+    if tid >= 0:
+        if _inputs_only_task is None:
+            _inputs_only_task = tid
+        elif tid != _inputs_only_task:
+            raise RuntimeError("two backward passes overlap while ops.inputs_only is active (loss.cal_derivative): the parameter "
+                               "gradients of one of them would be dropped; run them one at a time")
+    return True
 
 
 class _NoGraphCtx:
@@ -74,7 +94,7 @@ def _ap(fn, *args):
 
 def _wants(ctx, i: int) -> bool:
     """does this backward owe a gradient for PARAMETER input i?"""
-    return ctx.needs_input_grad[i] and not _inputs_only
+    return ctx.needs_input_grad[i] and not _inputs_only_here()
 
 
 # ---- prepared-weight cache -------------------------------------------------------------------------------------------
@@ -187,8 +207,11 @@ def _use_fp8(x: Tensor, k: int, stride: int) -> bool:
     """MX-fp8 operands for this convolution launch?  (config.conv_operands() == "fp8": BASELINE configs[4]; the stride-1 3x3 / 1x1 forward
     and data-gradient launches on grids of at least 16 x 16 positions -- 60 % of the step's FLOPs; everything else stays bf16)"""
     from . import config
-    return (config.conv_operands() == "fp8" and x.dtype == torch.bfloat16 and stride == 1 and x.shape[1] >= 16 and x.shape[2] >= 16
-            and x.shape[3] >= 64)
+    if config.conv_operands() != "fp8" or x.dtype != torch.bfloat16 or stride != 1 or x.shape[1] < 16 or x.shape[2] < 16 or x.shape[3] < 64:
+        return False
+    # the R1 penalty (loss.py:18-34) squares data gradients: its create_graph pass stays bf16 (e4m3 carries ~4 % noise per layer)
+    in_backward = getattr(torch._C, "_current_graph_task_id", lambda: -1)() >= 0
+    return not (_inputs_only or (in_backward and torch.is_grad_enabled()))
 
 
 # =====================================================================================================

@@ -332,3 +332,22 @@ def test_fid_evaluate_with_a_pluggable_feature_network(tmp_path):
     extractor = lambda img: torch.nn.functional.avg_pool2d(img.float(), 4).flatten(1)[:, :12]
     v = w.fid_evaluate(extractor, num_batches=6)
     assert np.isfinite(v) and v > 0 and w.best_fid == v
+
+
+def test_inputs_only_flag_rejects_an_overlapping_backward_pass():
+    """ops.inputs_only (loss.cal_derivative's only_inputs=True) is a process global read on autograd's thread: a second backward pass
+    that runs while it is set must fail loudly instead of silently dropping its parameter gradients."""
+    from lcgan_amd import ops
+    from lcgan_amd.kernels import ACT_NONE
+    w = torch.nn.Parameter(seeded_tensor((8, 8), 1))
+    x1, x2 = seeded_tensor((2, 8), 2).requires_grad_(True), seeded_tensor((2, 8), 3).requires_grad_(True)
+    y1 = ops.LinearFn.apply(x1, w, None, 1.0, 0.0, ACT_NONE, 1.0).sum()
+    y2 = ops.LinearFn.apply(x2, w, None, 1.0, 0.0, ACT_NONE, 1.0).sum()
+    with ops.inputs_only():
+        (g1,) = torch.autograd.grad(y1, x1, retain_graph=True)          # pins its graph task; weight gradient skipped
+        assert w.grad is None and g1 is not None
+        with pytest.raises(RuntimeError, match="overlap"):
+            y2.backward()                                               # another graph task under the same flag
+    w.grad = None
+    y2.backward()                                                       # outside the flag: ordinary backward, weight gradient formed
+    assert w.grad is not None
