@@ -59,6 +59,62 @@ template <> struct Feat<__bf16> {
   static __device__ __forceinline__ float rnd(float v) { return (float)(__bf16)v; }
 };
 
+// ---- raw buffer loads: resource in scalar registers + ONE 32-bit byte offset per lane (no 64-bit address arithmetic in vector
+// registers; tensors addressed this way are < 4 GB, checked by the launchers) ---------------------------------------------------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
+}
+template <typename T> __device__ __forceinline__ F8 buf_load8(__amdgpu_buffer_rsrc_t r, unsigned byte_off);
+template <> __device__ __forceinline__ F8 buf_load8<__bf16>(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const bf16x8 a = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+  F8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o.v[i] = (float)a[i];
+  return o;
+}
+template <> __device__ __forceinline__ F8 buf_load8<float>(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+  const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off + 16, 0, 0));
+  F8 o; o.v[0]=a[0]; o.v[1]=a[1]; o.v[2]=a[2]; o.v[3]=a[3]; o.v[4]=b[0]; o.v[5]=b[1]; o.v[6]=b[2]; o.v[7]=b[3];
+  return o;
+}
+// 8-channel dot product of two vectors as loaded (no unpacking for bf16: four v_dot2c_f32_bf16, exact products, f32 accumulation)
+template <typename T> struct Vec8;
+template <> struct Vec8<__bf16> {
+  typedef bf16x8 Raw;
+  static __device__ __forceinline__ Raw load(const __bf16* p) { return *(const bf16x8*)p; }
+  static __device__ __forceinline__ Raw buf(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); }
+  static __device__ __forceinline__ float dot(const Raw& a, const Raw& b) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{a[2 * i], a[2 * i + 1]}, bf16x2{b[2 * i], b[2 * i + 1]}, d, false);
+    return d;
+  }
+};
+template <> struct Vec8<float> {
+  typedef F8 Raw;
+  static __device__ __forceinline__ Raw load(const float* p) { f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+    F8 r; r.v[0]=a[0]; r.v[1]=a[1]; r.v[2]=a[2]; r.v[3]=a[3]; r.v[4]=b[0]; r.v[5]=b[1]; r.v[6]=b[2]; r.v[7]=b[3]; return r; }
+  static __device__ __forceinline__ Raw buf(__amdgpu_buffer_rsrc_t r, unsigned off) { return buf_load8<float>(r, off); }
+  static __device__ __forceinline__ float dot(const Raw& a, const Raw& b) {
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d += a.v[i] * b.v[i];
+    return d;
+  }
+};
+
+// n / d and n % d for the index decompositions of the elementwise kernels: d is a power of two in every LC-GAN shape (shift >= 0:
+// one shift / mask instead of a 32-bit multiply-high sequence); other sizes take the division
+struct FastDiv {
+  unsigned d; int shift;
+  __host__ __device__ FastDiv() : d(1), shift(0) {}
+  __host__ explicit FastDiv(unsigned dd) : d(dd), shift(-1) { for (int s = 0; s < 31; ++s) if ((1u << s) == dd) shift = s; }
+  __device__ __forceinline__ unsigned div(unsigned n) const { return shift >= 0 ? n >> shift : n / d; }
+  __device__ __forceinline__ unsigned mod(unsigned n) const { return shift >= 0 ? n & (d - 1) : n % d; }
+};
+
 __device__ __forceinline__ F8 f8_zero() { F8 r;
 #pragma unroll
   for (int i = 0; i < 8; ++i) r.v[i] = 0.f;

@@ -146,9 +146,10 @@ __global__ void box3_actbwd_reduce_kernel(const T* __restrict__ gy, const T* __r
 // forms gy * act'(y) for its OWN column only and takes the neighbours' from the lanes nvec away; only the wave's first / last
 // column still load their outer neighbour: 2 + 2 * (2 nvec / 64) vector loads per output row instead of 6 (the kernel is bound by
 // load issue, not by HBM: 3.7 TB/s against the 5 TB/s of the 2-load activation backward).
-template <typename T>
+template <typename T, int ACT>                                     // ACT: compile-time activation, -1 = the run-time argument (see rgb_expand_kernel)
 __global__ void box3_act_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ y, T* __restrict__ gx,
-                                    int B, int H, int W, int C, int act, float gain, int BOX_RH) {
+                                    int B, int H, int W, int C, int act_rt, float gain, int BOX_RH) {
+  const int act = ACT >= 0 ? ACT : act_rt;
   const int nvec = C >> 3;
   const int strips = (H + BOX_RH - 1) / BOX_RH;
   const long long total = (long long)B * strips * W * nvec;
@@ -460,46 +461,67 @@ __device__ __forceinline__ void warp_coords(const T* flow, size_t pix, int h, in
 
 // Branch-free taps: out-of-range taps are clamped to a valid address and given weight 0, so the 16 loads issue back to back
 // (the version with a bounds branch per tap spent ~70 % of its 1300 instructions on address arithmetic and exec-mask branches).
+// Round 3: the kernel was vector-ALU-bound, not memory-bound (1 150 instructions per output vector, 760 of them VALU, of which the
+// 16 x (unpack + 8 FMAs) are 200): taps are raw buffer loads (scalar resource + one 32-bit byte offset = row part + column part),
+// index decompositions are shifts for the power-of-two sizes, products are 24-bit multiplies.
+// (Walking the pixels of a block as 4 x 4 tiles instead of a run of one image row -- a 7 x 7 instead of a 4 x 19 bicubic footprint per 16
+// output pixels -- was measured: 0 ... +12 % SLOWER on the forward kernel, -4 % on the backward; not kept.)
+struct WarpDims {
+  FastDiv nvec, W, H;
+  __device__ __forceinline__ void pixel(unsigned pix, unsigned& b, unsigned& h, unsigned& w) const {
+    w = W.mod(pix); const unsigned t1 = W.div(pix); h = H.mod(t1); b = H.div(t1);
+  }
+};
+static inline WarpDims warp_dims(int C, int H, int W) {
+  WarpDims dm; dm.nvec = FastDiv((unsigned)(C / 8)); dm.W = FastDiv((unsigned)W); dm.H = FastDiv((unsigned)H);
+  return dm;
+}
 template <typename T>
-__global__ void warp_fwd_kernel(const T* __restrict__ x, const T* __restrict__ flow, T* __restrict__ y,
-                                int B, int H, int W, int C, float scale) {
-  const int nvec = C >> 3;
-  const long long total = (long long)B * H * W * nvec;
-  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
+__global__ __launch_bounds__(256) void warp_fwd_kernel(const T* __restrict__ x, const T* __restrict__ flow, T* __restrict__ y,
+                                                       int B, int H, int W, int C, float scale, WarpDims dm) {
+  const unsigned total = (unsigned)B * H * W * (C >> 3);
+  const unsigned gid = blockIdx.x * TPB + threadIdx.x;
   if (gid >= total) return;
-  const int v = (int)(gid % nvec);
-  const long long pix = gid / nvec;
-  const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+  const unsigned v = dm.nvec.mod(gid), tp = dm.nvec.div(gid);
+  unsigned b, h, w;
+  dm.pixel(tp, b, h, w);
+  const unsigned pix = (b * (unsigned)H + h) * (unsigned)W + w;
   float ix, iy;
-  warp_coords<T>(flow, (size_t)pix, h, w, H, W, scale, ix, iy);
+  warp_coords<T>(flow, (size_t)pix, (int)h, (int)w, H, W, scale, ix, iy);
   const float fx0 = floorf(ix), fy0 = floorf(iy);
   float cx[4], cy[4];
   cubic_coeffs(ix - fx0, cx);
   cubic_coeffs(iy - fy0, cy);
   const int x0 = (int)fx0 - 1, y0 = (int)fy0 - 1;
-  int xo[4];                                                  // element offsets of the 4 tap columns (clamped), weights zeroed outside
+  constexpr unsigned ES = sizeof(T);
+  const unsigned pitch = (unsigned)C * ES;                       // bytes per pixel
+  const __amdgpu_buffer_rsrc_t xr = buf_rsrc(x, (unsigned)B * H * W * pitch);
+  unsigned xo[4], yo[4];                                       // byte offsets of the 4 tap columns / rows (clamped), weights zeroed outside
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int xx = x0 + j;
     if ((unsigned)xx >= (unsigned)W) cx[j] = 0.f;
-    xo[j] = min(max(xx, 0), W - 1) * C;
+    xo[j] = (unsigned)__umul24((unsigned)min(max(xx, 0), W - 1), pitch) + v * (8 * ES);
   }
-  const T* xb = x + (size_t)b * H * W * C + v * 8;
-  F8 s = f8_zero();
+  const unsigned rowpitch = (unsigned)W * pitch, b0 = b * (unsigned)H;          // (W * C * element size < 2^24, checked by the launcher)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int yy = y0 + i;
-    const float wy = ((unsigned)yy < (unsigned)H) ? cy[i] : 0.f;
-    const T* row = xb + (size_t)(min(max(yy, 0), H - 1) * W) * C;
+    if ((unsigned)yy >= (unsigned)H) cy[i] = 0.f;
+    yo[i] = (unsigned)__umul24(b0 + (unsigned)min(max(yy, 0), H - 1), rowpitch);
+  }
+  F8 s = f8_zero();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float wgt = wy * cx[j];
-      const F8 t = Feat<T>::load(row + xo[j]);
+      const float wgt = cy[i] * cx[j];
+      const F8 t = buf_load8<T>(xr, yo[i] + xo[j]);
 #pragma unroll
       for (int q = 0; q < 8; ++q) s.v[q] += t.v[q] * wgt;
     }
   }
-  Feat<T>::store(y + (size_t)pix * C + v * 8, s);
+  Feat<T>::store(y + ((size_t)pix * (C >> 3) + v) * 8, s);
 }
 
 // ---- backward of the warp ------------------------------------------------------------------------------------
@@ -518,50 +540,56 @@ struct WarpEntry { int p; float w; };
 constexpr int SCAN_TILE = 1024;                              // elements per scan block (256 threads x 4)
 
 template <typename T>
-__global__ void warp_bwd_grid_kernel(const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ flow,
-                                     T* __restrict__ gflow, int* __restrict__ cnt, int B, int H, int W, int C, float scale) {
+__global__ __launch_bounds__(256) void warp_bwd_grid_kernel(const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ flow,
+                                                            T* __restrict__ gflow, int* __restrict__ cnt, int B, int H, int W, int C, float scale,
+                                                            WarpDims dm) {
   const int nvec = C >> 3;                                   // power of two, <= 64 (checked by the launcher)
-  const long long total = (long long)B * H * W * nvec;
-  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
-  const bool live = gid < total;
-  const long long gg = live ? gid : total - 1;
-  const int v = (int)(gg % nvec);
-  const long long pix = gg / nvec;
-  const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+  const unsigned total = (unsigned)B * H * W * nvec;
+  const unsigned gid0 = blockIdx.x * TPB + threadIdx.x;
+  const bool live = gid0 < total;
+  const unsigned gg = live ? gid0 : total - 1;
+  const unsigned v = dm.nvec.mod(gg), tp = dm.nvec.div(gg);
+  unsigned b, h, w;
+  dm.pixel(tp, b, h, w);
+  const unsigned pix = (b * (unsigned)H + h) * (unsigned)W + w;
   float ix, iy;
-  warp_coords<T>(flow, (size_t)pix, h, w, H, W, scale, ix, iy);
+  warp_coords<T>(flow, (size_t)pix, (int)h, (int)w, H, W, scale, ix, iy);
   const float fx0 = floorf(ix), fy0 = floorf(iy);
   float cx[4], cy[4], dx[4], dy[4];
   cubic_coeffs(ix - fx0, cx); cubic_coeffs(iy - fy0, cy);
   cubic_dcoeffs(ix - fx0, dx); cubic_dcoeffs(iy - fy0, dy);
   const int x0 = (int)fx0 - 1, y0 = (int)fy0 - 1;
-  const F8 g = Feat<T>::load(gy + (size_t)pix * C + v * 8);
+  constexpr unsigned ES = sizeof(T);
+  const unsigned pitch = (unsigned)C * ES;
+  const __amdgpu_buffer_rsrc_t xr = buf_rsrc(x, (unsigned)B * H * W * pitch);
+  const typename Vec8<T>::Raw g = Vec8<T>::load(gy + ((size_t)pix * nvec + v) * 8);
   float gix = 0.f, giy = 0.f;
-  // Branch-free taps as in the forward kernel: an out-of-range tap reads a clamped (valid) address and its weights are zero,
-  // so the 16 loads issue back to back instead of one per exec-mask branch (259 -> 17x us at 256 x 256, batch 32).
-  int xo[4];
+  // Branch-free taps as in the forward kernel (clamped address, zero weights outside), raw buffer loads with 32-bit offsets
+  unsigned xo[4], yo[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int xx = x0 + j;
     if ((unsigned)xx >= (unsigned)W) { cx[j] = 0.f; dx[j] = 0.f; }
-    xo[j] = min(max(xx, 0), W - 1) * C;
+    xo[j] = (unsigned)__umul24((unsigned)min(max(xx, 0), W - 1), pitch) + v * (8 * ES);
   }
-  const T* xb = x + (size_t)b * H * W * C + v * 8;
+  const unsigned rowpitch = (unsigned)W * pitch, b0 = b * (unsigned)H;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int yy = y0 + i;
-    const bool iny = (unsigned)yy < (unsigned)H;
-    const float wy = iny ? cy[i] : 0.f, wdy = iny ? dy[i] : 0.f;
-    const T* row = xb + (size_t)(min(max(yy, 0), H - 1) * W) * C;
+    if ((unsigned)yy >= (unsigned)H) { cy[i] = 0.f; dy[i] = 0.f; }
+    yo[i] = (unsigned)__umul24(b0 + (unsigned)min(max(yy, 0), H - 1), rowpitch);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float rx = 0.f, rd = 0.f;                                // sum_j dot_ij * dx[j] , sum_j dot_ij * cx[j]
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const F8 t = Feat<T>::load(row + xo[j]);
-      float dot = 0.f;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) dot += t.v[q] * g.v[q];
-      gix += dot * wy * dx[j];
-      giy += dot * wdy * cx[j];
+      const float dot = Vec8<T>::dot(Vec8<T>::buf(xr, yo[i] + xo[j]), g);      // bf16: 4 x v_dot2c_f32_bf16 on the packed vectors
+      rx += dot * dx[j];
+      rd += dot * cx[j];
     }
+    gix += rx * cy[i];
+    giy += rd * dy[i];
   }
   if (live && v == 0) {                                       // count the taps that land on every input pixel
 #pragma unroll
@@ -571,7 +599,7 @@ __global__ void warp_bwd_grid_kernel(const T* __restrict__ gy, const T* __restri
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int xx = x0 + j;
-        if ((unsigned)xx < (unsigned)W) atomicAdd(cnt + (b * H + yy) * W + xx, 1);
+        if ((unsigned)xx < (unsigned)W) atomicAdd(cnt + ((int)b * H + yy) * W + xx, 1);
       }
     }
   }
@@ -668,14 +696,18 @@ __global__ void warp_fill_kernel(const T* __restrict__ flow, int* __restrict__ c
 }
 
 template <typename T>
-__global__ void warp_gather_kernel(const T* __restrict__ gy, const int* __restrict__ offs, const WarpEntry* __restrict__ entries,
-                                   T* __restrict__ gx, long long npix, int C) {
-  const int nvec = C >> 3;
-  const long long total = npix * nvec;
-  const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
+__global__ __launch_bounds__(256) void warp_gather_kernel(const T* __restrict__ gy, const int* __restrict__ offs, const WarpEntry* __restrict__ entries,
+                                                          T* __restrict__ gx, unsigned npix, int C, int H, int W, WarpDims dm) {
+  const unsigned total = npix * (unsigned)(C >> 3);
+  const unsigned gid = blockIdx.x * TPB + threadIdx.x;
   if (gid >= total) return;
-  const int v = (int)(gid % nvec);
-  const long long q = gid / nvec;
+  const unsigned v = dm.nvec.mod(gid), tq = dm.nvec.div(gid);
+  unsigned qb, qh, qw;
+  dm.pixel(tq, qb, qh, qw);
+  const unsigned q = (qb * (unsigned)H + qh) * (unsigned)W + qw;
+  constexpr unsigned ES = sizeof(T);
+  const unsigned pitch = (unsigned)C * ES, voff = v * (8 * ES);
+  const __amdgpu_buffer_rsrc_t gr = buf_rsrc(gy, npix * pitch);
   const int beg = offs[q], end = offs[q + 1];                  // offs has npix + 1 entries
   F8 s = f8_zero();
   int k = beg;
@@ -685,7 +717,7 @@ __global__ void warp_gather_kernel(const T* __restrict__ gy, const int* __restri
 #pragma unroll
     for (int u = 0; u < 4; ++u) en[u] = entries[k + u];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) t[u] = Feat<T>::load(gy + (size_t)en[u].p * C + v * 8);
+    for (int u = 0; u < 4; ++u) t[u] = buf_load8<T>(gr, (unsigned)__umul24((unsigned)en[u].p, pitch) + voff);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -693,11 +725,11 @@ __global__ void warp_gather_kernel(const T* __restrict__ gy, const int* __restri
   }
   for (; k < end; ++k) {
     const WarpEntry en = entries[k];
-    const F8 t = Feat<T>::load(gy + (size_t)en.p * C + v * 8);
+    const F8 t = buf_load8<T>(gr, (unsigned)__umul24((unsigned)en.p, pitch) + voff);
 #pragma unroll
     for (int j = 0; j < 8; ++j) s.v[j] += en.w * t.v[j];
   }
-  Feat<T>::store(gx + (size_t)q * C + v * 8, s);
+  Feat<T>::store(gx + ((size_t)q * (C >> 3) + v) * 8, s);
 }
 
 template <typename T>
@@ -940,10 +972,13 @@ __global__ void mbstd_bwd2_kernel(const T* __restrict__ v, const T* __restrict__
 // ------------------------------------------------------------------------------------------------------------
 // One block = PB consecutive pixels of ONE sample; a thread owns one channel vector and keeps its 24 weights + 8 biases in
 // registers while it walks the pixels (the first version reloaded them per pixel: 18x off the HBM roofline).
-template <typename T>
+// ACT: the activation as a compile-time constant (leaky ReLU / none: the two the step uses), -1 = take the run-time argument.  With a
+// run-time activation every element carried a chain of uniform branches (and the tanh path): a pure write kernel ran at 2.8 TB/s.
+template <typename T, int ACT>
 __global__ void rgb_expand_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
                                   float bias_scale, T* __restrict__ y, int HW, int C, int Clog, int per_sample,
-                                  int act, float gain, int PB) {
+                                  int act_rt, float gain, int PB) {
+  const int act = ACT >= 0 ? ACT : act_rt;
   const int nvec = C >> 3;
   const int groups = TPB / nvec;
   const int grp = threadIdx.x / nvec, v = threadIdx.x - grp * nvec;
@@ -951,11 +986,14 @@ __global__ void rgb_expand_kernel(const float* __restrict__ img, const float* __
   const int b = blockIdx.y;
   const float* wb = w + (per_sample ? (size_t)b * 3 * C : 0);
   float w0[8], w1[8], w2[8], bv[8];
+  {                                                          // 8 consecutive floats each: float4 pairs (32 dword loads per thread were a third of the kernel's memory instructions)
+    const f32x4 a0 = *(const f32x4*)(wb + v * 8), a1 = *(const f32x4*)(wb + v * 8 + 4);
+    const f32x4 b0 = *(const f32x4*)(wb + C + v * 8), b1 = *(const f32x4*)(wb + C + v * 8 + 4);
+    const f32x4 c0 = *(const f32x4*)(wb + 2 * C + v * 8), c1 = *(const f32x4*)(wb + 2 * C + v * 8 + 4);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int c = v * 8 + j;
-    w0[j] = wb[c]; w1[j] = wb[C + c]; w2[j] = wb[2 * C + c];
-    bv[j] = (bias && c < Clog) ? bias[c] * bias_scale : 0.f;
+    for (int j = 0; j < 4; ++j) { w0[j] = a0[j]; w0[4 + j] = a1[j]; w1[j] = b0[j]; w1[4 + j] = b1[j]; w2[j] = c0[j]; w2[4 + j] = c1[j]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int c = v * 8 + j; bv[j] = (bias && c < Clog) ? bias[c] * bias_scale : 0.f; }
   }
   const int p0 = blockIdx.x * PB, p1 = min(p0 + PB, HW);
   const float* ib = img + (size_t)b * 3 * HW;
@@ -975,10 +1013,11 @@ __global__ void rgb_expand_kernel(const float* __restrict__ img, const float* __
 // POOLED pixels and produces the four outputs under each, so the pooled tensor costs a quarter-size store instead of the pooling
 // kernel's re-read of the whole 128-channel map.  Same per-element arithmetic as rgb_expand_kernel; pooled sums the values as STORED
 // (rounded to T), in the pooling kernel's order.
-template <typename T>
+template <typename T, int ACT>
 __global__ void rgb_expand_pool_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
                                        float bias_scale, T* __restrict__ y, T* __restrict__ pooled, int H, int W, int C, int Clog,
-                                       int per_sample, int act, float gain, int PB) {
+                                       int per_sample, int act_rt, float gain, int PB) {
+  const int act = ACT >= 0 ? ACT : act_rt;
   const int nvec = C >> 3;
   const int groups = TPB / nvec;
   const int grp = threadIdx.x / nvec, v = threadIdx.x - grp * nvec;
@@ -986,11 +1025,14 @@ __global__ void rgb_expand_pool_kernel(const float* __restrict__ img, const floa
   const int b = blockIdx.y, HW = H * W, Wq = W >> 1, HWq = (H >> 1) * Wq;
   const float* wb = w + (per_sample ? (size_t)b * 3 * C : 0);
   float w0[8], w1[8], w2[8], bv[8];
+  {
+    const f32x4 a0 = *(const f32x4*)(wb + v * 8), a1 = *(const f32x4*)(wb + v * 8 + 4);
+    const f32x4 b0 = *(const f32x4*)(wb + C + v * 8), b1 = *(const f32x4*)(wb + C + v * 8 + 4);
+    const f32x4 c0 = *(const f32x4*)(wb + 2 * C + v * 8), c1 = *(const f32x4*)(wb + 2 * C + v * 8 + 4);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int c = v * 8 + j;
-    w0[j] = wb[c]; w1[j] = wb[C + c]; w2[j] = wb[2 * C + c];
-    bv[j] = (bias && c < Clog) ? bias[c] * bias_scale : 0.f;
+    for (int j = 0; j < 4; ++j) { w0[j] = a0[j]; w0[4 + j] = a1[j]; w1[j] = b0[j]; w1[4 + j] = b1[j]; w2[j] = c0[j]; w2[4 + j] = c1[j]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int c = v * 8 + j; bv[j] = (bias && c < Clog) ? bias[c] * bias_scale : 0.f; }
   }
   const int q0 = blockIdx.x * PB, q1 = min(q0 + PB, HWq);
   const float* ib = img + (size_t)b * 3 * HW;
@@ -1155,10 +1197,11 @@ __global__ void flow_im2col_kernel(const T* __restrict__ gu, const float* __rest
 //   gw[bw,o,c]  += sum_p img[b,o,p] gz[b,p,c]           (optional)
 //   gbias[c]    += sum_{b,p} gz[b,p,c]                   (optional)
 // One block = P consecutive pixels of one sample; a pixel's channel vectors sit in adjacent lanes of one wave.
-template <typename T>
+template <typename T, int ACT>
 __global__ void rgb_expand_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ y, const float* __restrict__ img,
                                       const float* __restrict__ w, float* __restrict__ gimg, float* __restrict__ gw,
-                                      float* __restrict__ gbias, int HW, int C, int Clog, int per_sample, int act, float gain, int P) {
+                                      float* __restrict__ gbias, int HW, int C, int Clog, int per_sample, int act_rt, float gain, int P) {
+  const int act = ACT >= 0 ? ACT : act_rt;
   __shared__ float red[4][TPB * 8];
   const int nvec = C >> 3;                                   // power of two <= 64
   const int groups = TPB / nvec;
@@ -1379,7 +1422,9 @@ int lcgan_box3_act_bwd(const void* gy, const void* y, void* gx, int B, int H, in
   ProfScope p(KID_STENCIL, 0, (double)n * 8 * 3 * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
   const int BOX_RH = box_rh(n);
   const long long nthr = (long long)B * ((H + BOX_RH - 1) / BOX_RH) * W * (C / 8);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(box3_act_bwd_kernel<T>, grid1d(nthr), dim3(TPB), 0, s, (const T*)gy, (const T*)y, (T*)gx, B, H, W, C, act, gain, BOX_RH));
+#define BOXB(A) DISPATCH_T(dtype, hipLaunchKernelGGL((box3_act_bwd_kernel<T, A>), grid1d(nthr), dim3(TPB), 0, s, (const T*)gy, (const T*)y, (T*)gx, B, H, W, C, act, gain, BOX_RH))
+  if (act == ACT_LRELU) { BOXB(ACT_LRELU); } else if (act == ACT_NONE) { BOXB(ACT_NONE); } else { BOXB(-1); }
+#undef BOXB
   return launch_status();
 }
 
@@ -1474,7 +1519,9 @@ int lcgan_warp_fwd(const void* x, const void* flow, void* y, int B, int H, int W
   const long long n = (long long)B * H * W * (C / 8);
   Tag tg("warp_fwd", B, H, W, C);
   ProfScope p(KID_WARP_FWD, 0, (double)n * 8 * 2 * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(warp_fwd_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)x, (const T*)flow, (T*)y, B, H, W, C, scale));
+  if ((double)n * 8 * (dtype == DT_BF16 ? 2 : 4) >= 4294967296.0 || (long long)W * C * 4 >= (1 << 24) || (long long)B * H >= (1 << 24)) return LCGAN_EINVAL;     // 32-bit byte offsets, 24-bit factors
+  const WarpDims dm = warp_dims(C, H, W);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(warp_fwd_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)x, (const T*)flow, (T*)y, B, H, W, C, scale, dm));
   return launch_status();
 }
 
@@ -1490,18 +1537,21 @@ int lcgan_warp_bwd(const void* gy, const void* x, const void* flow, void* gx, vo
   if ((C & 7) || !pow2_le64(C / 8) || H < 2 || W < 2 || (long long)B * H * W * 16 >= (1ll << 31)) return LCGAN_EINVAL;
   const long long npix = (long long)B * H * W, n = npix * (C / 8);
   const double eb = dtype == DT_BF16 ? 2 : 4;
+  // 32-bit byte offsets and 24-bit multiplies in the tap addressing (see warp_fwd_kernel)
+  if ((double)n * 8 * eb >= 4294967296.0 || (long long)W * C * 4 >= (1 << 24) || npix >= (1 << 24)) return LCGAN_EINVAL;
+  const WarpDims dm = warp_dims(C, H, W);
   Tag tg("warp_bwd", B, H, W, C);
   ProfScope p(KID_WARP_BWD, 0, (double)n * 8 * 4 * eb + (double)npix * 16 * 8 * 2, s, tg.s);
   hipMemsetAsync(ws_cnt, 0, (size_t)(npix + 1) * sizeof(int), s);
   const int ntiles = cdiv(npix + 1, SCAN_TILE);
   DISPATCH_T(dtype, {
     hipLaunchKernelGGL(warp_bwd_grid_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)gy, (const T*)x, (const T*)flow, (T*)gflow, ws_cnt,
-                       B, H, W, C, scale);
+                       B, H, W, C, scale, dm);
     hipLaunchKernelGGL(warp_scan_tiles_kernel, dim3(ntiles), dim3(256), 0, s, ws_cnt, ws_off, ws_tiles, npix + 1);
     hipLaunchKernelGGL(warp_scan_sums_kernel, dim3(1), dim3(1024), 0, s, ws_tiles, ntiles);
     hipLaunchKernelGGL(warp_scan_add_kernel, grid1d(npix + 1), dim3(TPB), 0, s, ws_off, ws_tiles, npix + 1);
     hipLaunchKernelGGL(warp_fill_kernel<T>, grid1d(npix), dim3(TPB), 0, s, (const T*)flow, ws_cnt, ws_off, (WarpEntry*)ws_ent, B, H, W, scale);
-    hipLaunchKernelGGL(warp_gather_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)gy, ws_off, (const WarpEntry*)ws_ent, (T*)gx, npix, C);
+    hipLaunchKernelGGL(warp_gather_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)gy, ws_off, (const WarpEntry*)ws_ent, (T*)gx, (unsigned)npix, C, H, W, dm);
   });
   return launch_status();
 }
@@ -1549,14 +1599,18 @@ int lcgan_rgb_expand(const float* img, const float* w, const float* bias, float 
   ProfScope p(KID_RGB, 0, (double)n * 8 * (pooled ? 1.25 : 1.0) * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
   if (pooled) {
     if (W <= 0 || (W & 1) || HW % W || ((HW / W) & 1)) return LCGAN_EINVAL;
-    const int PBq = 64;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(rgb_expand_pool_kernel<T>, dim3(cdiv(HW / 4, PBq), B), dim3(TPB), 0, s, img, w, bias, bias_scale, (T*)y,
-                                         (T*)pooled, HW / W, W, C, Clog, per_sample, act, gain, PBq));
+    const int PBq = HW / 4 >= 16384 ? 256 : 64;            // pooled pixels per block: the per-thread constants are amortised over PBq / groups of them
+#define RGB_POOL(A) DISPATCH_T(dtype, hipLaunchKernelGGL((rgb_expand_pool_kernel<T, A>), dim3(cdiv(HW / 4, PBq), B), dim3(TPB), 0, s, img, w, bias, \
+                                                    bias_scale, (T*)y, (T*)pooled, HW / W, W, C, Clog, per_sample, act, gain, PBq))
+    if (act == ACT_LRELU) { RGB_POOL(ACT_LRELU); } else if (act == ACT_NONE) { RGB_POOL(ACT_NONE); } else { RGB_POOL(-1); }
+#undef RGB_POOL
     return launch_status();
   }
-  const int PB = 256;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(rgb_expand_kernel<T>, dim3(cdiv(HW, PB), B), dim3(TPB), 0, s, img, w, bias, bias_scale, (T*)y,
-                                       HW, C, Clog, per_sample, act, gain, PB));
+  const int PB = HW >= 65536 ? 1024 : 256;
+#define RGB_EXP(A) DISPATCH_T(dtype, hipLaunchKernelGGL((rgb_expand_kernel<T, A>), dim3(cdiv(HW, PB), B), dim3(TPB), 0, s, img, w, bias, bias_scale, \
+                                                   (T*)y, HW, C, Clog, per_sample, act, gain, PB))
+  if (act == ACT_LRELU) { RGB_EXP(ACT_LRELU); } else if (act == ACT_NONE) { RGB_EXP(ACT_NONE); } else { RGB_EXP(-1); }
+#undef RGB_EXP
   return launch_status();
 }
 // img[b,o,p] = sum_c x[b,p,c] w[bw,o,c] + bias[o]*bias_scale
@@ -1567,7 +1621,7 @@ int lcgan_rgb_reduce(const void* x, const float* w, const float* bias, float bia
   const long long n = (long long)B * HW * (C / 8);
   Tag tg("rgb_reduce", B, HW, 1, C);
   ProfScope p(KID_RGB, 0, (double)n * 8 * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
-  const int PB = 256;
+  const int PB = HW >= 65536 ? 1024 : 256;                 // (the 24 per-thread weights are amortised over PB / groups pixels)
   DISPATCH_T(dtype, hipLaunchKernelGGL(rgb_reduce_kernel<T>, dim3(cdiv(HW, PB), B), dim3(TPB), 0, s, (const T*)x, w, bias, bias_scale, img,
                                        HW, C, per_sample, PB));
   return launch_status();
@@ -1614,8 +1668,10 @@ int lcgan_rgb_expand_bwd(const void* gy, const void* y, const float* img, const 
   dim3 grid(cdiv(HW, P), B);
   Tag tg("rgb_expand_bwd", B, HW, 1, C);
   ProfScope p(KID_RGB, 0, (double)B * HW * C * (act != ACT_NONE ? 2 : 1) * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(rgb_expand_bwd_kernel<T>, grid, dim3(TPB), 0, s, (const T*)gy, (const T*)y, img, w, gimg, gw, gbias,
-                                       HW, C, Clog, per_sample, act, gain, P));
+#define RGBB(A) DISPATCH_T(dtype, hipLaunchKernelGGL((rgb_expand_bwd_kernel<T, A>), grid, dim3(TPB), 0, s, (const T*)gy, (const T*)y, img, w, gimg, gw, gbias, \
+                                                HW, C, Clog, per_sample, act, gain, P))
+  if (act == ACT_LRELU) { RGBB(ACT_LRELU); } else if (act == ACT_NONE) { RGBB(ACT_NONE); } else { RGBB(-1); }
+#undef RGBB
   return launch_status();
 }
 // Backward of  act(conv) -> lcgan_rgb_reduce  down to the conv's pre-activation gradient (see rgb_reduce_bwd_act_kernel).
