@@ -1449,11 +1449,25 @@ __global__ __launch_bounds__(512, RW == 2 ? 4 : 2) void conv_halo_narrow_kernel(
 // finalize kernel re-zeroes what it consumed -- additionally assumes that the convolutions of one device are issued on ONE stream
 // (the launch stream of the training step), which lcgan_amd guarantees.
 constexpr int MAX_DEV = 16;
+// The library-owned scratch buffers (split-K partials, weight-gradient slabs, prescaled operands) are reused launch after launch with
+// no event tracking: correct because the launches of a device are ordered on ONE stream.  A caller that switches streams (a side
+// stream, a capture stream) is ordered behind the work of the stream used before: the previous stream is drained once at the switch.
+hipStream_t g_scratch_stream[MAX_DEV] = {};
+bool g_scratch_stream_set[MAX_DEV] = {};
+void scratch_order(int dev, hipStream_t s) {
+  if (g_scratch_stream_set[dev] && g_scratch_stream[dev] != s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st == hipStreamCaptureStatusNone) hipStreamSynchronize(g_scratch_stream[dev]);
+    (void)hipGetLastError();
+  }
+  g_scratch_stream[dev] = s; g_scratch_stream_set[dev] = true;
+}
 float* g_splitk_ws[MAX_DEV] = {};
 size_t g_splitk_ws_bytes[MAX_DEV] = {};
 float* splitk_scratch(size_t bytes, hipStream_t s) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  scratch_order(dev, s);
   if (bytes > g_splitk_ws_bytes[dev]) {
     if (g_splitk_ws[dev]) hipFree(g_splitk_ws[dev]);
     g_splitk_ws_bytes[dev] = std::max(bytes, (size_t)8 << 20);
@@ -2207,9 +2221,10 @@ __global__ void slab_reduce_unprep_kernel(const float* __restrict__ slab, int ns
 
 float* g_slab[MAX_DEV] = {};
 size_t g_slab_bytes[MAX_DEV] = {};
-float* wgrad_slab_scratch(size_t bytes) {          // grow-only, per device, owned by the library; every element is written before it is read
+float* wgrad_slab_scratch(size_t bytes, hipStream_t s) {          // grow-only, per device, owned by the library; every element is written before it is read
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  scratch_order(dev, s);
   if (bytes > g_slab_bytes[dev]) {
     if (g_slab[dev]) hipFree(g_slab[dev]);
     g_slab_bytes[dev] = std::max(bytes, (size_t)64 << 20);
@@ -2461,9 +2476,10 @@ __global__ void prescale_kernel(const __bf16* __restrict__ x, const float* __res
 }
 __bf16* g_prescale[MAX_DEV] = {};
 size_t g_prescale_bytes[MAX_DEV] = {};
-__bf16* prescale_scratch(size_t bytes) {               // grow-only, per device; written in full before every use, one launch stream
+__bf16* prescale_scratch(size_t bytes, hipStream_t s) {               // grow-only, per device; written in full before every use
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  scratch_order(dev, s);
   if (bytes > g_prescale_bytes[dev]) {
     if (g_prescale[dev]) hipFree(g_prescale[dev]);
     g_prescale_bytes[dev] = std::max(bytes, (size_t)16 << 20);
@@ -2482,7 +2498,7 @@ int dispatch_igemm(const ConvArgs& a_in, int nphase, int dtype, hipStream_t s) {
   if (g_igemm_dma >= 2 && dtype == DT_BF16 && a.pre && a.Cin % 32 == 0 && a.Kpad == a.Cin && a.M >= 2048) {   // (below that the extra launch costs what the faster main loop gains: measured at local batch 4)
     const size_t elems = (size_t)a.B * a.Hin * a.Win * a.Cin;
     if (elems * sizeof(__bf16) <= ((size_t)32 << 20)) {
-      __bf16* xs_ = prescale_scratch(elems * sizeof(__bf16));
+      __bf16* xs_ = prescale_scratch(elems * sizeof(__bf16), s);
       if (xs_) {
         const long long nvec = (long long)(elems / 8);
         hipLaunchKernelGGL(prescale_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, s, (const __bf16*)a.x, a.pre, xs_, nvec,
@@ -2723,7 +2739,7 @@ static int conv_wgrad_impl(const void* x, const void* g, float* gwp,
     const size_t bx = (size_t)B * Hx * Wx * Cx * sizeof(__bf16), bg = (size_t)B * Hg * Wg * Cg * sizeof(__bf16);
     const size_t ox = (bx + 255) & ~(size_t)255;
     if (bx + bg <= ((size_t)g_wgrad_prescale_mb << 20)) {
-      __bf16* buf = prescale_scratch(ox + bg);
+      __bf16* buf = prescale_scratch(ox + bg, s);
       if (buf) {
         if (pre_x) {
           const long long nvec = (long long)(bx / 16);
@@ -2795,7 +2811,7 @@ static int conv_wgrad_impl(const void* x, const void* g, float* gwp,
     // iteration at local batch 4 (170 splits x 49 K atomics per layer were 77 us at the chip's 1.3 TB/s atomic rate), so every
     // launch with enough splits takes the slab.
     if (pk == 1 && g_wgrad_slab_min > 0 && a.nsplit >= g_wgrad_slab_min && slab_bytes <= ((size_t)1 << 30))
-      a.slab = wgrad_slab_scratch(slab_bytes);                    // (packed groups: several waves add into one element -> atomics only)
+      a.slab = wgrad_slab_scratch(slab_bytes, s);                    // (packed groups: several waves add into one element -> atomics only)
     if (up && !a.slab) hipMemsetAsync(gwp, 0, (size_t)k * k * A * Bc * sizeof(float), s);   // fused entry: gwp arrives uncleared
     a.na = cdiv(A, 128); a.nc = cdiv(Bc, 128); a.xcd_order = g_wgrad_xcd;
     dim3 grid3(a.na, a.nc, nkx * a.nsplit);
