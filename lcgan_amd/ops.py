@@ -82,6 +82,9 @@ class _NoGraphCtx:
     def mark_non_differentiable(self, *tensors):
         pass
 
+    def set_materialize_grads(self, value):
+        pass
+
 
 def _ap(fn, *args):
     """fn.apply(*args) from inside a backward pass.  The nested Functions exist so that a backward pass is itself differentiable
@@ -238,6 +241,8 @@ class Conv2dFn(Function):
 
     @staticmethod
     def backward(ctx, gy):
+        if gy is None:                                     # (Conv2dPoolFn runs without materialised gradients)
+            return (None,) * 10
         x, w, y = ctx.saved_tensors
         k, stride, act, gain, wscale, bias_scale, has_bias, has_res = ctx.cfg
         gy = gy.contiguous()
@@ -268,6 +273,7 @@ class Conv2dPoolFn(Function):
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.cfg = (k, stride, act, gain, wscale, bias_scale, bias is not None, residual is not None)
         ctx.mark_non_differentiable(pooled)
+        ctx.set_materialize_grads(False)        # (autograd would otherwise FILL a zero gradient of pooled's size for every backward pass)
         return y, pooled
 
     @staticmethod
@@ -365,6 +371,7 @@ class BoxActBwdFn(Function):
         ctx.save_for_backward(y)
         ctx.cfg = (act, gain)
         ctx.mark_non_differentiable(gb)
+        ctx.set_materialize_grads(False)
         return gz, gb
 
     @staticmethod
@@ -372,6 +379,8 @@ class BoxActBwdFn(Function):
     def backward(ctx, ggz, _ggb):
         (y,) = ctx.saved_tensors
         act, gain = ctx.cfg
+        if ggz is None:
+            return None, None, None, None, None, None, None
         return _K().box3_act_bwd(ggz.contiguous(), y, act, gain), None, None, None, None, None, None
 
 
@@ -414,13 +423,14 @@ class ActBwdFn(Function):
         ctx.save_for_backward(y)
         ctx.cfg = (act, gain, clog)
         ctx.mark_non_differentiable(gb)
+        ctx.set_materialize_grads(False)
         return gz, gb
 
     @staticmethod
     def backward(ctx, ggz, _ggb):
         (y,) = ctx.saved_tensors
         act, gain, clog = ctx.cfg
-        if act == ACT_NONE:
+        if act == ACT_NONE or ggz is None:
             return ggz, None, None, None, None, None, None
         g, _ = _ap(ActBwdFn, ggz.contiguous(), y, act, gain, clog, False, 1.0)
         return g, None, None, None, None, None, None
@@ -473,11 +483,14 @@ class RGBExpandFn(Function):
         ctx.cfg = (bias_scale, clog, act, gain, bias is not None)
         if pool:
             ctx.mark_non_differentiable(out[1])
+            ctx.set_materialize_grads(False)    # (no zero-filled gradient for the by-product)
             return y, out[1]
         return y
 
     @staticmethod
     def backward(ctx, gy, _gpooled=None):
+        if gy is None:
+            return (None,) * 9
         img, wt, y = ctx.saved_tensors
         bias_scale, clog, act, gain, has_bias = ctx.cfg
         gy = gy.contiguous()
@@ -877,9 +890,9 @@ class FlowConvFn(Function):
         gt = K.flow_im2col(gu, d)                                                # [B,H,W,24], demodulation folded in
         gx, gs = K.conv_bwd_data(gt, pw18T, Cin, 1, 1, post=s, xs=x)             # gx = s * (gt @ W18), gs = sum_p x * (gt @ W18)
         gwsq = K.demod_bwd(gdq, d, s, wsq, gs)                                   # gs += demod path
-        gw18 = K.conv_wgrad(x, gt, 18, Cin, 1, 1, pre_x=s)                       # [1][18][Cin]
-        gw = gw18.view(3, 3, 2, Cin).permute(2, 3, 0, 1) * c_eq + (2.0 * c_eq * c_eq) * w.detach() * gwsq[:, :, None, None]
-        return gx, gw.contiguous(), gb, gs
+        gw18 = K.conv_wgrad(x, gt, 18, Cin, 1, 1, pre_x=s)                       # [1][18][Cin], row (ky*3+kx)*2+o == the prepared layout [9][2][Cin]
+        gw = K.unprep_wgrad(gw18.view(9, 2, Cin), 2, Cin, 3, c_eq, False, w=w.detach(), gwsq=gwsq)      # + the demodulation term, one launch
+        return gx, gw, gb, gs
 
 
 class Box3ActFn(Function):
