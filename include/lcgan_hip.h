@@ -188,7 +188,8 @@ int lcgan_multi_tensor(const void* descs, const int* chunk_tensor, const int* ch
  * weight-gradient kernel (0 off, 1, 2 = split for two workgroups per CU, 3 = also stride 2); 13 parity-plane stride-2 forward;
  * 14 KB of weights concurrent channel blocks of one tile may keep in an XCD's L2 (0 = one input pass per channel block);
  * 15 XCD-grouped weight-gradient workgroup order; 16 LDS-DMA staging of the generic implicit-GEMM kernel (2 = modulated low-resolution layers too, through one prescale pass);
- * 17 MB of operands up to which a weight gradient with per-sample scales applies them by one elementwise pass and reduces the whole batch as one range (0 = never).  DESIGN.md section 2 ("Switches") has the measurements behind the defaults. */
+ * 17 MB of operands up to which a weight gradient with per-sample scales applies them by one elementwise pass and reduces the whole batch as one range (0 = never);
+ * 18 MB of per-sample weight copies up to which a convolution with per-sample input scales folds them into the weights (0 = never).  DESIGN.md section 2 ("Switches") has the measurements behind the defaults. */
 int lcgan_set_option(int option, int value);
 
 /* ---- per-launch HIP-event profiling (bench.py roofline) ---------------------------------------------------- */

@@ -48,6 +48,8 @@ int g_halo_s2dma = 4;                     // lcgan_set_option(13, ...): stride-2
 int g_halo_nb_group_kb = 8192;               // lcgan_set_option(14, ...): KB of weights (all taps x 128 rows x Cin) that concurrent channel blocks of one tile may hold in an XCD's L2; 0 = channel blocks slowest (one pass over the input per block)
 int g_wgrad_xcd = 0;                      // lcgan_set_option(15, ...): row-segment wgrad workgroups of one split share an XCD (1-D grid)
 int g_igemm_dma = 2;                      // lcgan_set_option(16, ...): LDS-DMA staging in the generic implicit-GEMM kernel (bf16, no input scales, Cin % 32 == 0)
+int g_halo_wmod_mb = 80;                  // lcgan_set_option(18, ...): convolutions with per-sample INPUT scales (modulated convs and their data gradients) whose per-sample
+                                          // weight copies (B x taps x N x Kpad bf16) fit this many MB fold the scales into the weights once and run the unscaled kernels; 0 = never
 int g_wgrad_prescale_mb = 180;            // lcgan_set_option(17, ...): weight gradients with per-sample operand scales whose two operands together are at most this many MB
                                           // get the scales applied ONCE by an elementwise pass (bf16) and then run as ONE batch-wide reduction; 0 = never
 int g_dbg_no_atomics = 0;                 // lcgan_set_option(3, ...): experiments, bit mask (the wgrad3 no-atomics switch is gone: it sat in the epilogue);
@@ -392,6 +394,7 @@ struct HaloArgs {
   const __bf16* x; const __bf16* w; __bf16* y;
   const float* pre; const float* post; const float* bias; const __bf16* residual; int res_half;
   __bf16* pool_out;                          // see ConvArgs (written by the EPI == 1 epilogue)
+  long long w_bstride;                       // elements between the weights of consecutive samples (0 = shared): per-sample modulated weight copies
   const __bf16* xs; float* gs;               // see ConvArgs
   int B, Hin, Win, Cin, Hout, Wout, Cout, Hm, Wm, N, Kpad, kc_per_tap;
   int out_mul, tiles_x, tiles_y;
@@ -430,7 +433,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 template <int IN_MUL, bool M16, int EPI, int DMA = 0, bool MOD = false>
 __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) void conv_halo_kernel(HaloArgs a) {
-  static_assert(DMA == 0 || (IN_MUL == 1 && DMA <= 2 && (!M16 || DMA == 2) && (MOD || EPI != 3)) || (IN_MUL == 2 && (DMA == 3 || DMA == 4) && !M16 && (MOD || EPI != 3)),
+  static_assert(DMA == 0 || (IN_MUL == 1 && DMA <= 2 && (!M16 || DMA == 2)) || (IN_MUL == 2 && (DMA == 3 || DMA == 4) && !M16),
                 "LDS-DMA staging: stride-1 geometries (1 / 2 taps per barrier) or the stride-2 forward structure (DMA == 3)");
   static_assert(!MOD || DMA != 0, "MOD: the swizzled-record structure with the halo staged through registers (per-sample input scales)");
   constexpr bool SR = EPI == 3;
@@ -487,7 +490,8 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
   //  chunk, tap -- as the scalar offset; no 64-bit address lives in vector registers and a lane outside the image / the weight
   //  rows reads zeros by the range check instead of a branch.  Tensors are < 2^31 elements, checked by the caller)
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(2u * (unsigned)(a.B * a.Hin * a.Win * a.Cin)), 0x00020000);
-  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
+  // (w_bstride != 0: this sample's own copy of the weights, the per-sample input scales already folded in)
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (size_t)b * (size_t)a.w_bstride), 0, 0x7fffffff, 0x00020000);
   unsigned goff[NI];
   int loff[NI];
 #pragma unroll
@@ -1540,6 +1544,38 @@ bool try_launch_halo_narrow(const ConvArgs& c, int nphase, hipStream_t s) {
 // epilogue staging of conv_halo_kernel: output tile [256][BN + 8] bf16 and three float rows (column sums, bias, demodulation)
 constexpr size_t HALO_EPI_SMEM = (size_t)256 * (BN + 8) * sizeof(__bf16) + 3 * BN * sizeof(float);
 
+// Per-sample weights with the input scales folded in: out[b][t][n][k] = bf16(w[t][n][k] * pre[b][k]).  A modulated convolution is
+// y = post * conv(pre * x, W); scaling the staged INPUT costs every chunk of every workgroup an in-place LDS pass (ds_read, 8 multiplies,
+// ds_write per 16-byte piece: +8 ... +16 % per launch, 1.5 ms per iteration), scaling the WEIGHTS once per launch costs one pass over
+// B x |W| bytes (38 MB for a 256 x 256 x 9 layer at batch 32) and the launch then runs the plain LDS-DMA kernel.  The reference forms
+// the same per-sample weights (custom_layers.py:62-64).  Rounding: one bf16 rounding of w * pre here instead of one of pre * x there.
+__global__ void modulate_weights_kernel(const __bf16* __restrict__ w, const float* __restrict__ pre, __bf16* __restrict__ out,
+                                        long long nvec, int Kpad, int Cin, int pre_stride) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;        // one 8-element vector of ONE sample's copy
+  if (i >= nvec) return;
+  const int b = blockIdx.y, kv = Kpad >> 3;
+  const int k0 = (int)(i % kv) * 8;
+  const bf16x8 t = *(const bf16x8*)(w + i * 8);
+  const float* ps = pre + (size_t)b * pre_stride + k0;
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (__bf16)((float)t[j] * (k0 + j < Cin ? ps[j] : 0.f));
+  *(bf16x8*)(out + ((size_t)b * nvec + i) * 8) = o;
+}
+__bf16* g_wmod[MAX_DEV] = {};
+size_t g_wmod_bytes[MAX_DEV] = {};
+__bf16* wmod_scratch(size_t bytes, hipStream_t s) {              // grow-only, per device; written in full before every use
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  scratch_order(dev, s);
+  if (bytes > g_wmod_bytes[dev]) {
+    if (g_wmod[dev]) hipFree(g_wmod[dev]);
+    g_wmod_bytes[dev] = std::max(bytes, (size_t)96 << 20);
+    if (hipMalloc((void**)&g_wmod[dev], g_wmod_bytes[dev]) != hipSuccess) { g_wmod[dev] = nullptr; g_wmod_bytes[dev] = 0; return nullptr; }
+  }
+  return g_wmod[dev];
+}
+
 // host side: returns true when the halo kernel was launched for this geometry
 bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   if (c.Hm < HT || c.Wm < HT || c.act == ACT_TANH) return false;
@@ -1575,6 +1611,22 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   if (g_use_splitk && halo_wgs < g_halo_min_wgs && c.taps[0].n * c.kc_per_tap >= 8) return false;
   a.halo_elems = max_halo_elems;
   g_pool_written = a.pool_out != nullptr;                         // (no `return false` below this line)
+  if (a.pre && g_halo_wmod_mb > 0 && c.Cin % 32 == 0 && c.Kpad == c.Cin && c.pre_stride >= c.Cin && g_mfma16 != 1) {
+    // taps of the whole prepared weight (9 for a 3x3 kernel whatever the phase structure, 1 for 1x1)
+    int wt_max = 0;
+    for (int p = 0; p < nphase; ++p) for (int t = 0; t < c.taps[p].n; ++t) wt_max = std::max(wt_max, c.taps[p].wt[t]);
+    const size_t per = (size_t)(wt_max + 1) * c.N * c.Kpad;       // elements of one sample's copy
+    const size_t bytes = (size_t)c.B * per * sizeof(__bf16);
+    const bool fast = in_mul == 2 ? (nphase == 1 && c.taps[0].n == 9) : true;      // geometries whose unscaled launch takes an LDS-DMA structure below
+    if (fast && bytes <= ((size_t)g_halo_wmod_mb << 20)) {
+      __bf16* wm = wmod_scratch(bytes, s);
+      if (wm) {
+        const long long nvec = (long long)(per / 8);
+        hipLaunchKernelGGL(modulate_weights_kernel, dim3((unsigned)((nvec + 255) / 256), c.B), dim3(256), 0, s, c.w, c.pre, wm, nvec, c.Kpad, c.Cin, c.pre_stride);
+        a.w = wm; a.w_bstride = (long long)per; a.pre = nullptr;
+      }
+    }
+  }
   const int NBT = (in_mul == 2 && g_mfma16 != 1) ? 4 : 2;             // stride-2 forward stages the weight tiles of two taps per step
   const size_t smem = std::max(((size_t)a.halo_elems + NBT * TILE) * sizeof(__bf16) + (size_t)c.Kpad * sizeof(float),
                                HALO_EPI_SMEM);
@@ -1599,7 +1651,7 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
     if (a.xs) LAUNCH_HALO(IM, MM, 3) else if (a.residual && a.res_half) LAUNCH_HALO(IM, MM, 2)                          \
     else if (a.residual) LAUNCH_HALO(IM, MM, 1) else LAUNCH_HALO(IM, MM, 0)                                             \
   }
-  if (g_halo_s2dma && in_mul == 2 && nphase == 1 && g_mfma16 != 1 && (a.pre ? g_halo_s2dma >= 2 : !a.xs) && c.taps[0].n == 9 && c.Cin % 32 == 0 && c.Kpad == c.Cin &&
+  if (g_halo_s2dma && in_mul == 2 && nphase == 1 && g_mfma16 != 1 && (a.pre ? g_halo_s2dma >= 2 : true) && c.taps[0].n == 9 && c.Cin % 32 == 0 && c.Kpad == c.Cin &&
       (!a.pre || c.Cin <= 1024)) {
     constexpr size_t S2_SMEM = 2 * (size_t)(42 * 1024 + 9 * 4096);      // two half-chunk stages (see the kernel)
     // one stage per workgroup only pays when two workgroups share a CU: a grid that cannot give every CU two keeps the two-stage form
@@ -1624,7 +1676,7 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
     if (!set) { hipFuncSetAttribute((const void*)conv_halo_kernel<2, false, EP, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
     hipLaunchKernelGGL((conv_halo_kernel<2, false, EP, 4>), grid, dim3(512), dsm1, s, a);                               \
   }
-      if (a.residual && a.res_half) LAUNCH_S2S(2) else if (a.residual) LAUNCH_S2S(1) else LAUNCH_S2S(0)
+      if (a.xs) LAUNCH_S2S(3) else if (a.residual && a.res_half) LAUNCH_S2S(2) else if (a.residual) LAUNCH_S2S(1) else LAUNCH_S2S(0)
 #undef LAUNCH_S2S
       return true;
     }
@@ -1646,12 +1698,12 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
     if (!set) { hipFuncSetAttribute((const void*)conv_halo_kernel<2, false, EP, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
     hipLaunchKernelGGL((conv_halo_kernel<2, false, EP, 3>), grid, dim3(512), dsmem, s, a);                              \
   }
-    if (a.residual && a.res_half) LAUNCH_S2(2) else if (a.residual) LAUNCH_S2(1) else LAUNCH_S2(0)
+    if (a.xs) LAUNCH_S2(3) else if (a.residual && a.res_half) LAUNCH_S2(2) else if (a.residual) LAUNCH_S2(1) else LAUNCH_S2(0)
 #undef LAUNCH_S2
     return true;
   }
   const bool mod = a.pre != nullptr;
-  bool dma_ok = g_halo_dma && in_mul == 1 && g_mfma16 != 1 && (mod ? g_halo_dma_mod != 0 : !a.xs) && c.Cin % 32 == 0 && c.Kpad == c.Cin;
+  bool dma_ok = g_halo_dma && in_mul == 1 && g_mfma16 != 1 && (mod ? g_halo_dma_mod != 0 : true) && c.Cin % 32 == 0 && c.Kpad == c.Cin;
   for (int p = 0; p < nphase; ++p) dma_ok = dma_ok && a.hh[p] <= DMA_HROWS && a.hw[p] <= DMA_HP && a.hw[p] - HT <= 2;
   if (dma_ok) {
     const int tp = mod ? (g_halo_dma_mod == 2 ? 2 : 1) : (g_halo_dma == 2 ? 2 : 1);
@@ -1663,7 +1715,7 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
     hipLaunchKernelGGL((conv_halo_kernel<1, false, EP, TPV, MD>), grid, dim3(512), dsmem, s, a);                        \
   }
 #define LAUNCH_DMA_EPI(TPV)                                                                                             \
-  { if (a.residual && a.res_half) LAUNCH_DMA(2, TPV, false) else if (a.residual) LAUNCH_DMA(1, TPV, false) else LAUNCH_DMA(0, TPV, false) }
+  { if (a.xs) LAUNCH_DMA(3, TPV, false) else if (a.residual && a.res_half) LAUNCH_DMA(2, TPV, false) else if (a.residual) LAUNCH_DMA(1, TPV, false) else LAUNCH_DMA(0, TPV, false) }
 #define LAUNCH_DMA_MOD(TPV)                                                                                             \
   { if (a.xs) LAUNCH_DMA(3, TPV, true) else if (a.residual && a.res_half) LAUNCH_DMA(2, TPV, true)                      \
     else if (a.residual) LAUNCH_DMA(1, TPV, true) else LAUNCH_DMA(0, TPV, true) }
@@ -1673,7 +1725,7 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
     if (!set) { hipFuncSetAttribute((const void*)conv_halo_kernel<1, true, EP, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
     hipLaunchKernelGGL((conv_halo_kernel<1, true, EP, 2, false>), grid, dim3(512), dsmem, s, a);                        \
   }
-    if (g_mfma16 == 2 && !mod && tp == 2) { if (a.residual && a.res_half) LAUNCH_DMA16(2) else if (a.residual) LAUNCH_DMA16(1) else LAUNCH_DMA16(0) }
+    if (g_mfma16 == 2 && !mod && !a.xs && tp == 2) { if (a.residual && a.res_half) LAUNCH_DMA16(2) else if (a.residual) LAUNCH_DMA16(1) else LAUNCH_DMA16(0) }
     else if (mod) { if (tp == 2) LAUNCH_DMA_MOD(2) else LAUNCH_DMA_MOD(1) }
     else if (tp == 2) LAUNCH_DMA_EPI(2) else LAUNCH_DMA_EPI(1)
 #undef LAUNCH_DMA16
@@ -2554,6 +2606,7 @@ int lcgan_set_option(int option, int value) {
   if (option == 15) { const int old = g_wgrad_xcd; g_wgrad_xcd = value; return old; }
   if (option == 16) { const int old = g_igemm_dma; g_igemm_dma = value; return old; }
   if (option == 17) { const int old = g_wgrad_prescale_mb; g_wgrad_prescale_mb = value; return old; }
+  if (option == 18) { const int old = g_halo_wmod_mb; g_halo_wmod_mb = value; return old; }
   return LCGAN_EINVAL;
 }
 

@@ -160,6 +160,51 @@ def test_conv_wgrad_prescaled_path(H, case):
     check(new, old.cpu(), dtype, "prescaled vs per-sample ranges", l2_scale=2.0)
 
 
+@pytest.mark.parametrize("case", [(4, 32, 32, 64, 128, 1, "fwd"), (4, 32, 32, 128, 64, 1, "dgrad"), (4, 16, 16, 64, 96, 2, "up"), (4, 32, 32, 96, 64, 2, "down"),
+                                  (8, 64, 64, 128, 128, 1, "fwd"), (8, 64, 64, 128, 128, 1, "dgrad")])
+def test_conv_per_sample_weights(H, case):
+    """convolutions with per-sample input scales through per-sample weight copies (option 18; the scales folded into the weights once,
+    then the unscaled LDS-DMA kernels) against the in-LDS scaling path (option 18 = 0) and the emulation: plain, + residual, and with the
+    fused style-gradient reduction; forward, data gradient, x2 transposed (`up`) and stride-2 forward (`down`) geometries.  Option 6 = 1
+    lets these small grids take the halo kernels at all."""
+    B, Hh, W, Ci, Co, stride, kind = case
+    dtype, k = torch.bfloat16, 3
+    x = feat((B, Hh, W, ceil8(Ci)), dtype, 1, Ci)
+    w = torch.randn(Co, Ci, k, k, generator=torch.Generator().manual_seed(2)) if kind in ("fwd", "down") else torch.randn(Ci, Co, k, k, generator=torch.Generator().manual_seed(2))
+    scale = 1 / math.sqrt(Ci * k * k)
+    tr = kind in ("dgrad", "up")
+    pw_e, _ = E.prep_weight(w, scale, tr, False)
+    pw_h, _ = H.prep_weight(w.cuda(), scale, tr, False)
+    pre, post = vec((B, ceil8(Ci)), 4), vec((B, ceil8(Co)), 5)
+    fn_h = H.conv_bwd_data if tr else H.conv_fwd
+    fn_e = E.conv_bwd_data if tr else E.conv_fwd
+    st = stride
+    ref = fn_e(x, pw_e, Co, k, st, pre=pre, post=post)
+    xs = feat(tuple(ref.shape), dtype, 6, Co)
+    old6 = H.lib.lcgan_set_option(6, 1)
+    try:
+        outs = {}
+        for mb in (80, 0):
+            old18 = H.lib.lcgan_set_option(18, mb)
+            try:
+                y = fn_h(x.cuda(), pw_h, Co, k, st, pre=pre.cuda(), post=post.cuda())
+                yr = fn_h(x.cuda(), pw_h, Co, k, st, pre=pre.cuda(), post=post.cuda(), residual=xs.cuda()) if kind != "up" else None
+                yg, gs = fn_h(x.cuda(), pw_h, Co, k, st, pre=pre.cuda(), post=post.cuda(), xs=xs.cuda())
+                outs[mb] = (y, yr, yg, gs)
+            finally:
+                H.lib.lcgan_set_option(18, old18)
+    finally:
+        H.lib.lcgan_set_option(6, old6)
+    yg_e, gs_e = fn_e(x, pw_e, Co, k, st, pre=pre, post=post, xs=xs)
+    for mb, (y, yr, yg, gs) in outs.items():
+        check(y, ref, dtype, f"option 18 = {mb}: plain", l2_scale=2.0)            # (w * pre rounded instead of pre * x: another bf16 rounding pattern)
+        if yr is not None:
+            check(yr, fn_e(x, pw_e, Co, k, st, pre=pre, post=post, residual=xs), dtype, f"option 18 = {mb}: residual", l2_scale=2.0)
+        check(yg, yg_e, dtype, f"option 18 = {mb}: fused y", l2_scale=2.0)
+        check(gs, gs_e, dtype, f"option 18 = {mb}: fused gs", l2_scale=3.0)
+    check(outs[80][0], outs[0][0].cpu(), dtype, "per-sample weights vs in-LDS scaling", l2_scale=2.0)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd(H, dtype, case):
