@@ -48,7 +48,8 @@ int g_halo_s2dma = 4;                     // lcgan_set_option(13, ...): stride-2
 int g_halo_nb_group_kb = 8192;               // lcgan_set_option(14, ...): KB of weights (all taps x 128 rows x Cin) that concurrent channel blocks of one tile may hold in an XCD's L2; 0 = channel blocks slowest (one pass over the input per block)
 int g_wgrad_xcd = 0;                      // lcgan_set_option(15, ...): row-segment wgrad workgroups of one split share an XCD (1-D grid)
 int g_igemm_dma = 2;                      // lcgan_set_option(16, ...): LDS-DMA staging in the generic implicit-GEMM kernel (bf16, no input scales, Cin % 32 == 0)
-int g_halo_wmod_mb = 80;                  // lcgan_set_option(18, ...): convolutions with per-sample INPUT scales (modulated convs and their data gradients) whose per-sample
+int g_halo_wmod_mb = 40;                  // (measured at batch 32: 9 MB of copies (128 x 128 layers) -56 us per launch, 38 MB (256 x 256) -25 us, 75 MB (512 x 256) +89 us: the copies stop fitting the L2s)
+                                          // lcgan_set_option(18, ...): convolutions with per-sample INPUT scales (modulated convs and their data gradients) whose per-sample
                                           // weight copies (B x taps x N x Kpad bf16) fit this many MB fold the scales into the weights once and run the unscaled kernels; 0 = never
 int g_wgrad_prescale_mb = 180;            // lcgan_set_option(17, ...): weight gradients with per-sample operand scales whose two operands together are at most this many MB
                                           // get the scales applied ONCE by an elementwise pass (bf16) and then run as ONE batch-wide reduction; 0 = never

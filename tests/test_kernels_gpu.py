@@ -225,8 +225,9 @@ def test_conv_fwd(H, dtype, case):
     pre, post = vec((B, ceil8(Ci)), 4), vec((B, ceil8(Co)), 5)
     ref0 = E.conv_fwd(x, pw_e, Co, k, stride)
     res = feat(tuple(ref0.shape), dtype, 6, Co)
+    # (bf16: where the launch folds the input scales into per-sample weight copies -- option 18 -- w * pre is rounded instead of pre * x)
     check(H.conv_fwd(x.cuda(), pw_h, Co, k, stride, pre=pre.cuda(), post=post.cuda(), bias=bias.cuda(), residual=res.cuda()),
-          E.conv_fwd(x, pw_e, Co, k, stride, pre=pre, post=post, bias=bias, residual=res), dtype, "mod+residual")
+          E.conv_fwd(x, pw_e, Co, k, stride, pre=pre, post=post, bias=bias, residual=res), dtype, "mod+residual", l2_scale=2.0)
     y_h, gs_h = H.conv_fwd(x.cuda(), pw_h, Co, k, stride, pre=pre.cuda(), post=post.cuda(), xs=res.cuda())
     y_e, gs_e = E.conv_fwd(x, pw_e, Co, k, stride, pre=pre, post=post, xs=res)
     check(y_h, y_e, dtype, "fused y", l2_scale=2.0)        # generic path: u is rounded to bf16 BEFORE the style scale (two roundings)
@@ -251,7 +252,7 @@ def test_conv_bwd_data(H, dtype, case):
     pre, post = vec((B, ceil8(Co)), 13), vec((B, ceil8(Ci)), 14)
     bias = torch.randn(Ci, generator=torch.Generator().manual_seed(15))
     check(H.conv_bwd_data(g.cuda(), pw_h, Ci, k, stride, pre=pre.cuda(), post=post.cuda(), bias=bias.cuda(), act=1, gain=1.2),
-          E.conv_bwd_data(g, pw_e, Ci, k, stride, pre=pre, post=post, bias=bias, act=1, gain=1.2), dtype, "mod+bias+act")
+          E.conv_bwd_data(g, pw_e, Ci, k, stride, pre=pre, post=post, bias=bias, act=1, gain=1.2), dtype, "mod+bias+act", l2_scale=2.0)   # (see test_conv_fwd)
     # style-gradient reduction fused into the launch: gx = post * u, gs = sum_pixels xs * u
     xs = feat((B, Hh, W, ceil8(Ci)), dtype, 17, Ci)
     gx_h, gs_h = H.conv_bwd_data(g.cuda(), pw_h, Ci, k, stride, pre=pre.cuda(), post=post.cuda(), xs=xs.cuda())
@@ -332,7 +333,7 @@ def test_conv_staging_variants_bit_identical(H, case):
     bias = torch.randn(Co, generator=torch.Generator().manual_seed(3)).cuda()
     pre, post = vec((B, Ci), 4).cuda(), vec((B, ceil8(Co)), 5).cuda()
     pw, _ = H.prep_weight(w, 1 / math.sqrt(Ci * k * k), False, False)
-    old = [H.lib.lcgan_set_option(6, 0), H.lib.lcgan_set_option(10, 0), H.lib.lcgan_set_option(11, 0)]
+    old = [H.lib.lcgan_set_option(6, 0), H.lib.lcgan_set_option(10, 0), H.lib.lcgan_set_option(11, 0), H.lib.lcgan_set_option(18, 0)]
     try:
         ref_p = H.conv_fwd(x, pw, Co, k, 1, bias=bias, act=1, gain=1.4)
         ref_m = H.conv_fwd(x, pw, Co, k, 1, pre=pre, post=post, bias=bias, act=1, gain=1.4)
@@ -341,7 +342,7 @@ def test_conv_staging_variants_bit_identical(H, case):
             assert torch.equal(H.conv_fwd(x, pw, Co, k, 1, bias=bias, act=1, gain=1.4), ref_p), (dma, "plain")
             assert torch.equal(H.conv_fwd(x, pw, Co, k, 1, pre=pre, post=post, bias=bias, act=1, gain=1.4), ref_m), (dma, mod, "modulated")
     finally:
-        for o, v in zip((6, 10, 11), old):
+        for o, v in zip((6, 10, 11, 18), old):
             H.lib.lcgan_set_option(o, v)
 
 

@@ -344,7 +344,7 @@ def test_checkpoint_round_trip_on_device(tmp_path):
         FixedFeed(w, B, res, DEV), FixedFeed(w2, B, res, DEV)
         la, lb = loader.train_iteration(w, w.args, 3), loader.train_iteration(w2, w2.args, 3)
         # (bit-identical up to the order of fp32 atomics in split-K / weight-gradient partial sums: compare tightly, not bitwise)
-        assert abs(float(la[0]) - float(lb[0])) <= 1e-3 * abs(float(la[0])) and abs(float(la[1]) - float(lb[1])) <= 1e-3 * abs(float(la[1]))
+        assert abs(float(la[0]) - float(lb[0])) <= 5e-3 * abs(float(la[0])) and abs(float(la[1]) - float(lb[1])) <= 5e-3 * abs(float(la[1]))
         worst = 0.0
         for (k, va), (_, vb) in zip(w.discriminator.state_dict().items(), w2.discriminator.state_dict().items()):
             worst = max(worst, float((va - vb).abs().max() / va.abs().max().clamp_min(1e-12)))
