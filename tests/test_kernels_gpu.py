@@ -286,6 +286,7 @@ def test_conv_halo_staging_variants(H, case, variant):
     B, Hh, W, Ci, Co, k, stride = case
     dtype = torch.bfloat16
     old = [H.lib.lcgan_set_option(6, 0), H.lib.lcgan_set_option(10, variant[0]), H.lib.lcgan_set_option(11, variant[1]), H.lib.lcgan_set_option(13, 1)]
+    old18 = H.lib.lcgan_set_option(18, 0)          # the in-kernel input scaling is what these variants are (per-sample weight copies: test_conv_per_sample_weights)
     try:
         scale = 1 / math.sqrt(Ci * k * k)
         w = torch.randn(Co, Ci, k, k, generator=torch.Generator().manual_seed(2))
@@ -321,6 +322,7 @@ def test_conv_halo_staging_variants(H, case, variant):
     finally:
         for o, v in zip((6, 10, 11, 13), old):
             H.lib.lcgan_set_option(o, v)
+        H.lib.lcgan_set_option(18, old18)
 
 
 @pytest.mark.parametrize("case", [(2, 64, 64, 128, 128, 3, 1), (1, 64, 128, 64, 256, 3, 1), (2, 64, 64, 96, 160, 1, 1)])
