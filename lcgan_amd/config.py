@@ -23,18 +23,6 @@ import os as _os
 _flow_gemm = _os.environ.get("LCGAN_FLOW_GEMM", "1") != "0"     # A/B switch: the flow layer as 1x1 GEMM + scatter (ops.FlowConvFn) or the generic up-conv
 
 
-_side_wgrad = _os.environ.get("LCGAN_SIDE_WGRAD", "1") != "0"   # A/B switch: convolution weight gradients on a second HIP stream (ops.deferred_weight_grads)
-
-
-def side_stream_wgrad() -> bool:
-    return _side_wgrad
-
-
-def set_side_stream_wgrad(on: bool) -> None:
-    global _side_wgrad
-    _side_wgrad = bool(on)
-
-
 def flow_gemm() -> bool:
     return _flow_gemm
 

@@ -1457,23 +1457,22 @@ constexpr int MAX_DEV = 16;
 // The library-owned scratch buffers (split-K partials, weight-gradient slabs, prescaled operands) are reused launch after launch with
 // no event tracking: correct because the launches of a device are ordered on ONE stream.  A caller that switches streams (a side
 // stream, a capture stream) is ordered behind the work of the stream used before: the previous stream is drained once at the switch.
-enum { SCR_SPLITK = 0, SCR_SLAB, SCR_PRESCALE, SCR_WPRESCALE, SCR_WMOD, SCR_COUNT };       // (each buffer remembers the stream that used it last)
-hipStream_t g_scratch_stream[MAX_DEV][SCR_COUNT] = {};
-bool g_scratch_stream_set[MAX_DEV][SCR_COUNT] = {};
-void scratch_order(int dev, int which, hipStream_t s) {
-  if (g_scratch_stream_set[dev][which] && g_scratch_stream[dev][which] != s) {
+hipStream_t g_scratch_stream[MAX_DEV] = {};
+bool g_scratch_stream_set[MAX_DEV] = {};
+void scratch_order(int dev, hipStream_t s) {
+  if (g_scratch_stream_set[dev] && g_scratch_stream[dev] != s) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &st) != hipSuccess || st == hipStreamCaptureStatusNone) hipStreamSynchronize(g_scratch_stream[dev][which]);
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st == hipStreamCaptureStatusNone) hipStreamSynchronize(g_scratch_stream[dev]);
     (void)hipGetLastError();
   }
-  g_scratch_stream[dev][which] = s; g_scratch_stream_set[dev][which] = true;
+  g_scratch_stream[dev] = s; g_scratch_stream_set[dev] = true;
 }
 float* g_splitk_ws[MAX_DEV] = {};
 size_t g_splitk_ws_bytes[MAX_DEV] = {};
 float* splitk_scratch(size_t bytes, hipStream_t s) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
-  scratch_order(dev, SCR_SPLITK, s);
+  scratch_order(dev, s);
   if (bytes > g_splitk_ws_bytes[dev]) {
     if (g_splitk_ws[dev]) hipFree(g_splitk_ws[dev]);
     g_splitk_ws_bytes[dev] = std::max(bytes, (size_t)8 << 20);
@@ -1569,7 +1568,7 @@ size_t g_wmod_bytes[MAX_DEV] = {};
 __bf16* wmod_scratch(size_t bytes, hipStream_t s) {              // grow-only, per device; written in full before every use
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
-  scratch_order(dev, SCR_WMOD, s);
+  scratch_order(dev, s);
   if (bytes > g_wmod_bytes[dev]) {
     if (g_wmod[dev]) hipFree(g_wmod[dev]);
     g_wmod_bytes[dev] = std::max(bytes, (size_t)96 << 20);
@@ -2278,7 +2277,7 @@ size_t g_slab_bytes[MAX_DEV] = {};
 float* wgrad_slab_scratch(size_t bytes, hipStream_t s) {          // grow-only, per device, owned by the library; every element is written before it is read
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
-  scratch_order(dev, SCR_SLAB, s);
+  scratch_order(dev, s);
   if (bytes > g_slab_bytes[dev]) {
     if (g_slab[dev]) hipFree(g_slab[dev]);
     g_slab_bytes[dev] = std::max(bytes, (size_t)64 << 20);
@@ -2528,20 +2527,18 @@ __global__ void prescale_kernel(const __bf16* __restrict__ x, const float* __res
   for (int j = 0; j < 8; ++j) o[j] = (__bf16)((float)t[j] * (j < 4 ? p0[j] : p1[j - 4]));
   *(bf16x8*)(out + i * 8) = o;
 }
-// two buffers: [0] prescaled inputs of low-resolution modulated convolutions (the launch stream of the forward / data-gradient chain),
-// [1] prescaled operands of weight gradients (which may run on a side stream of their own, lcgan_amd/ops.py:deferred_weight_grads)
-__bf16* g_prescale[MAX_DEV][2] = {};
-size_t g_prescale_bytes[MAX_DEV][2] = {};
-__bf16* prescale_scratch(size_t bytes, hipStream_t s, int which = 0) {               // grow-only, per device; written in full before every use
+__bf16* g_prescale[MAX_DEV] = {};
+size_t g_prescale_bytes[MAX_DEV] = {};
+__bf16* prescale_scratch(size_t bytes, hipStream_t s) {               // grow-only, per device; written in full before every use
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
-  scratch_order(dev, which ? SCR_WPRESCALE : SCR_PRESCALE, s);
-  if (bytes > g_prescale_bytes[dev][which]) {
-    if (g_prescale[dev][which]) hipFree(g_prescale[dev][which]);
-    g_prescale_bytes[dev][which] = std::max(bytes, (size_t)16 << 20);
-    if (hipMalloc((void**)&g_prescale[dev][which], g_prescale_bytes[dev][which]) != hipSuccess) { g_prescale[dev][which] = nullptr; g_prescale_bytes[dev][which] = 0; return nullptr; }
+  scratch_order(dev, s);
+  if (bytes > g_prescale_bytes[dev]) {
+    if (g_prescale[dev]) hipFree(g_prescale[dev]);
+    g_prescale_bytes[dev] = std::max(bytes, (size_t)16 << 20);
+    if (hipMalloc((void**)&g_prescale[dev], g_prescale_bytes[dev]) != hipSuccess) { g_prescale[dev] = nullptr; g_prescale_bytes[dev] = 0; return nullptr; }
   }
-  return g_prescale[dev][which];
+  return g_prescale[dev];
 }
 
 // Small-M layers (4x4 ... 16x16 grids) are weight-streaming bound and would occupy a handful of CUs: split the (tap, chunk)
@@ -2796,7 +2793,7 @@ static int conv_wgrad_impl(const void* x, const void* g, float* gwp,
     const size_t bx = (size_t)B * Hx * Wx * Cx * sizeof(__bf16), bg = (size_t)B * Hg * Wg * Cg * sizeof(__bf16);
     const size_t ox = (bx + 255) & ~(size_t)255;
     if (bx + bg <= ((size_t)g_wgrad_prescale_mb << 20)) {
-      __bf16* buf = prescale_scratch(ox + bg, s, 1);
+      __bf16* buf = prescale_scratch(ox + bg, s);
       if (buf) {
         if (pre_x) {
           const long long nvec = (long long)(bx / 16);

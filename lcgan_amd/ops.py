@@ -95,69 +95,6 @@ def _ap(fn, *args):
     return fn.forward(_NoGraphCtx(), *args)
 
 
-# ---- weight gradients on a side stream --------------------------------------------------------------------------------------------
-# In a first-order backward pass nothing downstream waits for a convolution's WEIGHT gradient until the optimiser step, while its
-# launch sits in the middle of the data-gradient chain: a compute-bound MFMA kernel between memory-bound activation / box-filter /
-# warp passes, all on one stream, so the chip alternates between an idle matrix pipe and an idle memory system.  Inside
-# `with deferred_weight_grads():` (WORKER wraps its backward() calls in it) those launches go to a second HIP stream ordered behind
-# the producer of their operands; the node returns None for the parameter, the results are summed per parameter on the side stream
-# (which also takes autograd's accumulation adds off the main stream) and handed to `.grad` when the context exits, where the main
-# stream joins.  Under create_graph (the R1 pass) and outside the context nothing changes: the gradient is returned to autograd.
-_defer = {"on": False, "stream": None, "acc": {}}
-
-
-class deferred_weight_grads:
-    def __init__(self, enabled=None):
-        from . import config
-        self.enabled = config.side_stream_wgrad() if enabled is None else bool(enabled)
-
-    def __enter__(self):
-        self.prev = _defer["on"]
-        _defer["on"] = self.enabled
-        return self
-
-    def __exit__(self, *exc):
-        _defer["on"] = self.prev
-        if not self.prev:
-            flush_deferred_weight_grads()
-
-
-def flush_deferred_weight_grads() -> None:
-    acc, _defer["acc"] = _defer["acc"], {}
-    if not acc:
-        return
-    torch.cuda.current_stream().wait_stream(_defer["stream"])
-    with torch.no_grad():
-        for p, g in acc.values():
-            g.record_stream(torch.cuda.current_stream())
-            if p.grad is None:
-                p.grad = g
-            else:
-                p.grad.add_(g)
-
-
-def _deferred_wgrad(w, compute, operands) -> bool:
-    """compute() -> gradient in w's layout.  True: launched on the side stream and booked for w (the caller returns None for it)."""
-    if not (_defer["on"] and isinstance(w, torch.nn.Parameter) and w.is_cuda and not torch.is_grad_enabled() and not _inputs_only):
-        return False
-    main = torch.cuda.current_stream()
-    side = _defer["stream"]
-    if side is None or side.device != w.device:
-        side = _defer["stream"] = torch.cuda.Stream(device=w.device)
-    side.wait_stream(main)                                     # the operands were produced on the main stream
-    with torch.cuda.stream(side):
-        g = compute()
-        ent = _defer["acc"].get(id(w))
-        if ent is None:
-            _defer["acc"][id(w)] = (w, g)
-        else:
-            ent[1].add_(g)                                     # a parameter used by several passes (real + fake): summed here, off the main stream
-    for t in operands:
-        if t is not None:
-            t.record_stream(side)                              # (allocated on the main stream: not to be reused before the side stream has read it)
-    return True
-
-
 def _wants(ctx, i: int) -> bool:
     """does this backward owe a gradient for PARAMETER input i?"""
     return ctx.needs_input_grad[i] and not _inputs_only_here()
@@ -316,9 +253,7 @@ class Conv2dFn(Function):
         else:
             gz, gb = gy, None
         gx = _ap(ConvTransposeFn, gz, w, k, stride, wscale, x.shape[-1], None) if ctx.needs_input_grad[0] else None
-        gw = None
-        if _wants(ctx, 1) and not _deferred_wgrad(w, lambda: _K().conv_wgrad_unprep(x, gz, w.shape[0], w.shape[1], k, stride, wscale), (x, gz)):
-            gw = _ap(ConvWeightGradFn, x, gz, k, stride, wscale, w.shape[0], w.shape[1])
+        gw = _ap(ConvWeightGradFn, x, gz, k, stride, wscale, w.shape[0], w.shape[1]) if _wants(ctx, 1) else None
         gres = gy if (has_res and ctx.needs_input_grad[3]) else None
         return gx, gw, (gb if want_gb else None), gres, None, None, None, None, None, None
 
@@ -419,9 +354,7 @@ class ConvPoolFn(Function):
         gx = None
         if ctx.needs_input_grad[0]:
             gx = _ap(ConvTransposeFn, gz, w, k, 1, wscale, x.shape[-1], None if gpooled is None else gpooled.contiguous())
-        gw = None
-        if _wants(ctx, 1) and not _deferred_wgrad(w, lambda: _K().conv_wgrad_unprep(x, gz, w.shape[0], w.shape[1], k, 1, wscale), (x, gz)):
-            gw = _ap(ConvWeightGradFn, x, gz, k, 1, wscale, w.shape[0], w.shape[1])
+        gw = _ap(ConvWeightGradFn, x, gz, k, 1, wscale, w.shape[0], w.shape[1]) if _wants(ctx, 1) else None
         return gx, gw, (gb if want_gb else None), None, None, None, None, None, None, None
 
 
@@ -855,12 +788,10 @@ def _modconv_bwd_tail(x, w, s, d, wsq, gz, gdq, up, c_eq):
         gx, gs = K.conv_bwd_data(gz, pwT, Cin, k, 1, pre=d, post=s, xs=x)
     gwsq = K.demod_bwd(gdq, d, s, wsq, gs)                                   # gs += demod path
     if up == 2:
-        compute = lambda: K.conv_wgrad_unprep(gz, x, Cin, O, k, 2, c_eq, transposed=True, pre_x=d, pre_g=s, w=w, gwsq=gwsq)    # gwp [t][Cin][O]
+        gw = K.conv_wgrad_unprep(gz, x, Cin, O, k, 2, c_eq, transposed=True, pre_x=d, pre_g=s, w=w, gwsq=gwsq)    # gwp [t][Cin][O]
     else:
-        compute = lambda: K.conv_wgrad_unprep(x, gz, O, Cin, k, 1, c_eq, transposed=False, pre_x=s, pre_g=d, w=w, gwsq=gwsq)   # gwp [t][O][Cin]
-    if _deferred_wgrad(w, compute, (x, gz, d, s, gwsq)):
-        return gx, None, gs
-    return gx, compute(), gs
+        gw = K.conv_wgrad_unprep(x, gz, O, Cin, k, 1, c_eq, transposed=False, pre_x=s, pre_g=d, w=w, gwsq=gwsq)   # gwp [t][O][Cin]
+    return gx, gw, gs
 
 
 class ModConvRGBFn(Function):

@@ -16,7 +16,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from . import cnn, loss, ops
+from . import cnn, loss
 from .ema import Ema
 from .optim import Adam, DataParallel
 
@@ -213,8 +213,7 @@ class WORKER(object):
                           + loss.contrastive_loss(appearance_feat, appearance_positive, appearance_negative, self.args.tau)) * self.args.l_aux
             d_loss = d_adv_loss + d_aug_loss
 
-        with ops.deferred_weight_grads():          # convolution weight gradients on a side stream, joined when the pass is over
-            d_loss.backward()
+        d_loss.backward()
         self._after_backward("d", self.discriminator, self.d_optimizer)
         return LazyLoss(d_loss)
 
@@ -248,8 +247,7 @@ class WORKER(object):
                                                 self.generator.module.appearance_mapping.diagonal_params], self.args.l_s)
             g_loss = g_adv_loss + g_aug_loss + g_sparsity_loss
 
-        with ops.deferred_weight_grads():
-            g_loss.backward()
+        g_loss.backward()
         self._after_backward("g", self.generator, self.g_optimizer)
         return LazyLoss(g_loss)
 
