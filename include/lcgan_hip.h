@@ -187,9 +187,10 @@ int lcgan_multi_tensor(const void* descs, const int* chunk_tensor, const int* ch
  * kernel (0 off, 1 / 2 = taps per barrier); 11 the same record layout for convolutions with per-sample input scales; 12 LDS-DMA
  * weight-gradient kernel (0 off, 1, 2 = split for two workgroups per CU, 3 = also stride 2); 13 parity-plane stride-2 forward;
  * 14 KB of weights concurrent channel blocks of one tile may keep in an XCD's L2 (0 = one input pass per channel block);
- * 15 XCD-grouped weight-gradient workgroup order; 16 LDS-DMA staging of the generic implicit-GEMM kernel (2 = modulated low-resolution layers too, through one prescale pass);
+ * 15 XCD-grouped weight-gradient workgroup order; 16 LDS-DMA staging of the generic implicit-GEMM kernel (2 = modulated low-resolution layers too, through one prescale pass; 3 = its eight-wave form, 4 = with four stages);
  * 17 MB of operands up to which a weight gradient with per-sample scales applies them by one elementwise pass and reduces the whole batch as one range (0 = never);
- * 18 MB of per-sample weight copies up to which a convolution with per-sample input scales folds them into the weights (0 = never).  DESIGN.md section 2 ("Switches") has the measurements behind the defaults. */
+ * 18 MB of per-sample weight copies up to which a convolution with per-sample input scales folds them into the weights (0 = never);
+ * 19 split-K launches of the eight-wave generic kernel with at most this many splits exchange partials through per-split slabs and the last split to arrive finishes the tile (more, or 0: atomics + a finalize launch).  DESIGN.md section 2 ("Switches") has the measurements behind the defaults. */
 int lcgan_set_option(int option, int value);
 
 /* ---- per-launch HIP-event profiling (bench.py roofline) ---------------------------------------------------- */

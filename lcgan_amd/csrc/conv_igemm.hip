@@ -37,7 +37,7 @@ int g_mfma16 = 0;                         // lcgan_set_option(4, ...): halo kern
 int g_wgrad3_small = 0;                   // lcgan_set_option(5, ...): row-segment wgrad kernel for 16/8-wide layers and 1x1 kernels: 0 = only without per-sample scales (multi-sample splits), 1 = always, 2 = never
                                           // (default off: measured 0.5 ms/iteration SLOWER than the generic kernel on those shapes)
 int g_wgrad3_wgs = 0;                     // lcgan_set_option(2, ...): 0 = cost-model split of the row-segment wgrad kernel, > 0 = explicit workgroup target
-int g_halo_min_wgs = 128;                 // lcgan_set_option(6, ...): halo launches with fewer workgroups go to the split-K implicit GEMM
+int g_halo_min_wgs = 192;                 // lcgan_set_option(6, ...): halo launches with fewer workgroups go to the split-K implicit GEMM
 int g_wgrad_slab_min = 4;                 // lcgan_set_option(8, ...): row-segment wgrad launches with at least this many splits reduce through a slab instead of atomics (0 = never)
 int g_halo_narrow_min_wgs = 256;          // lcgan_set_option(7, ...): narrow-layer halo kernel (Cout <= 64, 16 x 32 tiles) from this many workgroups; 0 = never
 int g_wgrad3_pack = 1;                    // lcgan_set_option(9, ...): packed channel groups in the row-segment wgrad kernel for layers with <= 64 channels
@@ -47,7 +47,10 @@ int g_wgrad_dma = 3;                      // lcgan_set_option(12, ...): LDS-DMA 
 int g_halo_s2dma = 4;                     // lcgan_set_option(13, ...): stride-2 forward 3x3 on the parity-plane LDS-DMA structure: 0 off, 1 = layers without per-sample input scales, 2 = all (two stages per workgroup, one workgroup per CU), 4 = as 2 but unscaled layers with ONE stage per workgroup and two workgroups per CU
 int g_halo_nb_group_kb = 8192;               // lcgan_set_option(14, ...): KB of weights (all taps x 128 rows x Cin) that concurrent channel blocks of one tile may hold in an XCD's L2; 0 = channel blocks slowest (one pass over the input per block)
 int g_wgrad_xcd = 0;                      // lcgan_set_option(15, ...): row-segment wgrad workgroups of one split share an XCD (1-D grid)
-int g_igemm_dma = 2;                      // lcgan_set_option(16, ...): LDS-DMA staging in the generic implicit-GEMM kernel (bf16, no input scales, Cin % 32 == 0)
+int g_splitk_slabs = 8;                  // lcgan_set_option(19, ...): split-K launches of the 8-wave generic kernel with up to this many splits exchange partials through per-split slabs and
+                                          // the last split to arrive finishes the tile; more splits (or 0) = atomics + the finalize launch (the last split's serial sum grows with the count:
+                                          // measured -5..-7 us per launch at 2-4 splits, -1.6 at 8, +5 at 16, +14 at 32)
+int g_igemm_dma = 3;                      // lcgan_set_option(16, ...): LDS-DMA staging in the generic implicit-GEMM kernel (bf16, no input scales, Cin % 32 == 0)
 int g_halo_wmod_mb = 40;                  // (measured at batch 32: 9 MB of copies (128 x 128 layers) -56 us per launch, 38 MB (256 x 256) -25 us, 75 MB (512 x 256) +89 us: the copies stop fitting the L2s)
                                           // lcgan_set_option(18, ...): convolutions with per-sample INPUT scales (modulated convs and their data gradients) whose per-sample
                                           // weight copies (B x taps x N x Kpad bf16) fit this many MB fold the scales into the weights once and run the unscaled kernels; 0 = never
@@ -77,6 +80,7 @@ struct ConvArgs {
   int res_half;                              // residual is [B,Hout/2,Wout/2,Cout]: add 0.25 * residual[oy/2][ox/2] (avg_pool2d adjoint)
   void* pool_out;                            // optional by-product [B,Hout/2,Wout/2,Cout] = avg_pool2d(y, 2) (the next DiscriminatorBlock's skip input)
   int nsplit; float* ws;                     // split-K: blockIdx.z = phase * nsplit + split; raw fp32 partials are atomically added to ws [M_out pixels][Cout]
+  float* slab; int* cnt;                     // split-K of conv_igemm8_kernel: per-(tile, split) partial tiles and per-tile arrival counters (the last split to arrive sums and finishes)
   TapTable taps[4];
 };
 
@@ -379,6 +383,213 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         Feat<T>::st1(y + off, v);
       }
     }
+}
+
+// Eight-wave form of the LDS-DMA main loop above (bf16, same ConvArgs, same tiles and LDS records): 512 threads, waves 4 (M) x 2 (N),
+// each 32 x 64 outputs.  The launches that take this kernel run ONE workgroup per CU (few tiles x split-K), so with 4 waves every SIMD
+// held a single wave and nothing overlapped its DMA issue (8 instructions per stage, ~100 cycles each) or its ds_read latency with
+// MFMA work: a stage of 16 MFMAs per wave (512 cycles) took ~3000.  With two waves per SIMD one wave's MFMAs run under the other's
+// address work, each wave issues half the DMA pieces (one A and one B piece per chunk), and NST stages keep NST - 1 in flight.
+template <int NST>
+__global__ __launch_bounds__(512) void conv_igemm8_kernel(ConvArgs a) {
+  typedef __bf16 T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int QT = 128 * 64, SB = 4 * QT;                    // bytes per operand tile; per stage (two chunks: A, B, A, B)
+  int* row_off = (int*)(smem + NST * SB);
+  int* row_b = row_off + BM;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, phase = blockIdx.z / a.nsplit, split = blockIdx.z - phase * a.nsplit;
+  const TapTable& tt = a.taps[phase];
+  const int HWm = a.Hm * a.Wm;
+  if (tid < BM) {
+    const int m = m0 + tid;
+    const bool ok = m < a.M;
+    const int mm = ok ? m : 0;
+    const int b = mm / HWm, rem = mm - b * HWm;
+    const int iy = rem / a.Wm, ix = rem - iy * a.Wm;
+    const int oy = iy * a.out_mul + (phase >> 1), ox = ix * a.out_mul + (phase & 1);
+    row_off[tid] = ok ? ((b * a.Hout + oy) * a.Wout + ox) : -1;
+    row_b[tid] = b;
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int nq_all = tt.n * a.kc_per_tap;
+  const int per = (nq_all + a.nsplit - 1) / a.nsplit;
+  const int q0 = split * per, nq = min(q0 + per, nq_all);
+  const int widu = __builtin_amdgcn_readfirstlane(wid);
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(2u * (unsigned)(a.B * a.Hin * a.Win * a.Cin)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
+  // piece widu of each tile: rows 16 widu .. 16 widu + 15, four 16-byte slots per row
+  int abase, aiy, aix;
+  unsigned wvo;
+  {
+    const int row = 16 * widu + (lane >> 2), ch = ((lane & 3) ^ ((row >> 2) & 3)) * 8;
+    const int m = m0 + row;
+    const bool ok = m < a.M;
+    const int mm = ok ? m : 0;
+    const int b = mm / HWm, rem = mm - b * HWm;
+    const int iy = (rem / a.Wm) * a.in_mul, ix = (rem % a.Wm) * a.in_mul;
+    aiy = ok ? iy : -0x40000000; aix = ix;
+    abase = 2 * (((b * a.Hin + iy) * a.Win + ix) * a.Cin + ch);
+    const int n = n0 + row;
+    wvo = n < a.N ? 2u * (unsigned)(n * a.Kpad + ch) : 0xffffffffu;
+  }
+  auto dma = [&](int q, int buf) {                             // chunks q, q + 1 -> stage buf: 4 DMA instructions per wave
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bool live = q + h < nq;
+      const int qq = live ? q + h : q;
+      const int tap = qq / a.kc_per_tap, c0 = (qq - tap * a.kc_per_tap) * BK;
+      const int dy = tt.dy[tap], dx = tt.dx[tap];
+      const int tofs = 2 * ((dy * a.Win + dx) * a.Cin + c0);
+      char* S = smem + buf * SB + h * 2 * QT;
+      const bool ok = live && (unsigned)(aiy + dy) < (unsigned)a.Hin && (unsigned)(aix + dx) < (unsigned)a.Win;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void_g*)(S + widu * 1024), 16, ok ? (unsigned)(abase + tofs) : 0xffffffffu, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void_g*)(S + QT + widu * 1024), 16, live ? wvo : 0xffffffffu,
+                                               __builtin_amdgcn_readfirstlane(2 * (tt.wt[tap] * a.N * a.Kpad + c0)), 0, 0);
+    }
+  };
+  const int half = lane >> 5, sw = (lane >> 2) & 3;
+  const int fa0 = (wm * 32 + (lane & 31)) * 64 + ((half ^ sw) << 4);            // k-step 1: ^ 32
+  const int fb0 = QT + (wn * 64 + (lane & 31)) * 64 + ((half ^ sw) << 4);       // ni = 1: + 32 rows
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const char* S = smem + buf * SB + h * 2 * QT;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 af = *(const bf16x8*)(S + (fa0 ^ (ks * 32)));
+        const bf16x8 b0 = *(const bf16x8*)(S + (fb0 ^ (ks * 32)));
+        const bf16x8 b1 = *(const bf16x8*)(S + (fb0 ^ (ks * 32)) + 32 * 64);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[1], 0, 0, 0);
+      }
+    }
+  };
+  // NST stages, NST - 1 in flight: `s_waitcnt vmcnt(4 (NST - 2))` leaves the youngest NST - 2 stages pending (4 instructions each);
+  // towards the end fewer are outstanding and the wait is for everything (a stricter wait is always safe)
+  const int nstep = (nq - q0 + 1) >> 1;                        // stages of this split
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i)
+    if (i < nstep) dma(q0 + 2 * i, i);
+  if (nstep >= NST - 1) {
+    if constexpr (NST == 3) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();                                // (also publishes row_off / row_b: LDS writes are in order per wave, lgkmcnt below)
+  int cur = 0;
+  for (int st = 0; st < nstep; ++st) {
+    const int nxt = cur + NST - 1 >= NST ? cur - 1 : cur + NST - 1;
+    if (st + NST - 1 < nstep) dma(q0 + 2 * (st + NST - 1), nxt);
+    compute(cur);
+    if (st + NST - 1 < nstep) {
+      if constexpr (NST == 3) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    cur = cur + 1 == NST ? 0 : cur + 1;
+  }
+
+  if (a.nsplit > 1 && !a.slab) {            // split-K through atomics: raw partial sums; the finalize kernel applies the epilogue
+    if (q0 >= nq) return;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int ro = row_off[row];
+        if (ro >= 0 && n < a.Cout) atomicAdd(a.ws + (size_t)ro * a.Cout + n, acc[ni][r]);
+      }
+    }
+    return;
+  }
+  if (a.nsplit > 1) {
+    // split-K without float atomics or a second launch: every split stores its partial tile (registers as they are, one dword per
+    // thread and store: coalesced) in its own slab and bumps the tile's counter; the split that arrives LAST sums the slabs in split
+    // order (its own from registers: the result does not depend on the arrival order, unlike atomic accumulation) and runs the
+    // epilogue below.  The splits of a tile run on different XCDs, whose L2s are not coherent with each other: the partials move as
+    // device-scope relaxed atomic stores / loads (sc1: written through, read past the local L2) ordered around the counter by
+    // vmcnt(0) + the workgroup barrier; device-scope FENCES (__threadfence) would write back and invalidate the whole L2 per wave,
+    // measured at +55 us per launch.  An empty split (q0 >= nq) contributes zeros.  The counter is left at 0 for the next launch.
+    int& s_last = row_b[BM];                                   // (one more int of the dynamic allocation)
+    const int tile = (phase * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    float* slabs = a.slab + (size_t)tile * a.nsplit * (BM * BN);
+    float* mine = slabs + (size_t)split * (BM * BN);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        __hip_atomic_store(mine + (ni * 16 + r) * 512 + tid, acc[ni][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const int old = __hip_atomic_fetch_add(a.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = old == a.nsplit - 1;
+      if (last) __hip_atomic_store(a.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    f32x16 tot[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tot[j][r] = 0.f;
+    for (int sp = 0; sp < a.nsplit; ++sp) {
+      if (sp == split) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tot[j][r] += acc[j][r];
+      } else {
+        const float* other = slabs + (size_t)sp * (BM * BN);
+        float v[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v[j] = __hip_atomic_load(other + j * 512 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) tot[j >> 4][j & 15] += v[j];
+      }
+    }
+    acc[0] = tot[0]; acc[1] = tot[1];
+  }
+  T* __restrict__ y = (T*)a.y;
+  const T* __restrict__ res = (const T*)a.residual;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int n = n0 + wn * 64 + ni * 32 + (lane & 31);
+    const bool nalloc = n < a.Cout, nlog = n < a.N;
+    const float bv = (a.bias && nlog) ? a.bias[n] * a.bias_scale : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int ro = row_off[row];
+      if (ro < 0 || !nalloc) continue;
+      float v = acc[ni][r];
+      if (a.post) v *= a.post[(size_t)row_b[row] * a.post_stride + n];
+      v += bv;
+      v = act_fwd(v, a.act) * a.gain;
+      const size_t off = (size_t)ro * a.Cout + n;
+      if (res) {
+        if (a.res_half) {
+          const int ox = ro % a.Wout, t = ro / a.Wout, oy = t % a.Hout, bb = t / a.Hout;
+          v += 0.25f * Feat<T>::ld1(res + ((size_t)(bb * (a.Hout >> 1) + (oy >> 1)) * (a.Wout >> 1) + (ox >> 1)) * a.Cout + n);
+        } else {
+          v += Feat<T>::ld1(res + off);
+        }
+      }
+      Feat<T>::st1(y + off, v);
+    }
+  }
 }
 
 // =========================================================================================================
@@ -1481,6 +1692,27 @@ float* splitk_scratch(size_t bytes, hipStream_t s) {
   }
   return g_splitk_ws[dev];
 }
+// partial-tile slabs + arrival counters of conv_igemm8_kernel's split-K (counters: zero at allocation, left at zero by every launch)
+float* g_splitk_slab[MAX_DEV] = {};
+size_t g_splitk_slab_bytes[MAX_DEV] = {};
+int* g_splitk_cnt[MAX_DEV] = {};
+constexpr int SPLITK_MAX_TILES = 4096;
+float* splitk_slab_scratch(size_t bytes, int** cnt, hipStream_t s) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  scratch_order(dev, s);
+  if (!g_splitk_cnt[dev]) {
+    if (hipMalloc((void**)&g_splitk_cnt[dev], SPLITK_MAX_TILES * sizeof(int)) != hipSuccess) { g_splitk_cnt[dev] = nullptr; return nullptr; }
+    hipMemsetAsync(g_splitk_cnt[dev], 0, SPLITK_MAX_TILES * sizeof(int), s);
+  }
+  if (bytes > g_splitk_slab_bytes[dev]) {
+    if (g_splitk_slab[dev]) hipFree(g_splitk_slab[dev]);
+    g_splitk_slab_bytes[dev] = std::max(bytes, (size_t)32 << 20);
+    if (hipMalloc((void**)&g_splitk_slab[dev], g_splitk_slab_bytes[dev]) != hipSuccess) { g_splitk_slab[dev] = nullptr; g_splitk_slab_bytes[dev] = 0; return nullptr; }
+  }
+  *cnt = g_splitk_cnt[dev];
+  return g_splitk_slab[dev];
+}
 template <typename T>
 __global__ void conv_finalize_kernel(float* __restrict__ ws, T* __restrict__ y, const float* __restrict__ post,
                                      const float* __restrict__ bias, const T* __restrict__ residual,
@@ -2502,11 +2734,21 @@ int launch_igemm(const ConvArgs& a, int nphase, hipStream_t s) {
     if (dmaq) {
       static bool dset = false;
       if (!dset) { hipFuncSetAttribute((const void*)conv_igemm_kernel<T, NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); dset = true; }
+      if (g_igemm_dma >= 3) {
+        static bool d8 = false;
+        if (!d8) {
+          hipFuncSetAttribute((const void*)conv_igemm8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 4 * 128 * 64 + (2 * BM + 4) * (int)sizeof(int));
+          hipFuncSetAttribute((const void*)conv_igemm8_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4 * 128 * 64 + (2 * BM + 4) * (int)sizeof(int));
+          d8 = true;
+        }
+        if (g_igemm_dma == 3) hipLaunchKernelGGL((conv_igemm8_kernel<3>), grid, dim3(512), (size_t)(3 * 4 * 128 * 64 + (2 * BM + 4) * sizeof(int)), s, a);
+        else hipLaunchKernelGGL((conv_igemm8_kernel<4>), grid, dim3(512), (size_t)(4 * 4 * 128 * 64 + (2 * BM + 4) * sizeof(int)), s, a);
+      } else
       hipLaunchKernelGGL((conv_igemm_kernel<T, NS, true>), grid, dim3(256), (size_t)(12 * 128 * 64 + 2 * BM * sizeof(int)), s, a);
     }
   }
   if (!dmaq) hipLaunchKernelGGL((conv_igemm_kernel<T, NS>), grid, dim3(256), smem, s, a);
-  if (a.nsplit > 1) launch_finalize<T>(a, a.ws, s);
+  if (a.nsplit > 1 && !a.slab) launch_finalize<T>(a, a.ws, s);
   return launch_status();
 }
 
@@ -2545,7 +2787,7 @@ __bf16* prescale_scratch(size_t bytes, hipStream_t s) {               // grow-on
 // loop over blockIdx.z so >= ~256 workgroups stream disjoint weight slices; partials meet in an fp32 workspace.
 int dispatch_igemm(const ConvArgs& a_in, int nphase, int dtype, hipStream_t s) {
   ConvArgs a = a_in;
-  a.nsplit = 1; a.ws = nullptr;
+  a.nsplit = 1; a.ws = nullptr; a.slab = nullptr; a.cnt = nullptr;
   g_pool_written = false;
   if (dtype == DT_BF16 && g_use_halo && try_launch_halo(a, nphase, a.in_mul, s)) return launch_status();
   if (g_igemm_dma >= 2 && dtype == DT_BF16 && a.pre && a.Cin % 32 == 0 && a.Kpad == a.Cin && a.M >= 2048) {   // (below that the extra launch costs what the faster main loop gains: measured at local batch 4)
@@ -2566,8 +2808,16 @@ int dispatch_igemm(const ConvArgs& a_in, int nphase, int dtype, hipStream_t s) {
   if (g_use_splitk && wgs <= 192 && nq_min >= 8) {
     int ns = std::min(nq_min / 4, (256 + wgs - 1) / wgs);
     if (ns > 1) {
-      float* ws = splitk_scratch((size_t)a.B * a.Hout * a.Wout * a.Cout * sizeof(float), s);
-      if (ws) { a.nsplit = ns; a.ws = ws; }
+      const bool k8 = dtype == DT_BF16 && g_igemm_dma >= 3 && g_splitk_slabs > 0 && ns <= g_splitk_slabs && !a.pre && a.Cin % 32 == 0 && a.Kpad == a.Cin &&
+                      (long long)a.B * a.Hin * a.Win * a.Cin < (1ll << 31) && wgs <= SPLITK_MAX_TILES;      // (launch_igemm's conditions for conv_igemm8_kernel)
+      if (k8) {
+        int* cnt = nullptr;
+        float* slab = splitk_slab_scratch((size_t)wgs * ns * BM * BN * sizeof(float), &cnt, s);
+        if (slab) { a.nsplit = ns; a.slab = slab; a.cnt = cnt; }
+      } else {
+        float* ws = splitk_scratch((size_t)a.B * a.Hout * a.Wout * a.Cout * sizeof(float), s);
+        if (ws) { a.nsplit = ns; a.ws = ws; }
+      }
     }
   }
   // generic path: the fused style-gradient reduction (xs, gs) runs as its own pass over the unscaled output
@@ -2606,6 +2856,7 @@ int lcgan_set_option(int option, int value) {
   if (option == 14) { const int old = g_halo_nb_group_kb; g_halo_nb_group_kb = value; return old; }
   if (option == 15) { const int old = g_wgrad_xcd; g_wgrad_xcd = value; return old; }
   if (option == 16) { const int old = g_igemm_dma; g_igemm_dma = value; return old; }
+  if (option == 19) { const int old = g_splitk_slabs; g_splitk_slabs = value; return old; }
   if (option == 17) { const int old = g_wgrad_prescale_mb; g_wgrad_prescale_mb = value; return old; }
   if (option == 18) { const int old = g_halo_wmod_mb; g_halo_wmod_mb = value; return old; }
   return LCGAN_EINVAL;

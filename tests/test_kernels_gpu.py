@@ -387,6 +387,37 @@ def test_conv_igemm_register_staging(H, case):
         H.lib.lcgan_set_option(16, old)
 
 
+@pytest.mark.parametrize("opts", [(2, 0), (3, 0), (3, 8), (4, 64)])
+@pytest.mark.parametrize("case", [(2, 8, 8, 64, 128, 3, 1), (8, 8, 8, 512, 512, 3, 1), (4, 4, 4, 512, 512, 3, 1), (3, 16, 16, 64, 96, 3, 2), (2, 8, 8, 128, 256, 1, 1),
+                                  (32, 16, 16, 128, 128, 3, 1)])
+def test_conv_igemm_dma_variants(H, case, opts):
+    """the generic implicit-GEMM kernel's LDS-DMA loops: four waves (option 16 = 2), eight waves with three / four stages (3 / 4), split-K
+    through atomics + finalize (option 19 = 0) or through per-split slabs finished by the last split to arrive (up to option 19 splits);
+    the slab form sums in split order, so two launches agree bit for bit"""
+    B, Hh, W, Ci, Co, k, stride = case
+    dtype = torch.bfloat16
+    old16, old19, old6 = H.lib.lcgan_set_option(16, opts[0]), H.lib.lcgan_set_option(19, opts[1]), H.lib.lcgan_set_option(6, 1 << 20)
+    try:
+        x = feat((B, Hh, W, Ci), dtype, 1)
+        w = torch.randn(Co, Ci, k, k, generator=torch.Generator().manual_seed(2))
+        scale = 1 / math.sqrt(Ci * k * k)
+        pw_e, _ = E.prep_weight(w, scale, False, False)
+        pw_h, _ = H.prep_weight(w.cuda(), scale, False, False)
+        bias = vec((Co,), 5)
+        res = feat((B, Hh // stride, W // stride, ceil8(Co)), dtype, 7, Co)
+        got = H.conv_fwd(x.cuda(), pw_h, Co, k, stride, bias=bias.cuda(), act=1, gain=1.4, residual=res.cuda())
+        check(got, E.conv_fwd(x, pw_e, Co, k, stride, bias=bias, act=1, gain=1.4, residual=res), dtype, "fwd")
+        if opts[1] >= 64:
+            again = H.conv_fwd(x.cuda(), pw_h, Co, k, stride, bias=bias.cuda(), act=1, gain=1.4, residual=res.cuda())
+            assert torch.equal(got, again)
+        g = feat((B, Hh // stride, W // stride, ceil8(Co)), dtype, 11, Co)
+        pw_e, _ = E.prep_weight(w, scale, True, False)
+        pw_h, _ = H.prep_weight(w.cuda(), scale, True, False)
+        check(H.conv_bwd_data(g.cuda(), pw_h, Ci, k, stride), E.conv_bwd_data(g, pw_e, Ci, k, stride), dtype, "dgrad")
+    finally:
+        H.lib.lcgan_set_option(16, old16); H.lib.lcgan_set_option(19, old19); H.lib.lcgan_set_option(6, old6)
+
+
 @pytest.mark.parametrize("case", [(2, 64, 64, 128, 128, 3, 1, False), (2, 64, 64, 64, 96, 3, 2, True), (4, 16, 16, 128, 256, 3, 1, False),
                                   (1, 32, 32, 72, 40, 1, 1, False)])
 def test_conv_wgrad_unprep_fused(H, case):
