@@ -190,7 +190,9 @@ int lcgan_multi_tensor(const void* descs, const int* chunk_tensor, const int* ch
  * 15 XCD-grouped weight-gradient workgroup order; 16 LDS-DMA staging of the generic implicit-GEMM kernel (2 = modulated low-resolution layers too, through one prescale pass; 3 = its eight-wave form, 4 = with four stages);
  * 17 MB of operands up to which a weight gradient with per-sample scales applies them by one elementwise pass and reduces the whole batch as one range (0 = never);
  * 18 MB of per-sample weight copies up to which a convolution with per-sample input scales folds them into the weights (0 = never);
- * 19 split-K launches of the eight-wave generic kernel with at most this many splits exchange partials through per-split slabs and the last split to arrive finishes the tile (more, or 0: atomics + a finalize launch).  DESIGN.md section 2 ("Switches") has the measurements behind the defaults. */
+ * 19 split-K launches of the eight-wave generic kernel with at most this many splits exchange partials through per-split slabs and the last split to arrive finishes the tile (more, or 0: atomics + a finalize launch);
+ * 20 launch plan of the small-grid (8 x 8, 16 x 16) weight gradients: splits from a measured cost model, a single split writes the gradient in weight layout from its epilogue (0 = the round-2 plan);
+ * 21 forced split count of the small-grid weight gradients (tuning; 0 = automatic).  DESIGN.md section 2 ("Switches") has the measurements behind the defaults. */
 int lcgan_set_option(int option, int value);
 
 /* ---- per-launch HIP-event profiling (bench.py roofline) ---------------------------------------------------- */

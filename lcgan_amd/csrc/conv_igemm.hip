@@ -47,6 +47,10 @@ int g_wgrad_dma = 3;                      // lcgan_set_option(12, ...): LDS-DMA 
 int g_halo_s2dma = 4;                     // lcgan_set_option(13, ...): stride-2 forward 3x3 on the parity-plane LDS-DMA structure: 0 off, 1 = layers without per-sample input scales, 2 = all (two stages per workgroup, one workgroup per CU), 4 = as 2 but unscaled layers with ONE stage per workgroup and two workgroups per CU
 int g_halo_nb_group_kb = 8192;               // lcgan_set_option(14, ...): KB of weights (all taps x 128 rows x Cin) that concurrent channel blocks of one tile may hold in an XCD's L2; 0 = channel blocks slowest (one pass over the input per block)
 int g_wgrad_xcd = 0;                      // lcgan_set_option(15, ...): row-segment wgrad workgroups of one split share an XCD (1-D grid)
+int g_wgrad_low_direct = 1;               // lcgan_set_option(20, ...): launch plan of the small-grid (8 x 8, 16 x 16) weight gradients without per-sample scales: splits chosen by the measured
+                                          // cost model in conv_wgrad_impl, one split = the epilogue writes the finished gradient in weight layout, XCD order only from 8 splits
+                                          // (0 = the round-2 plan: >= 1024 positions per split, XCD order always, atomics below 4 splits)
+int g_wgrad_low_parts = 0;                // lcgan_set_option(21, ...): force the number of splits of the small-grid weight gradients (tuning experiments; 0 = automatic)
 int g_splitk_slabs = 8;                  // lcgan_set_option(19, ...): split-K launches of the 8-wave generic kernel with up to this many splits exchange partials through per-split slabs and
                                           // the last split to arrive finishes the tile; more splits (or 0) = atomics + the finalize launch (the last split's serial sum grows with the count:
                                           // measured -5..-7 us per launch at 2-4 splits, -1.6 at 8, +5 at 16, +14 at 32)
@@ -1991,7 +1995,9 @@ struct WgradArgs {
   int parts;                                 // wgrad3: split = group * parts + part
   int cps_group;                             // wgrad3: chunks per group (group = one sample when per-sample scales exist, else the whole batch)
   float* slab;                               // wgrad3: non-null = every split stores its partial tile to slab[split][tap][A][Bc] (plain stores) instead of atomics
-  int xcd_order, na, nc;                     // wgrad3: 1-D XCD-aware workgroup order (see WG3_INDEX); a / c blocks of 128
+  int xcd_order, na, nc;                     // wgrad3: 1-D XCD-aware workgroup order (see WG3_INDEX); a / c blocks of 128  // wgrad3, single split, fused un-prep: the epilogue writes the gradient in WEIGHT layout itself (no gwp clear, no atomics, no second launch):
+  // dgw[a][b][t] = dscale * acc + 2 dscale^2 dw[a][b][t] dgwsq[a][b]  (see unprep_wgrad_kernel; dtransposed: the weight is [Bc][A])
+  float* dgw; const float* dw; const float* dgwsq; float dscale; int dtransposed;
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -2308,6 +2314,29 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
     if (q + 1 < q_end) step(q + 1, s1, s0);
   }
 
+  if (PK == 1 && a.dgw) {                                    // single split: finished gradient straight to weight layout
+    const int cc = c0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int aa = a0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (aa >= a.A || cc >= a.Bc) continue;
+        const size_t ab = a.dtransposed ? (size_t)cc * a.A + aa : (size_t)aa * a.Bc + cc;
+        const size_t base = ab * (NKX * NKX) + ky * NKX;
+        float v[NKX];
+#pragma unroll
+        for (int kx = 0; kx < NKX; ++kx) v[kx] = acc[kx][mi][r] * a.dscale;
+        if (a.dgwsq) {
+          const float f = 2.f * a.dscale * a.dscale * a.dgwsq[ab];
+#pragma unroll
+          for (int kx = 0; kx < NKX; ++kx) v[kx] += f * a.dw[base + kx];
+        }
+#pragma unroll
+        for (int kx = 0; kx < NKX; ++kx) a.dgw[base + kx] = v[kx];
+      }
+    return;
+  }
 #pragma unroll
   for (int kx = 0; kx < NKX; ++kx)
 #pragma unroll
@@ -2857,6 +2886,8 @@ int lcgan_set_option(int option, int value) {
   if (option == 15) { const int old = g_wgrad_xcd; g_wgrad_xcd = value; return old; }
   if (option == 16) { const int old = g_igemm_dma; g_igemm_dma = value; return old; }
   if (option == 19) { const int old = g_splitk_slabs; g_splitk_slabs = value; return old; }
+  if (option == 20) { const int old = g_wgrad_low_direct; g_wgrad_low_direct = value; return old; }
+  if (option == 21) { const int old = g_wgrad_low_parts; g_wgrad_low_parts = value; return old; }
   if (option == 17) { const int old = g_wgrad_prescale_mb; g_wgrad_prescale_mb = value; return old; }
   if (option == 18) { const int old = g_halo_wmod_mb; g_halo_wmod_mb = value; return old; }
   return LCGAN_EINVAL;
@@ -3104,9 +3135,33 @@ static int conv_wgrad_impl(const void* x, const void* g, float* gwp,
         if (cost < best) { best = cost; parts = real_parts; }
       }
     }
+    // Small grids (8 x 8 and 16 x 16; the register-staged kernels): a launch is a handful of chunks per workgroup and tiles3 = 16-48
+    // workgroups per split, so what it costs is everything AROUND the chunk loop: clearing gwp, 2.4 M atomics (or a slab of nsplit
+    // copies of the 9 MB gradient and its reduction pass) and the un-prep launch.  Unscaled launches therefore take ONE split where
+    // the chunk loop is short (the epilogue then writes the finished gradient in weight layout: one launch, 9 MB of traffic), and
+    // otherwise as many as the cost model below likes, no longer held to >= 1024 positions per split.
+    const bool lowres = segw <= 16 && pk == 1 && !scaled && g_wgrad_low_direct > 0;
+    if (lowres && g_wgrad3_wgs <= 0) {
+      if (g_wgrad_low_parts > 0) parts = min(g_wgrad_low_parts, cps);
+      else {
+        // measured (scripts/micro_wgrad_low.py, 512 x 512 layers, batch 4 and 32): a launch takes ~c0 + cc x chunks per workgroup
+        // (cc = 0.69 us for 3x3, 0.5 us for 1x1) while the grid fits one round of 256 workgroups, and S > 1 splits add
+        // ~2 + MB x (1.2 + 0.45 S) us for the slab of S gradient copies (MB each) and its reduction launch
+        const double mb = (double)k * k * A * Bc * 4e-6, cc = k == 3 ? 0.69 : 0.5;
+        double best = 1e30;
+        for (int pt = 1; pt <= max(1, cps / 2); ++pt) {
+          const int cpsplit = cdiv(cps, pt), S = cdiv(cps, cpsplit);
+          const int rounds = (tiles3 * S + 255) / 256;
+          const double cost = cc * cpsplit * rounds + (S > 1 ? 2.0 + mb * (1.2 + 0.45 * S) : 0.0);
+          if (cost < best) { best = cost; parts = S; }
+        }
+      }
+    }
     a.chunks_per_split = cdiv(cps, parts);
     a.parts = cdiv(cps, a.chunks_per_split);
     a.nsplit = groups * a.parts;
+    const bool direct = a.nsplit == 1 && !scaled && up && up->gw && lowres;
+    if (direct) { a.dgw = up->gw; a.dw = up->w; a.dgwsq = up->gwsq; a.dscale = up->scale; a.dtransposed = up->transposed; }
     // partial tiles meet in a slab + one reduction pass instead of atomics when there are enough splits to make atomics hurt
     a.slab = nullptr;
     const size_t slab_bytes = (size_t)a.nsplit * k * k * A * Bc * sizeof(float);
@@ -3115,10 +3170,11 @@ static int conv_wgrad_impl(const void* x, const void* g, float* gwp,
     // With the LDS-DMA kernel (shorter chunk loops) the big stride-1 layers are neutral at local batch 32 and -5 % of the whole
     // iteration at local batch 4 (170 splits x 49 K atomics per layer were 77 us at the chip's 1.3 TB/s atomic rate), so every
     // launch with enough splits takes the slab.
-    if (pk == 1 && g_wgrad_slab_min > 0 && a.nsplit >= g_wgrad_slab_min && slab_bytes <= ((size_t)1 << 30))
+    if (pk == 1 && g_wgrad_slab_min > 0 && (a.nsplit >= g_wgrad_slab_min || (lowres && a.nsplit > 1)) && slab_bytes <= ((size_t)1 << 30))
       a.slab = wgrad_slab_scratch(slab_bytes, s);                    // (packed groups: several waves add into one element -> atomics only)
-    if (up && !a.slab) hipMemsetAsync(gwp, 0, (size_t)k * k * A * Bc * sizeof(float), s);   // fused entry: gwp arrives uncleared
-    a.na = cdiv(A, 128); a.nc = cdiv(Bc, 128); a.xcd_order = g_wgrad_xcd;
+    if (up && !a.slab && !direct) hipMemsetAsync(gwp, 0, (size_t)k * k * A * Bc * sizeof(float), s);   // fused entry: gwp arrives uncleared
+    // (XCD order puts split i on XCD i % 8: with fewer than 8 splits it would leave whole XCDs idle)
+    a.na = cdiv(A, 128); a.nc = cdiv(Bc, 128); a.xcd_order = g_wgrad_xcd && (a.nsplit >= 8 || g_wgrad_low_direct <= 0);
     dim3 grid3(a.na, a.nc, nkx * a.nsplit);
     if (a.xcd_order) grid3 = dim3(8 * a.na * a.nc * nkx * cdiv(a.nsplit, 8), 1, 1);
 #define LAUNCH_WG3(ST, SG, SW, NK)                                                                                      \
@@ -3165,6 +3221,7 @@ static int conv_wgrad_impl(const void* x, const void* g, float* gwp,
 #undef LAUNCH_WG3_K
 #undef LAUNCH_WG3
 #undef LAUNCH_WG3_PK
+    if (direct) return launch_status() ? launch_status() : 1;    // 1 = un-prep done
     if (a.slab) {
       const int total = k * k * A * Bc;
       if (up && up->gw) {

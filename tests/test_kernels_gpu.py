@@ -419,9 +419,12 @@ def test_conv_igemm_dma_variants(H, case, opts):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 64, 128, 128, 3, 1, False), (2, 64, 64, 64, 96, 3, 2, True), (4, 16, 16, 128, 256, 3, 1, False),
-                                  (1, 32, 32, 72, 40, 1, 1, False)])
+                                  (1, 32, 32, 72, 40, 1, 1, False),
+                                  # small grids, few chunks: ONE split whose epilogue writes the weight-layout gradient itself
+                                  (2, 8, 8, 128, 256, 3, 1, False), (2, 8, 8, 256, 136, 3, 1, True), (3, 16, 16, 72, 40, 1, 1, False),
+                                  (2, 16, 16, 128, 128, 3, 2, False), (2, 16, 16, 200, 264, 1, 1, True)])
 def test_conv_wgrad_unprep_fused(H, case):
-    """lcgan_conv_wgrad_fused == lcgan_conv_wgrad + lcgan_conv_wgrad_unprep (slab and atomic routes, both orientations, demod term)"""
+    """lcgan_conv_wgrad_fused == lcgan_conv_wgrad + lcgan_conv_wgrad_unprep (slab, atomic and single-split routes, both orientations, demod term)"""
     B, Hh, W, Ci, Co, k, stride, tr = case
     dtype = torch.bfloat16
     x = feat((B, Hh, W, ceil8(Ci)), dtype, 21, Ci).cuda()
