@@ -51,6 +51,10 @@ int g_wgrad_low_direct = 1;               // lcgan_set_option(20, ...): launch p
                                           // cost model in conv_wgrad_impl, one split = the epilogue writes the finished gradient in weight layout, XCD order only from 8 splits
                                           // (0 = the round-2 plan: >= 1024 positions per split, XCD order always, atomics below 4 splits)
 int g_wgrad_low_parts = 0;                // lcgan_set_option(21, ...): force the number of splits of the small-grid weight gradients (tuning experiments; 0 = automatic)
+int g_halo_split = 0;                     // lcgan_set_option(22, ...): halo launches below option 6's workgroup count split their input-channel range so that about this many workgroups run
+                                          // (stride-1 LDS-DMA structure).  0 = off, the default: such launches go to the generic split-K kernel.  Measured with 256: the conv launches
+                                          // of an iteration +0.35 ms at batch 4, +0.5 at batch 8, neutral at batch 32 -- the last split re-reads nsplit x 128 KB of partials per
+                                          // tile through device-scope loads (16 dependent round trips to memory), which costs more than the generic kernel's extra L2 traffic
 int g_splitk_slabs = 8;                  // lcgan_set_option(19, ...): split-K launches of the 8-wave generic kernel with up to this many splits exchange partials through per-split slabs and
                                           // the last split to arrive finishes the tile; more splits (or 0) = atomics + the finalize launch (the last split's serial sum grows with the count:
                                           // measured -5..-7 us per launch at 2-4 splits, -1.6 at 8, +5 at 16, +14 at 32)
@@ -620,6 +624,9 @@ struct HaloArgs {
   int nblocks, nb_group;                     // channel blocks of 128; how many of them run together per tile (see the kernel's workgroup order)
   int halo_elems;                            // LDS elements reserved for the halo (max over phases)
   int dbg;                                   // option 3, bit 8: linear instead of XCD-contiguous tile order
+  // split of the input-channel range over blockIdx.y (stride-1 LDS-DMA structure only; launches that would leave most CUs idle): every
+  // split runs its share of the 32-channel chunks; partial tiles and the finish as in conv_igemm8_kernel (slab + arrival counter)
+  int nsplit; float* slab; int* cnt;
 };
 
 #ifdef HALO_STAMPS
@@ -685,6 +692,15 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
   }
   const int n0 = nb * BN;
   const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
+  // channel-range split: this workgroup runs chunks [cb, cb + nchunks) -- as a shift of both operand bases, so the main loop below
+  // counts from 0 as ever
+  constexpr bool CAN_SPLIT = IN_MUL == 1 && (DMA == 1 || DMA == 2) && !M16 && EPI != 3 && !MOD;
+  int coff = 0, nchunks_l = a.kc_per_tap;
+  if (CAN_SPLIT && a.nsplit > 1) {
+    const int per = (a.kc_per_tap + a.nsplit - 1) / a.nsplit, cb = blockIdx.y * per;
+    nchunks_l = max(0, min(per, a.kc_per_tap - cb));
+    coff = cb * BK;
+  }
   const TapTable& tt = a.taps[phase];
   const int hy0 = a.hy0[phase], hx0 = a.hx0[phase], hh = a.hh[phase], hw = a.hw[phase];
   // the epilogue's per-channel constants, fetched now (thread t < 128: channel n0 + t) instead of in front of the epilogue's barrier
@@ -705,9 +721,9 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
   // (global loads are raw buffer loads: resource in scalar registers, a 32-bit BYTE offset per lane, the moving part -- channel
   //  chunk, tap -- as the scalar offset; no 64-bit address lives in vector registers and a lane outside the image / the weight
   //  rows reads zeros by the range check instead of a branch.  Tensors are < 2^31 elements, checked by the caller)
-  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(2u * (unsigned)(a.B * a.Hin * a.Win * a.Cin)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + coff), 0, (int)(2u * (unsigned)(a.B * a.Hin * a.Win * a.Cin - coff)), 0x00020000);
   // (w_bstride != 0: this sample's own copy of the weights, the per-sample input scales already folded in)
-  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (size_t)b * (size_t)a.w_bstride), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (size_t)b * (size_t)a.w_bstride + coff), 0, 0x7fffffff, 0x00020000);
   unsigned goff[NI];
   int loff[NI];
 #pragma unroll
@@ -750,7 +766,7 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
 
   // ---- weight tiles: 128 rows x 4 vectors = 512 items per tap, one per thread ------------------------------------------------
   const int brow = tid >> 2;
-  const int ntaps = tt.n, nchunks = a.kc_per_tap;
+  const int ntaps = tt.n, nchunks = nchunks_l;
   const unsigned wrow = 2u * (unsigned)((n0 + brow) * a.Kpad + hvec * 8);
   const bool bvalid = n0 + brow < a.N;
 
@@ -1285,6 +1301,53 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
     o[0] = sA; o[1] = sB; o[2] = sC; o[3] = sD; o[4] = total;
   }
 #endif
+  }
+  if constexpr (CAN_SPLIT) {
+    if (a.nsplit > 1) {
+      // partial tiles meet as in conv_igemm8_kernel: relaxed device-scope stores to this split's slab, vmcnt(0), the tile's arrival
+      // counter; the last split to arrive re-reads ALL the slabs in split order (its own included: the sum does not depend on who was
+      // last, and no second set of 64 accumulator registers is needed) and goes on to the epilogue
+      int* flag = (int*)smem;
+      const int tileid = blockIdx.z * gridDim.x + blockIdx.x, split = blockIdx.y;
+      float* slabs = a.slab + (size_t)tileid * a.nsplit * (256 * BN);
+      float* mine = slabs + (size_t)split * (256 * BN);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            __hip_atomic_store(mine + ((mi * 2 + ni) * 16 + r) * 512 + tid, acc[mi][ni][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(a.cnt + tileid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == a.nsplit - 1;
+        if (last) __hip_atomic_store(a.cnt + tileid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = last;
+      }
+      __syncthreads();
+      const int last = *flag;
+      __syncthreads();                                           // (the epilogue reuses this LDS)
+      if (!last) return;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+      for (int sp = 0; sp < a.nsplit; ++sp) {
+        const float* other = slabs + (size_t)sp * (256 * BN);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = __hip_atomic_load(other + (q * 16 + r) * 512 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[q >> 1][q & 1][r] += v[r];
+        }
+      }
+    }
   }
   // ---- epilogue: demod/bias/act in registers -> bf16 tile in LDS -> 16-byte coalesced stores (+ residual) ----------------
   // (the main loop ended with a barrier, so the staging buffers are free)
@@ -1845,7 +1908,24 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   // a launch that cannot cover half the CUs (small local batch x low resolution: 16..64 tiles, each walking the full K =
   // 9*Cin reduction) goes to the split-K implicit GEMM instead, which spreads the reduction over ~256 workgroups
   const int halo_wgs = c.B * a.tiles_x * a.tiles_y * cdiv(c.Cout, BN) * nphase;
-  if (g_use_splitk && halo_wgs < g_halo_min_wgs && c.taps[0].n * c.kc_per_tap >= 8) return false;
+  a.nsplit = 1;
+  if (g_use_splitk && halo_wgs < g_halo_min_wgs && c.taps[0].n * c.kc_per_tap >= 8) {
+    // ... unless the launch takes the stride-1 LDS-DMA structure, which can split its input-channel range (the tile's input patch is
+    // still fetched once per chunk for all taps: the generic kernel re-reads it per tap and runs into the L2 -> LDS bandwidth)
+    bool can = g_halo_split > 0 && in_mul == 1 && g_halo_dma == 2 && g_mfma16 == 0 && !c.xs && c.Cin % 32 == 0 && c.Kpad == c.Cin && halo_wgs <= SPLITK_MAX_TILES;
+    for (int p = 0; p < nphase; ++p) can = can && a.hh[p] <= DMA_HROWS && a.hw[p] <= DMA_HP && a.hw[p] - HT <= 2;
+    if (can && c.pre) {                                           // per-sample input scales: only where they will be folded into weight copies (below)
+      int wt_max = 0;
+      for (int p = 0; p < nphase; ++p) for (int t = 0; t < c.taps[p].n; ++t) wt_max = std::max(wt_max, c.taps[p].wt[t]);
+      can = g_halo_wmod_mb > 0 && c.pre_stride >= c.Cin && (size_t)c.B * (wt_max + 1) * c.N * c.Kpad * sizeof(__bf16) <= ((size_t)g_halo_wmod_mb << 20);
+    }
+    const int ns = std::min({c.kc_per_tap / 2, cdiv(g_halo_split, halo_wgs), 16});
+    if (!can || ns < 2) return false;
+    int* cnt = nullptr;
+    float* slab = splitk_slab_scratch((size_t)halo_wgs * ns * 256 * BN * sizeof(float), &cnt, s);
+    if (!slab) return false;
+    a.nsplit = ns; a.slab = slab; a.cnt = cnt;
+  }
   a.halo_elems = max_halo_elems;
   g_pool_written = a.pool_out != nullptr;                         // (no `return false` below this line)
   if (a.pre && g_halo_wmod_mb > 0 && c.Cin % 32 == 0 && c.Kpad == c.Cin && c.pre_stride >= c.Cin && g_mfma16 != 1) {
@@ -1876,7 +1956,7 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
     for (int gsz = a.nblocks; gsz >= 1; --gsz)
       if (a.nblocks % gsz == 0 && gsz * wbytes <= (size_t)g_halo_nb_group_kb * 1024) { a.nb_group = gsz; break; }
   }
-  dim3 grid(c.B * a.tiles_x * a.tiles_y * a.nblocks, 1, nphase);
+  dim3 grid(c.B * a.tiles_x * a.tiles_y * a.nblocks, a.nsplit, nphase);
 #define LAUNCH_HALO(IM, MM, EP)                                                                                         \
   {                                                                                                                     \
     static bool set = false;                                                                                            \
@@ -2888,6 +2968,7 @@ int lcgan_set_option(int option, int value) {
   if (option == 19) { const int old = g_splitk_slabs; g_splitk_slabs = value; return old; }
   if (option == 20) { const int old = g_wgrad_low_direct; g_wgrad_low_direct = value; return old; }
   if (option == 21) { const int old = g_wgrad_low_parts; g_wgrad_low_parts = value; return old; }
+  if (option == 22) { const int old = g_halo_split; g_halo_split = value; return old; }
   if (option == 17) { const int old = g_wgrad_prescale_mb; g_wgrad_prescale_mb = value; return old; }
   if (option == 18) { const int old = g_halo_wmod_mb; g_halo_wmod_mb = value; return old; }
   return LCGAN_EINVAL;
@@ -3074,7 +3155,9 @@ static int conv_wgrad_impl(const void* x, const void* g, float* gwp,
   if (dtype == DT_BF16 && (pre_x || pre_g) && g_wgrad_prescale_mb > 0) {
     const size_t bx = (size_t)B * Hx * Wx * Cx * sizeof(__bf16), bg = (size_t)B * Hg * Wg * Cg * sizeof(__bf16);
     const size_t ox = (bx + 255) & ~(size_t)255;
-    if (bx + bg <= ((size_t)g_wgrad_prescale_mb << 20)) {
+    // (the threshold scales with the batch: what pinning splits to samples costs grows with B, what the pass costs with the bytes.
+    // Measured at batch 4: 256 x 256 x 128 layers 157 us prescaled against 116 per sample, 128 x 128 x 256 132 against 114)
+    if (bx + bg <= ((size_t)g_wgrad_prescale_mb << 20) * (size_t)min(B, 32) / 32) {
       __bf16* buf = prescale_scratch(ox + bg, s);
       if (buf) {
         if (pre_x) {
@@ -3140,18 +3223,19 @@ static int conv_wgrad_impl(const void* x, const void* g, float* gwp,
     // copies of the 9 MB gradient and its reduction pass) and the un-prep launch.  Unscaled launches therefore take ONE split where
     // the chunk loop is short (the epilogue then writes the finished gradient in weight layout: one launch, 9 MB of traffic), and
     // otherwise as many as the cost model below likes, no longer held to >= 1024 positions per split.
-    const bool lowres = segw <= 16 && pk == 1 && !scaled && g_wgrad_low_direct > 0;
+    const bool lowres = (segw <= 16 || k == 1) && pk == 1 && !scaled && g_wgrad_low_direct > 0;   // (1x1 kernels on any grid: tiles3 is 2-16 workgroups per split, the old plan's >= 1024 positions per split left most CUs idle at small batch)
     if (lowres && g_wgrad3_wgs <= 0) {
       if (g_wgrad_low_parts > 0) parts = min(g_wgrad_low_parts, cps);
       else {
         // measured (scripts/micro_wgrad_low.py, 512 x 512 layers, batch 4 and 32): a launch takes ~c0 + cc x chunks per workgroup
         // (cc = 0.69 us for 3x3, 0.5 us for 1x1) while the grid fits one round of 256 workgroups, and S > 1 splits add
         // ~2 + MB x (1.2 + 0.45 S) us for the slab of S gradient copies (MB each) and its reduction launch
-        const double mb = (double)k * k * A * Bc * 4e-6, cc = k == 3 ? 0.69 : 0.5;
+        const double mb = (double)k * k * A * Bc * 4e-6, cc = (k == 3 ? 0.69 : 0.5) * (seg == 64 ? 1.6 : 1.0);
         double best = 1e30;
         for (int pt = 1; pt <= max(1, cps / 2); ++pt) {
           const int cpsplit = cdiv(cps, pt), S = cdiv(cps, cpsplit);
-          const int rounds = (tiles3 * S + 255) / 256;
+          const int slots = k == 1 ? 512 : 256;                  // (the 1x1 instantiations fit two workgroups per CU)
+          const int rounds = (tiles3 * S + slots - 1) / slots;
           const double cost = cc * cpsplit * rounds + (S > 1 ? 2.0 + mb * (1.2 + 0.45 * S) : 0.0);
           if (cost < best) { best = cost; parts = S; }
         }

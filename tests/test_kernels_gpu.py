@@ -160,6 +160,44 @@ def test_conv_wgrad_prescaled_path(H, case):
     check(new, old.cpu(), dtype, "prescaled vs per-sample ranges", l2_scale=2.0)
 
 
+@pytest.mark.parametrize("case", [(2, 32, 32, 128, 128, "fwd"), (4, 16, 16, 512, 512, "fwd"), (3, 32, 32, 256, 136, "dgrad"), (2, 16, 16, 128, 96, "up"),
+                                  (1, 48, 32, 160, 128, "fwd")])
+def test_conv_halo_channel_split(H, case):
+    """halo-tile launches too small to fill the chip can split their input-channel range over blockIdx.y (option 22, off by default; stride-1 LDS-DMA
+    structure, partial tiles through slabs, the last split to arrive finishes): plain / bias + activation + residual / half-resolution
+    residual / per-sample scales (folded into weight copies) against the emulation and the generic split-K kernel (option 22 = 0);
+    the slab sum runs in split order, so two launches agree bit for bit"""
+    B, Hh, W, Ci, Co, kind = case
+    dtype, k = torch.bfloat16, 3
+    st = 2 if kind == "up" else 1
+    tr = kind in ("dgrad", "up")
+    x = feat((B, Hh, W, ceil8(Ci)), dtype, 1, Ci)
+    w = torch.randn(Ci, Co, k, k, generator=torch.Generator().manual_seed(2)) if tr else torch.randn(Co, Ci, k, k, generator=torch.Generator().manual_seed(2))
+    scale = 1 / math.sqrt(Ci * k * k)
+    pw_e, _ = E.prep_weight(w, scale, tr, False)
+    pw_h, _ = H.prep_weight(w.cuda(), scale, tr, False)
+    fn_h = H.conv_bwd_data if tr else H.conv_fwd
+    fn_e = E.conv_bwd_data if tr else E.conv_fwd
+    ref = fn_e(x, pw_e, Co, k, st)
+    bias = vec((Co,), 5)
+    res = feat(tuple(ref.shape), dtype, 7, Co)
+    pre, post = vec((B, ceil8(Ci)), 8), vec((B, ceil8(Co)), 9)
+    variants = {"plain": dict(), "epilogue": dict(bias=bias, act=1, gain=1.4, residual=res), "scaled": dict(pre=pre, post=post)}
+    if kind != "up":
+        variants["half residual"] = dict(residual=feat((B, ref.shape[1] // 2, ref.shape[2] // 2, ref.shape[3]), dtype, 10, Co), residual_half=True)
+    cu = lambda kw: {key: (v.cuda() if torch.is_tensor(v) else v) for key, v in kw.items()}
+    for name, kw in variants.items():
+        want = fn_e(x, pw_e, Co, k, st, **kw)
+        check(fn_h(x.cuda(), pw_h, Co, k, st, **cu(kw)), want, dtype, name + " (generic kernel)", l2_scale=2.0 if name == "scaled" else 1.0)
+        old = H.lib.lcgan_set_option(22, 256)                      # (off by default: see the switch's comment in conv_igemm.hip)
+        try:
+            got = fn_h(x.cuda(), pw_h, Co, k, st, **cu(kw))
+            check(got, want, dtype, name, l2_scale=2.0 if name == "scaled" else 1.0)
+            assert torch.equal(got, fn_h(x.cuda(), pw_h, Co, k, st, **cu(kw))), name
+        finally:
+            H.lib.lcgan_set_option(22, old)
+
+
 @pytest.mark.parametrize("case", [(4, 32, 32, 64, 128, 1, "fwd"), (4, 32, 32, 128, 64, 1, "dgrad"), (4, 16, 16, 64, 96, 2, "up"), (4, 32, 32, 96, 64, 2, "down"),
                                   (8, 64, 64, 128, 128, 1, "fwd"), (8, 64, 64, 128, 128, 1, "dgrad")])
 def test_conv_per_sample_weights(H, case):
