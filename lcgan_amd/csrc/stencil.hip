@@ -466,6 +466,12 @@ __device__ __forceinline__ void warp_coords(const T* flow, size_t pix, int h, in
 // index decompositions are shifts for the power-of-two sizes, products are 24-bit multiplies.
 // (Walking the pixels of a block as 4 x 4 tiles instead of a run of one image row -- a 7 x 7 instead of a 4 x 19 bicubic footprint per 16
 // output pixels -- was measured: 0 ... +12 % SLOWER on the forward kernel, -4 % on the backward; not kept.)
+// (Two ways of doing the per-pixel part -- flow, sample point, coefficients, clamped offsets: ~200 of the 475 vector instructions -- once
+// per pixel instead of once per lane were measured too and not kept.  A thread owning four of the pixel's vectors: 1.66 -> 2.98 ms per
+// iteration for the forward launches, every load instruction then touching 16 half cache lines instead of 8 whole ones.  A wave doing
+// the pixel work for 64 pixels, parking it in LDS and walking the pixels with the lane layout of this kernel: 1.70 -> 2.29 ms, the
+// 16 dependent tap loads of a step no longer overlapping with another pixel's.  The kernel is bound by its tap traffic through the L1 /
+// texture path at this occupancy, not by its instruction count.)
 struct WarpDims {
   FastDiv nvec, W, H;
   __device__ __forceinline__ void pixel(unsigned pix, unsigned& b, unsigned& h, unsigned& w) const {
