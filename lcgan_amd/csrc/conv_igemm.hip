@@ -1031,10 +1031,18 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
       const int hxl = txl + tt.dx[t] - hx0;                      // this lane's halo column under the tap: record hxl, slot (chunk ^ swizzle)
       const int a0 = (rowofs + (c & 1) * DMA_HBUF + (tt.dy[t] - hy0) * (DMA_HP * 64) + ((hxl << 6) | (halfs ^ ((hxl << 2) & 0x30)))) ^ (ks * 32);
       af[ks][0] = *(const bf16x8*)(smem + a0);
+#if defined(HALO_EXP) && HALO_EXP >= 1                           // timing experiment only (wrong results): how much of a step is LDS read traffic
+      af[ks][1] = af[ks][0];
+#else
       af[ks][1] = *(const bf16x8*)(smem + a0 + 2 * DMA_HP * 64);
+#endif
       const int b0 = (ks ? baddr1 : baddr0) + tilebase;
       bf[ks][0] = *(const bf16x8*)(smem + b0);
+#if defined(HALO_EXP) && HALO_EXP >= 2
+      bf[ks][1] = bf[ks][0];
+#else
       bf[ks][1] = *(const bf16x8*)(smem + b0 + 32 * 64);
+#endif
     };
     auto mfmas = [&](int ks) {
 #pragma unroll
