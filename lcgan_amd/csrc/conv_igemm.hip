@@ -2907,7 +2907,7 @@ int dispatch_igemm(const ConvArgs& a_in, int nphase, int dtype, hipStream_t s) {
   a.nsplit = 1; a.ws = nullptr; a.slab = nullptr; a.cnt = nullptr;
   g_pool_written = false;
   if (dtype == DT_BF16 && g_use_halo && try_launch_halo(a, nphase, a.in_mul, s)) return launch_status();
-  if (g_igemm_dma >= 2 && dtype == DT_BF16 && a.pre && a.Cin % 32 == 0 && a.Kpad == a.Cin && a.M >= 2048) {   // (below that the extra launch costs what the faster main loop gains: measured at local batch 4)
+  if (g_igemm_dma >= 2 && dtype == DT_BF16 && a.pre && a.Cin % 32 == 0 && a.Kpad == a.Cin && a.M >= 256) {   // (with the eight-wave kernel and its slab split-K behind it the pass pays from M = 256: conv family 8.96 -> 8.83 ms at local batch 4, 13.39 -> 13.31 at 8; it was 2048 with the four-wave loop)
     const size_t elems = (size_t)a.B * a.Hin * a.Win * a.Cin;
     if (elems * sizeof(__bf16) <= ((size_t)32 << 20)) {
       __bf16* xs_ = prescale_scratch(elems * sizeof(__bf16), s);
