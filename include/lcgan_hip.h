@@ -193,7 +193,8 @@ int lcgan_multi_tensor(const void* descs, const int* chunk_tensor, const int* ch
  * 19 split-K launches of the eight-wave generic kernel with at most this many splits exchange partials through per-split slabs and the last split to arrive finishes the tile (more, or 0: atomics + a finalize launch);
  * 20 launch plan of the small-grid (8 x 8, 16 x 16) weight gradients: splits from a measured cost model, a single split writes the gradient in weight layout from its epilogue (0 = the round-2 plan);
  * 21 forced split count of the small-grid weight gradients (tuning; 0 = automatic);
- * 22 workgroup count up to which a halo-tile launch that option 6 would turn away splits its input-channel range instead (0 = never).  DESIGN.md section 2 ("Switches") has the measurements behind the defaults. */
+ * 22 workgroup count up to which a halo-tile launch that option 6 would turn away splits its input-channel range instead (0 = never);
+ * 23 one-pass weight gradient of the flow layer's 1x1 GEMM (0 = the row-segment kernel).  DESIGN.md section 2 ("Switches") has the measurements behind the defaults. */
 int lcgan_set_option(int option, int value);
 
 /* ---- per-launch HIP-event profiling (bench.py roofline) ---------------------------------------------------- */

@@ -51,6 +51,7 @@ int g_wgrad_low_direct = 1;               // lcgan_set_option(20, ...): launch p
                                           // cost model in conv_wgrad_impl, one split = the epilogue writes the finished gradient in weight layout, XCD order only from 8 splits
                                           // (0 = the round-2 plan: >= 1024 positions per split, XCD order always, atomics below 4 splits)
 int g_wgrad_low_parts = 0;                // lcgan_set_option(21, ...): force the number of splits of the small-grid weight gradients (tuning experiments; 0 = automatic)
+int g_flow_wgrad = 1;                     // lcgan_set_option(23, ...): one-pass weight gradient of the flow layer's 1x1 GEMM (flow_wgrad_kernel); 0 = the row-segment kernel
 int g_halo_split = 0;                     // lcgan_set_option(22, ...): halo launches below option 6's workgroup count split their input-channel range so that about this many workgroups run
                                           // (stride-1 LDS-DMA structure).  0 = off, the default: such launches go to the generic split-K kernel.  Measured with 256: the conv launches
                                           // of an iteration +0.35 ms at batch 4, +0.5 at batch 8, neutral at batch 32 -- the last split re-reads nsplit x 128 KB of partials per
@@ -2900,6 +2901,74 @@ __bf16* prescale_scratch(size_t bytes, hipStream_t s) {               // grow-on
   return g_prescale[dev];
 }
 
+// Weight gradient of the flow layer's 1x1 GEMM (ops.FlowConvFn: A = 18 = 9 taps x 2 flow channels against Cin input channels):
+//   gwp[a][c] += pre_x[b][c] * sum_p g[b][p][a] * x[b][p][c]
+// One pass over x, which is all the work there is (9.6 GFLOP against 268 MB at 128 x 128 x 256, batch 32): the row-segment MFMA kernel ran it
+// as a 128-wide tile for 18 useful columns, one register-staged workgroup per CU, two chunks of 16 KB in flight -- 229 us, 1.3 TB/s.  Here a
+// workgroup takes FW_POS positions of one sample: g goes to LDS once (48 B per position), thread (pl, cv) walks positions pl, pl + npl, ...
+// with 8 channels of x per 16-byte load and 18 x 8 accumulators, the position lanes meet through LDS and the sample's scale is applied
+// to the sum (as the row-segment kernel applies it to its accumulator).
+constexpr int FW_POS = 1024, FW_A = 18, FW_CG = 24;
+__global__ __launch_bounds__(256) void flow_wgrad_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ g, float* __restrict__ gwp,
+                                                         const float* __restrict__ pre_x, int HW, int Cx, int Bc, int npos) {
+  __shared__ __attribute__((aligned(16))) __bf16 gsh[FW_POS * FW_CG];       // 48 KB
+  __shared__ float red[256 * 4];                                            // 4 KB: [position lane][channel]
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const int tid = threadIdx.x, b = blockIdx.y, p0 = blockIdx.x * npos, np = min(npos, HW - p0);        // npos <= FW_POS
+  // thread (pl, cq): FOUR channels of x per 8-byte load (eight would need 144 accumulators: one wave per SIMD), positions pl, pl + npl, ...
+  const int ncq = Cx >> 2, npl = 256 / ncq, cq = tid % ncq, pl = tid / ncq;
+  {
+    const u32x4* src = (const u32x4*)(g + ((size_t)b * HW + p0) * FW_CG);
+    u32x4* dst = (u32x4*)gsh;
+    for (int i = tid; i < np * 3; i += 256) dst[i] = src[i];
+  }
+  __syncthreads();
+  f32x2 acc[FW_A][2];
+#pragma unroll
+  for (int a = 0; a < FW_A; ++a) { acc[a][0] = f32x2{0.f, 0.f}; acc[a][1] = f32x2{0.f, 0.f}; }
+  const __bf16* xb = x + ((size_t)b * HW + p0) * Cx + cq * 4;
+  auto one = [&](const u32x2 u, int p) {
+    const f32x2 x0 = {__builtin_bit_cast(float, u[0] << 16), __builtin_bit_cast(float, u[0] & 0xffff0000u)};
+    const f32x2 x1 = {__builtin_bit_cast(float, u[1] << 16), __builtin_bit_cast(float, u[1] & 0xffff0000u)};
+    const u32x4* gp = (const u32x4*)(gsh + p * FW_CG);
+    const u32x4 g0 = gp[0], g1 = gp[1];
+    const unsigned g2 = ((const unsigned*)(gp + 2))[0];
+    const unsigned gw[9] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3], g2};
+#pragma unroll
+    for (int a = 0; a < FW_A; ++a) {
+      const float gv = __builtin_bit_cast(float, (a & 1) ? (gw[a >> 1] & 0xffff0000u) : (gw[a >> 1] << 16));
+      const f32x2 g2v = {gv, gv};
+      acc[a][0] = __builtin_elementwise_fma(x0, g2v, acc[a][0]);
+      acc[a][1] = __builtin_elementwise_fma(x1, g2v, acc[a][1]);
+    }
+  };
+  int p = pl;
+  constexpr int UNR = 4;                                         // loads of x in flight per thread (eight: more registers, one workgroup less per CU, 111 -> 130 us at 128 x 128 x 256)
+  for (; p + (UNR - 1) * npl < np; p += UNR * npl) {
+    u32x2 u[UNR];
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) u[k] = *(const u32x2*)(xb + (size_t)(p + k * npl) * Cx);
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) one(u[k], p + k * npl);
+  }
+  for (; p < np; p += npl) one(*(const u32x2*)(xb + (size_t)p * Cx), p);
+  // position lanes meet through LDS, one output row (a) at a time
+  for (int a = 0; a < FW_A; ++a) {
+    __syncthreads();
+    float* r = red + pl * Cx + cq * 4;
+    r[0] = acc[a][0][0]; r[1] = acc[a][0][1]; r[2] = acc[a][1][0]; r[3] = acc[a][1][1];
+    __syncthreads();
+    for (int c = tid; c < Cx; c += 256) {
+      float sum = 0.f;
+      for (int q = 0; q < npl; ++q) sum += red[q * Cx + c];
+      if (pre_x) sum *= pre_x[(size_t)b * Cx + c];
+      if (c < Bc) atomicAdd(gwp + (size_t)a * Bc + c, sum);
+    }
+  }
+}
+
 // Small-M layers (4x4 ... 16x16 grids) are weight-streaming bound and would occupy a handful of CUs: split the (tap, chunk)
 // loop over blockIdx.z so >= ~256 workgroups stream disjoint weight slices; partials meet in an fp32 workspace.
 int dispatch_igemm(const ConvArgs& a_in, int nphase, int dtype, hipStream_t s) {
@@ -2977,6 +3046,7 @@ int lcgan_set_option(int option, int value) {
   if (option == 20) { const int old = g_wgrad_low_direct; g_wgrad_low_direct = value; return old; }
   if (option == 21) { const int old = g_wgrad_low_parts; g_wgrad_low_parts = value; return old; }
   if (option == 22) { const int old = g_halo_split; g_halo_split = value; return old; }
+  if (option == 23) { const int old = g_flow_wgrad; g_flow_wgrad = value; return old; }
   if (option == 17) { const int old = g_wgrad_prescale_mb; g_wgrad_prescale_mb = value; return old; }
   if (option == 18) { const int old = g_halo_wmod_mb; g_halo_wmod_mb = value; return old; }
   return LCGAN_EINVAL;
@@ -3155,6 +3225,15 @@ static int conv_wgrad_impl(const void* x, const void* g, float* gwp,
   char tag[96] = "";
   if (lcgan_prof_active()) snprintf(tag, sizeof(tag), "wgrad B%d %dx%d A%d Bc%d k%d s%d%s", B, Hg, Wg, A, Bc, k, stride, (pre_x || pre_g) ? " mod" : "");
   ProfScope p(KID_CONV_WGRAD, 2.0 * M * A * Bc * k * k, 0, s, tag);
+  if (dtype == DT_BF16 && g_flow_wgrad && k == 1 && stride == 1 && A == FW_A && Cg == FW_CG && !pre_g && Hx == Hg && Wx == Wg &&
+      Cx >= 32 && Cx <= 1024 && (Cx & (Cx - 1)) == 0 &&           // (256 threads = (Cx / 4) channel quads x position lanes)
+      (long long)B * Hg * Wg >= 32768) {                          // (smaller launches are latency either way: measured equal or behind the row-segment plan at local batch 4)
+    if (up) hipMemsetAsync(gwp, 0, (size_t)A * Bc * sizeof(float), s);
+    // positions per workgroup: ~512 workgroups (two per CU) where the grid allows, at least 64 positions each (18 x Cx atomics per workgroup)
+    const int npos = std::min(FW_POS, std::max(64, cdiv((long long)B * Hg * Wg, 512)));
+    hipLaunchKernelGGL(flow_wgrad_kernel, dim3(cdiv(Hg * Wg, npos), B), dim3(256), 0, s, (const __bf16*)x, (const __bf16*)g, gwp, pre_x, Hg * Wg, Cx, Bc, npos);
+    return launch_status();
+  }
   // Per-sample operand scales (modulated convolutions: style on the input side, demodulation on the output side) pin every split of
   // the row-segment kernel to ONE sample -- the scales are applied to the fp32 accumulator, once per sample -- which costs the
   // low-resolution layers 115-170 us per launch at batch 32 (B x more, B x smaller workgroups; slabs of B x parts partial tiles).

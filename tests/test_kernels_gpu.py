@@ -425,6 +425,30 @@ def test_conv_igemm_register_staging(H, case):
         H.lib.lcgan_set_option(16, old)
 
 
+@pytest.mark.parametrize("case", [(8, 64, 64, 128), (24, 32, 48, 256), (32, 32, 32, 512), (16, 64, 32, 64), (40, 40, 24, 32), (2, 16, 16, 64)])
+def test_flow_wgrad_one_pass(H, case):
+    """the flow layer's 1x1 weight gradient (A = 18 against Cin, per-sample style scale on the input side) as one pass over x
+    (flow_wgrad_kernel, option 23) against the row-segment kernel (option 23 = 0) and the emulation"""
+    B, Hh, W, Ci = case
+    dtype = torch.bfloat16
+    x = feat((B, Hh, W, Ci), dtype, 31)
+    gt = feat((B, Hh, W, 24), dtype, 32, 18)
+    s_ = vec((B, Ci), 33)
+    want = E.conv_wgrad(x, gt, 18, Ci, 1, 1, pre_x=s_)
+    got = H.conv_wgrad(x.cuda(), gt.cuda(), 18, Ci, 1, 1, pre_x=s_.cuda())
+    old = H.lib.lcgan_set_option(23, 0)
+    try:
+        ref = H.conv_wgrad(x.cuda(), gt.cuda(), 18, Ci, 1, 1, pre_x=s_.cuda())
+    finally:
+        H.lib.lcgan_set_option(23, old)
+    for name, t in (("one pass", got), ("row-segment kernel", ref)):
+        e_l2 = float((t.float().cpu() - want).norm() / want.norm())
+        assert e_l2 <= 4e-3, (name, e_l2)
+    assert float((got - ref).norm() / ref.norm()) <= 4e-3
+    # without the scale, and through the fused entry (which clears gwp itself)
+    check(H.conv_wgrad(x.cuda(), gt.cuda(), 18, Ci, 1, 1), E.conv_wgrad(x, gt, 18, Ci, 1, 1), dtype, "unscaled", l2_scale=2.0)
+
+
 @pytest.mark.parametrize("opts", [(2, 0), (3, 0), (3, 8), (4, 64)])
 @pytest.mark.parametrize("case", [(2, 8, 8, 64, 128, 3, 1), (8, 8, 8, 512, 512, 3, 1), (4, 4, 4, 512, 512, 3, 1), (3, 16, 16, 64, 96, 3, 2), (2, 8, 8, 128, 256, 1, 1),
                                   (32, 16, 16, 128, 128, 3, 1)])
