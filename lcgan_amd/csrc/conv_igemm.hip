@@ -2223,7 +2223,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int aa = a0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (aa < a.A && cc < a.Bc) atomicAdd(a.gwp + ((size_t)tap * a.A + aa) * a.Bc + cc, acc[mi][ni][r]);
+        if (aa >= a.A || cc >= a.Bc) continue;
+        if (a.dgw) {                                             // single split + fused un-prep: the finished gradient in weight layout (see WgradArgs)
+          const size_t ab = a.dtransposed ? (size_t)cc * a.A + aa : (size_t)aa * a.Bc + cc;
+          const size_t idx = ab * (a.k * a.k) + tap;
+          float v = acc[mi][ni][r] * a.dscale;
+          if (a.dgwsq) v += 2.f * a.dscale * a.dscale * a.dw[idx] * a.dgwsq[ab];
+          a.dgw[idx] = v;
+        } else {
+          atomicAdd(a.gwp + ((size_t)tap * a.A + aa) * a.Bc + cc, acc[mi][ni][r]);
+        }
       }
     }
 }
@@ -3405,6 +3414,14 @@ static int conv_wgrad_impl(const void* x, const void* g, float* gwp,
     }
   } else if (dtype == DT_BF16) {
     const size_t smem = 2 * 2 * WG_TILE * sizeof(__bf16);
+    // 4 x 4 grids (and whatever else lands here with a short reduction): one split whose epilogue writes the finished gradient -- no
+    // clear, no atomics, no un-prep launch (same reasoning as the small-grid plan of the row-segment kernel)
+    if (up && up->gw && g_wgrad_low_direct > 0 && a.nchunks <= 64) {
+      a.nsplit = 1; a.chunks_per_split = a.nchunks;
+      a.dgw = up->gw; a.dw = up->w; a.dgwsq = up->gwsq; a.dscale = up->scale; a.dtransposed = up->transposed;
+      hipLaunchKernelGGL((conv_wgrad_kernel<__bf16, 1>), dim3(cdiv(A, 128), cdiv(Bc, 128), k * k), dim3(256), smem, s, a);
+      return launch_status() ? launch_status() : 1;              // 1 = un-prep done
+    }
     if (up) hipMemsetAsync(gwp, 0, (size_t)k * k * A * Bc * sizeof(float), s);
     hipLaunchKernelGGL((conv_wgrad_kernel<__bf16, 1>), grid, dim3(256), smem, s, a);
   } else if (dtype == DT_F32) {

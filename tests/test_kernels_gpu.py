@@ -484,7 +484,9 @@ def test_conv_igemm_dma_variants(H, case, opts):
                                   (1, 32, 32, 72, 40, 1, 1, False),
                                   # small grids, few chunks: ONE split whose epilogue writes the weight-layout gradient itself
                                   (2, 8, 8, 128, 256, 3, 1, False), (2, 8, 8, 256, 136, 3, 1, True), (3, 16, 16, 72, 40, 1, 1, False),
-                                  (2, 16, 16, 128, 128, 3, 2, False), (2, 16, 16, 200, 264, 1, 1, True)])
+                                  (2, 16, 16, 128, 128, 3, 2, False), (2, 16, 16, 200, 264, 1, 1, True),
+                                  # 4 x 4 grids: the generic kernel, one split, same direct epilogue
+                                  (8, 4, 4, 128, 256, 3, 1, False), (8, 4, 4, 256, 136, 3, 1, True), (3, 4, 4, 72, 40, 1, 1, False), (32, 4, 4, 64, 64, 3, 1, False)])
 def test_conv_wgrad_unprep_fused(H, case):
     """lcgan_conv_wgrad_fused == lcgan_conv_wgrad + lcgan_conv_wgrad_unprep (slab, atomic and single-split routes, both orientations, demod term)"""
     B, Hh, W, Ci, Co, k, stride, tr = case
