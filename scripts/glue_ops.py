@@ -31,3 +31,18 @@ for ev in prof.events():
         cnt[(ev.name, site, shape)] += 1
 for k, v in cnt.most_common(45):
     print(v, k)
+print("---- large operands (>= 1M elements at this batch)")
+big = collections.Counter()
+for ev in prof.events():
+    if ev.name in ("aten::add", "aten::add_", "aten::fill_", "aten::zero_", "aten::copy_", "aten::mul") and ev.input_shapes and ev.input_shapes[0]:
+        n = 1
+        for d in ev.input_shapes[0]:
+            n *= d
+        if n >= (1 << 20):
+            par, chain = ev.cpu_parent, []
+            while par is not None and len(chain) < 4:
+                chain.append(par.name.replace("autograd::engine::evaluate_function: ", "")[:40])
+                par = par.cpu_parent
+            big[(ev.name, str(ev.input_shapes[0]), " < ".join(chain))] += 1
+for k, v in big.most_common(40):
+    print(v, k)
