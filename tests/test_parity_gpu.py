@@ -329,7 +329,9 @@ def test_checkpoint_round_trip_on_device(tmp_path):
             wrecked = min(relmax(w.generator(z1, z2, 0.7), img0), relmax(w.generate(z1, z2, 0.7), ema0), relmax(w.discriminator(real, True)[0], d0[0]))
             assert wrecked >= 0.1, wrecked                        # what a stale prepared copy would look like
         w.load_model()
-        tol = max(4 * noise, 1e-3)
+        # (one repeat can under-estimate the noise now that most split-K launches sum in a fixed order: a single bf16 rounding flip in one of
+        #  the remaining atomically-reduced layers moves the output by ~1e-2 of its maximum; stale weights are >= 0.1, asserted above)
+        tol = max(4 * noise, 2e-2)
         with torch.no_grad():
             assert relmax(w.generator(z1, z2, 0.7), img0) <= tol, "stale prepared weights after load_model (generator)"
             assert relmax(w.generate(z1, z2, 0.7), ema0) <= tol, "stale prepared weights after load_model (EMA generator)"
