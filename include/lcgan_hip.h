@@ -143,6 +143,8 @@ int lcgan_linear_fwd(const float* x, const float* w, const float* bias, float* y
 int lcgan_linear_bwd_data(const float* gy, const float* w, float* gx, int M, int I, int O, float scale, void* stream);
 int lcgan_linear_wgrad(const float* gy, const float* x, float* gw, int M, int I, int O, float scale, void* stream);
 int lcgan_colsum(const float* gy, float* gb, int M, int O, float scale, void* stream);
+/* the two calls above as one launch: gw = scale * gy^T x, gb = bias_scale * colsum(gy) (backward of F.linear with bias, custom_layers.py:25) */
+int lcgan_linear_wgrad_bias(const float* gy, const float* x, float* gw, float* gb, int M, int I, int O, float scale, float bias_scale, void* stream);
 /* L <= 24 linear layers sharing their input x [M,I] -- the style affines of every synthesis layer (SynthesisLayer.linear,
    custom_layers.py:100,108; all blocks receive the same latent, cnn.py:103-104) in ONE launch.  w/bias/y/gy/gw/gb are HOST
    arrays of L device pointers, O/scale/bias_scale host arrays of L values; y_l = x w_l^T scale_l + bias_l*bias_scale_l.

@@ -50,6 +50,7 @@ SIGNATURES = {
     "lcgan_linear_bwd_data": [P, P, P, I, I, I, F, P],
     "lcgan_linear_wgrad": [P, P, P, I, I, I, F, P],
     "lcgan_colsum": [P, P, I, I, F, P],
+    "lcgan_linear_wgrad_bias": [P, P, P, P, I, I, I, F, F, P],
     "lcgan_linear_group_fwd": [P, P, P, P, P, P, P, I, I, I, I, F, P],
     "lcgan_linear_group_bwd": [P, P, P, P, P, P, I, I, I, P, P, P, P],
     "lcgan_act_bwd_f32": [P, P, P, LL, I, F, P],

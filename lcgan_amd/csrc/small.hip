@@ -28,6 +28,7 @@ struct LinGroup {
   int O[LIN_MAXL];
   float scale[LIN_MAXL];         // equalized-lr weight scale c_l
   float bscale[LIN_MAXL];        // bias scale (lr_mul)
+  float* out2[LIN_MAXL];         // wgrad: gb_l [O_l] = bscale_l * colsum(gy_l), written by the i == 0 blocks from their staged gy slice (or null)
 };
 
 // y_l[m,o] = act(scale_l * sum_i x[m,i] w_l[o,i] + bias_l[o]*bscale_l) * gain
@@ -201,6 +202,9 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(const LinGroup g, con
   float acc[LW_OT];
 #pragma unroll
   for (int r = 0; r < LW_OT; ++r) acc[r] = 0.f;
+  // the bias gradient (column sums of gy) leaves the same launch: the first block of every row group has the 16 columns staged anyway
+  const bool bias_blk = blockIdx.x == 0 && g.out2[l] != nullptr && threadIdx.x < LW_OT;
+  float gbacc = 0.f;
   for (int m0 = 0; m0 < M; m0 += LW_MC) {
     const int mc = min(LW_MC, M - m0);
     __syncthreads();
@@ -209,6 +213,8 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(const LinGroup g, con
       gs[mm][r] = (o0 + r < O) ? gy[(size_t)(m0 + mm) * O + o0 + r] : 0.f;
     }
     __syncthreads();
+    if (bias_blk)
+      for (int mm = 0; mm < mc; ++mm) gbacc += gs[mm][threadIdx.x];
     if (i < I) {
       for (int mm = 0; mm < mc; ++mm) {
         const float xv = x[(size_t)(m0 + mm) * I + i];
@@ -222,6 +228,7 @@ __global__ __launch_bounds__(TPB) void linear_wgrad_kernel(const LinGroup g, con
     for (int r = 0; r < LW_OT; ++r)
       if (o0 + r < O) g.out[l][(size_t)(o0 + r) * I + i] = acc[r] * g.scale[l];
   }
+  if (bias_blk && o0 + (int)threadIdx.x < O) g.out2[l][o0 + threadIdx.x] = gbacc * g.bscale[l];
 }
 
 // gb_l[o] = bscale_l * sum_m gy_l[m,o]
@@ -578,6 +585,16 @@ int lcgan_linear_wgrad(const float* gy, const float* x, float* gw, int M, int I,
   hipLaunchKernelGGL(linear_wgrad_kernel, dim3(cdiv(I, TPB), cdiv(O, LW_OT), 1), dim3(TPB), 0, s, g, x, M, I);
   return launch_status();
 }
+// lcgan_linear_wgrad + lcgan_colsum as ONE launch (gb = bias_scale * column sums of gy): the backward of an EqualizedLinear with bias
+int lcgan_linear_wgrad_bias(const float* gy, const float* x, float* gw, float* gb, int M, int I, int O, float scale, float bias_scale, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!gb) return LCGAN_EINVAL;
+  ProfScope p(KID_LINEAR, 2.0 * M * I * O, 4.0 * I * O, s);
+  LinGroup g = {};
+  g.aux[0] = gy; g.out[0] = gw; g.out2[0] = gb; g.O[0] = O; g.scale[0] = scale; g.bscale[0] = bias_scale;
+  hipLaunchKernelGGL(linear_wgrad_kernel, dim3(cdiv(I, TPB), cdiv(O, LW_OT), 1), dim3(TPB), 0, s, g, x, M, I);
+  return launch_status();
+}
 int lcgan_colsum(const float* gy, float* gb, int M, int O, float scale, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(KID_SMALL, 0, 0, s);
@@ -612,8 +629,9 @@ int lcgan_linear_group_bwd(const float* const* gy, const float* x, const float* 
   ProfScope p(KID_LINEAR, (gx ? 2.0 : 0.0) * M * I * sumO + (gw ? 2.0 : 0.0) * M * I * sumO, 4.0 * I * sumO, s);
   if (gx) { const int rc = linear_group_bwd_data(g, L, maxO, gx, M, I, s); if (rc) return rc; }
   if (gw) {
-    for (int l = 0; l < L; ++l) g.out[l] = gw[l];
+    for (int l = 0; l < L; ++l) { g.out[l] = gw[l]; g.out2[l] = gb ? gb[l] : nullptr; }
     hipLaunchKernelGGL(linear_wgrad_kernel, dim3(cdiv(I, TPB), cdiv(maxO, LW_OT), L), dim3(TPB), 0, s, g, x, M, I);
+    if (gb) return launch_status();                             // (the bias gradients left the weight-gradient launch)
   }
   if (gb) {
     for (int l = 0; l < L; ++l) g.out[l] = gb[l];

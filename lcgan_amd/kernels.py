@@ -511,6 +511,17 @@ class HipKernels:
         self._call("lcgan_linear_wgrad", gy.data_ptr(), x.data_ptr(), gw.data_ptr(), M, I, O, float(scale), self._stream())
         return gw
 
+    def linear_wgrad_bias(self, gy: Tensor, x: Tensor, scale: float, bias_scale: float):
+        """-> (gw [O,I], gb [O]) from one launch"""
+        self._chk(gy, x)
+        M, O = gy.shape
+        I = x.shape[1]
+        gw = torch.empty((O, I), dtype=torch.float32, device=gy.device)
+        gb = torch.empty((O,), dtype=torch.float32, device=gy.device)
+        self._call("lcgan_linear_wgrad_bias", gy.data_ptr(), x.data_ptr(), gw.data_ptr(), gb.data_ptr(), M, I, O, float(scale), float(bias_scale),
+                   self._stream())
+        return gw, gb
+
     def colsum(self, gy: Tensor, scale: float) -> Tensor:
         self._chk(gy)
         M, O = gy.shape

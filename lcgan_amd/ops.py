@@ -639,8 +639,12 @@ class LinearFn(Function):
         gy = gy.contiguous()
         gz = _ap(ActBwdF32Fn, gy, y, act, gain) if act != ACT_NONE else (gy * gain if gain != 1.0 else gy)
         gx = _ap(LinearTFn, gz, w, scale) if ctx.needs_input_grad[0] else None
-        gw = _ap(LinearWeightGradFn, gz, x, scale) if _wants(ctx, 1) else None
-        gb = _K().colsum(gz.detach().contiguous(), bias_scale) if (has_bias and _wants(ctx, 2)) else None
+        want_w, want_b = _wants(ctx, 1), has_bias and _wants(ctx, 2)
+        if want_w and want_b and not torch.is_grad_enabled():    # (no graph through this backward: both gradients from one launch)
+            gw, gb = _K().linear_wgrad_bias(gz.contiguous(), x, scale, bias_scale)
+        else:
+            gw = _ap(LinearWeightGradFn, gz, x, scale) if want_w else None
+            gb = _K().colsum(gz.detach().contiguous(), bias_scale) if want_b else None
         return gx, gw, gb, None, None, None, None
 
 

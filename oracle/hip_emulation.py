@@ -437,6 +437,9 @@ class EmulatedKernels:
     def colsum(self, gy, scale):
         return gy.sum(0) * scale
 
+    def linear_wgrad_bias(self, gy, x, scale, bias_scale):
+        return self.linear_wgrad(gy, x, scale), self.colsum(gy, bias_scale)
+
     def linear_group_fwd(self, x, ws, biases, scales, bias_scales, act=0, gain=1.0):
         return [self.linear_fwd(x, w, b, sc, bs, act, gain) for w, b, sc, bs in zip(ws, biases, scales, bias_scales)]
 

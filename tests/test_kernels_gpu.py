@@ -858,6 +858,9 @@ def test_linear(H, M, I, O):
     check(H.linear_bwd_data(gy.cuda(), w.cuda(), sc), E.linear_bwd_data(gy, w, sc), f32, "bwd data")
     check(H.linear_wgrad(gy.cuda(), x.cuda(), sc), E.linear_wgrad(gy, x, sc), f32, "wgrad")
     check(H.colsum(gy.cuda(), 0.01), E.colsum(gy, 0.01), f32, "colsum")
+    gw, gb = H.linear_wgrad_bias(gy.cuda(), x.cuda(), sc, 0.01)           # both from one launch
+    check(gw, E.linear_wgrad(gy, x, sc), f32, "wgrad (fused)")
+    check(gb, E.colsum(gy, 0.01), f32, "colsum (fused)")
     check(H.act_bwd_f32(gy.cuda(), x[:, :1].expand(M, O).contiguous().cuda(), 1, 1.0), E.act_bwd_f32(gy, x[:, :1].expand(M, O), 1, 1.0), f32, "act bwd")
 
 
