@@ -156,6 +156,10 @@ int lcgan_linear_group_bwd(const float* const* gy, const float* x, const float* 
 int lcgan_act_bwd_f32(const float* gy, const float* y, float* gz, long long n, int act, float gain, void* stream);
 /* demodulation statistic custom_layers.py:67 : d[b,o] = rsqrt(sum_c s^2 wsq[o,c] + eps), d is [B][Os] */
 int lcgan_demod_fwd(const float* s, const float* wsq, float* d, int B, int C, int O, int Os, float eps, void* stream);
+/* L <= 24 demodulation vectors in one launch (host arrays of L device pointers / sizes): every modulated layer of a generator pass, whose
+   styles are all known before the first convolution (cnn.py:103-104) */
+int lcgan_demod_group(const float* const* s, const float* const* wsq, float* const* d, const int* C, const int* O, const int* Os,
+                      int L, int B, float eps, void* stream);
 int lcgan_demod_bwd(const float* gdq, const float* d, const float* s, const float* wsq, float* gs, float* gwsq,
                     int B, int C, int O, int Os, void* stream);
 

@@ -55,6 +55,7 @@ SIGNATURES = {
     "lcgan_linear_group_bwd": [P, P, P, P, P, P, I, I, I, P, P, P, P],
     "lcgan_act_bwd_f32": [P, P, P, LL, I, F, P],
     "lcgan_demod_fwd": [P, P, P, I, I, I, I, F, P],
+    "lcgan_demod_group": [P, P, P, P, P, P, I, I, F, P],
     "lcgan_demod_bwd": [P, P, P, P, P, P, I, I, I, I, P],
     "lcgan_bce_fwd": [P, I, I, P, P],
     "lcgan_bce_bwd": [P, I, I, P, P, P],

@@ -124,7 +124,16 @@ class Generator(torch.nn.Module):
         a_styles = ops.grouped_linear(appearance_code, [l.linear for b in blocks for l in (b.modulated_conv0, b.modulated_conv1)]
                                       + [self.rgb_layer.modulated_conv0.linear, self.rgb_layer.modulated_conv1.linear])
         x = ops.ConstInputFn.apply(self.const, batch_size, config.feature_dtype())     # cnn.py:106
-        for i, block in enumerate(blocks):
-            x = block(x, (geometry_code,), (appearance_code, appearance_code),
-                      styles=(g_styles[i], a_styles[2 * i], a_styles[2 * i + 1]))
-        return self.rgb_layer(x, (appearance_code, appearance_code), styles=(a_styles[-2], a_styles[-1]))
+        # ... and the demodulation vectors of all 19 modulated 3x3 layers (custom_layers.py:67) one launch (ops.precompute_demod)
+        ops.precompute_demod([(b.flow_layer.modulated_conv.weight.weight, g_styles[i], config.flow_gemm()) for i, b in enumerate(blocks)]
+                             + [(l.modulated_conv.weight.weight, a_styles[2 * i + j], False)
+                                for i, b in enumerate(blocks) for j, l in enumerate((b.modulated_conv0, b.modulated_conv1))]
+                             + [(self.rgb_layer.modulated_conv0.modulated_conv.weight.weight, a_styles[-2], False)],
+                             config.feature_dtype() == torch.float32)
+        try:
+            for i, block in enumerate(blocks):
+                x = block(x, (geometry_code,), (appearance_code, appearance_code),
+                          styles=(g_styles[i], a_styles[2 * i], a_styles[2 * i + 1]))
+            return self.rgb_layer(x, (appearance_code, appearance_code), styles=(a_styles[-2], a_styles[-1]))
+        finally:
+            ops.clear_demod()

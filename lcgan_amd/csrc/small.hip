@@ -260,6 +260,21 @@ __global__ void demod_fwd_kernel(const float* __restrict__ s, const float* __res
   acc = wave_sum(acc);
   if (lane == 0) d[(size_t)b * Os + o] = rsqrtf(acc + eps);
 }
+// the same for L <= 24 layers in one launch (table by value): the generator knows every layer's style before its first convolution
+// (the grouped affines, cnn.py:103-104), so the 19 demodulation launches of a forward pass are one
+constexpr int DM_MAXL = 24;
+struct DemodGroup { const float* s[DM_MAXL]; const float* wsq[DM_MAXL]; float* d[DM_MAXL]; int C[DM_MAXL], O[DM_MAXL], Os[DM_MAXL]; };
+__global__ void demod_group_kernel(const DemodGroup g, int B, float eps) {
+  const int l = blockIdx.z, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int o = blockIdx.x * 4 + wid, b = blockIdx.y, C = g.C[l];
+  if (o >= g.O[l]) return;
+  const float* __restrict__ s = g.s[l];
+  const float* __restrict__ wsq = g.wsq[l];
+  float acc = 0.f;
+  for (int c = lane; c < C; c += 64) { const float sv = s[(size_t)b * C + c]; acc += sv * sv * wsq[(size_t)o * C + c]; }
+  acc = wave_sum(acc);
+  if (lane == 0) g.d[l][(size_t)b * g.Os[l] + o] = rsqrtf(acc + eps);
+}
 // gq[b,o] = -0.5 * gdq[b,o] * d[b,o]^2 ;  gs[b,c] += 2 s[b,c] sum_o gq[b,o] wsq[o,c]
 // block = (256 channels c, sample b, chunk of 64 outputs o): gq of the chunk sits in LDS, partial sums meet through atomics
 __global__ void demod_bwd_s_kernel(const float* __restrict__ gdq, const float* __restrict__ d, const float* __restrict__ s,
@@ -650,6 +665,17 @@ int lcgan_demod_fwd(const float* sv, const float* wsq, float* d, int B, int C, i
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(KID_SMALL, 0, 0, s);
   hipLaunchKernelGGL(demod_fwd_kernel, dim3(cdiv(O, 4), B), dim3(TPB), 0, s, sv, wsq, d, B, C, O, Os, eps);
+  return launch_status();
+}
+int lcgan_demod_group(const float* const* sv, const float* const* wsq, float* const* d, const int* C, const int* O, const int* Os,
+                      int L, int B, float eps, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (L <= 0 || L > DM_MAXL || B <= 0) return LCGAN_EINVAL;
+  ProfScope p(KID_SMALL, 0, 0, s);
+  DemodGroup g = {};
+  int maxO = 0;
+  for (int l = 0; l < L; ++l) { g.s[l] = sv[l]; g.wsq[l] = wsq[l]; g.d[l] = d[l]; g.C[l] = C[l]; g.O[l] = O[l]; g.Os[l] = Os[l]; maxO = std::max(maxO, O[l]); }
+  hipLaunchKernelGGL(demod_group_kernel, dim3(cdiv(maxO, 4), B, L), dim3(TPB), 0, s, g, B, eps);
   return launch_status();
 }
 // gs[b,c] += (demod path) ; gwsq[o,c] = (demod path).  gdq is the raw reduction of lcgan_act_bwd_reduce.

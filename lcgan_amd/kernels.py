@@ -586,6 +586,17 @@ class HipKernels:
         self._call("lcgan_demod_fwd", s.data_ptr(), wsq.data_ptr(), d.data_ptr(), B, Cc, O, ostride, float(eps), self._stream())
         return d
 
+    def demod_group(self, ss, wsqs, ostrides, eps: float = 1e-8):
+        """[demod_fwd(s_l, wsq_l, ostride_l)] for up to 24 layers from one launch"""
+        import ctypes as C
+        self._chk(*ss, *wsqs)
+        B = ss[0].shape[0]
+        L = len(ss)
+        ds = [self._zeros.take((B, int(o)), ss[0].device) for o in ostrides]
+        self._call("lcgan_demod_group", self._ptr_array(ss), self._ptr_array(wsqs), self._ptr_array(ds), (C.c_int * L)(*[int(t.shape[1]) for t in ss]),
+                   (C.c_int * L)(*[int(w.shape[0]) for w in wsqs]), (C.c_int * L)(*[int(o) for o in ostrides]), L, B, float(eps), self._stream())
+        return ds
+
     def demod_bwd(self, gdq: Tensor, d: Tensor, s: Tensor, wsq: Tensor, gs: Tensor) -> Tensor:
         """gs += demod path (in place); returns gwsq [O,C]"""
         self._chk(gdq, d, s, wsq, gs)

@@ -461,6 +461,9 @@ class EmulatedKernels:
         d[:, :wsq.shape[0]] = torch.rsqrt(s.square() @ wsq.t() + eps)
         return d
 
+    def demod_group(self, ss, wsqs, ostrides, eps=1e-8):
+        return [self.demod_fwd(s_, w_, int(o), eps) for s_, w_, o in zip(ss, wsqs, ostrides)]
+
     def demod_bwd(self, gdq, d, s, wsq, gs):
         O = wsq.shape[0]
         gq = -0.5 * gdq[:, :O] * d[:, :O] ** 2

@@ -887,6 +887,19 @@ def test_linear_group(H, M, I, Os):
     assert H.linear_group_bwd([t.cuda() for t in gys], x.cuda(), [w.cuda() for w in ws], scs, bss, want_gx=False)[0] is None
 
 
+def test_demod_group(H):
+    """demodulation vectors of several layers from one launch == the per-layer kernel"""
+    g = torch.Generator().manual_seed(102)
+    B = 5
+    shapes = [(64, 24, 24), (512, 512, 512), (128, 2, 8), (72, 40, 40)]          # (C, O, alloc stride)
+    ss = [torch.randn(B, C, generator=g) + 1 for C, _, _ in shapes]
+    wsqs = [torch.rand(O, C, generator=g) * 0.1 for C, O, _ in shapes]
+    got = H.demod_group([t.cuda() for t in ss], [t.cuda() for t in wsqs], [o for _, _, o in shapes])
+    for (C, O, ost), s_, w_, d in zip(shapes, ss, wsqs, got):
+        check(d, E.demod_fwd(s_, w_, ost), torch.float32, f"C{C} O{O}")
+        assert torch.equal(d, H.demod_fwd(s_.cuda(), w_.cuda(), ost))
+
+
 def test_demod(H):
     g = torch.Generator().manual_seed(101)
     B, C, O = 4, 64, 24
