@@ -153,6 +153,13 @@ int lcgan_linear_group_fwd(const float* x, const float* const* w, const float* c
                            const float* scale, const float* bias_scale, int L, int M, int I, int act, float gain, void* stream);
 int lcgan_linear_group_bwd(const float* const* gy, const float* x, const float* const* w, const int* O, const float* scale,
                            const float* bias_scale, int L, int M, int I, float* gx, float* const* gw, float* const* gb, void* stream);
+/* L <= 24 linear layers with their OWN inputs x_l [M, I_l] and shapes [O_l, I_l]: the layers at equal depth of the geometry and the appearance
+   mapping network (MappingNetwork.forward, custom_layers.py:283-287; cnn.py:66-72), which the reference evaluates as two sequential chains.
+   x/w/bias/y/gy/gx/gw/gb are HOST arrays of L device pointers, I/O/scale/bias_scale host arrays of L values. */
+int lcgan_linear_multi_fwd(const float* const* x, const float* const* w, const float* const* bias, float* const* y, const int* I, const int* O,
+                           const float* scale, const float* bias_scale, int L, int M, int act, float gain, void* stream);
+int lcgan_linear_multi_bwd(const float* const* gy, const float* const* x, const float* const* w, const int* I, const int* O, const float* scale,
+                           const float* bias_scale, int L, int M, float* const* gx, float* const* gw, float* const* gb, void* stream);
 int lcgan_act_bwd_f32(const float* gy, const float* y, float* gz, long long n, int act, float gain, void* stream);
 /* demodulation statistic custom_layers.py:67 : d[b,o] = rsqrt(sum_c s^2 wsq[o,c] + eps), d is [B][Os] */
 int lcgan_demod_fwd(const float* s, const float* wsq, float* d, int B, int C, int O, int Os, float eps, void* stream);

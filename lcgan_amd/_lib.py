@@ -53,6 +53,8 @@ SIGNATURES = {
     "lcgan_linear_wgrad_bias": [P, P, P, P, I, I, I, F, F, P],
     "lcgan_linear_group_fwd": [P, P, P, P, P, P, P, I, I, I, I, F, P],
     "lcgan_linear_group_bwd": [P, P, P, P, P, P, I, I, I, P, P, P, P],
+    "lcgan_linear_multi_fwd": [P, P, P, P, P, P, P, P, I, I, I, F, P],
+    "lcgan_linear_multi_bwd": [P, P, P, P, P, P, P, I, I, P, P, P, P],
     "lcgan_act_bwd_f32": [P, P, P, LL, I, F, P],
     "lcgan_demod_fwd": [P, P, P, I, I, I, I, F, P],
     "lcgan_demod_group": [P, P, P, P, P, P, I, I, F, P],

@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from . import config, ops
 from . import kernels as KM
-from .custom_layers import (DiscriminatorBlock, DiscriminatorEpilogue, EqualizedConv2d, MappingNetwork, ProjectionHead, mapping_matrices,
+from .custom_layers import (DiscriminatorBlock, DiscriminatorEpilogue, EqualizedConv2d, MappingNetwork, ProjectionHead, mapping_forward, mapping_matrices,
                             SynthesisBlock, ToRGBBlock)
 from .kernels import ACT_LRELU
 
@@ -107,8 +107,9 @@ class Generator(torch.nn.Module):
     def forward(self, rand_noise1, rand_noise2, w_psi=-1.0):
         batch_size = rand_noise1.size(0)
         Lg, La = mapping_matrices((self.geometry_mapping, self.appearance_mapping))      # both QR factorisations in one launch
-        geometry_code = self.geometry_mapping(rand_noise1.float(), Lg)
-        appearance_code = self.appearance_mapping(rand_noise2.float(), La)
+        # the two mapping chains side by side: their layers of equal shape (the fourth to the twelfth) share launches
+        geometry_code, appearance_code = mapping_forward((self.geometry_mapping, self.appearance_mapping),
+                                                         (rand_noise1.float(), rand_noise2.float()), (Lg, La))
 
         if w_psi <= 0:                                   # running latent means (cnn.py:95-97), one tiny kernel each
             KM.K.avg_latent(geometry_code.detach(), self.avg_latent1, self.w_avg_beta)

@@ -28,6 +28,8 @@ struct LinGroup {
   int O[LIN_MAXL];
   float scale[LIN_MAXL];         // equalized-lr weight scale c_l
   float bscale[LIN_MAXL];        // bias scale (lr_mul)
+  const float* xin[LIN_MAXL];    // per-layer input x_l [M, I_l] (or null: the shared x of the launch) -- layers at equal depth of DIFFERENT chains (the two mapping networks)
+  int Iv[LIN_MAXL];              // ... and its width I_l (0: the launch's I)
   float* out2[LIN_MAXL];         // wgrad: gb_l [O_l] = bscale_l * colsum(gy_l), written by the i == 0 blocks from their staged gy slice (or null)
 };
 
@@ -37,7 +39,7 @@ struct LinGroup {
 // isplit > 1 (long rows: the discriminator epilogue's 8192-wide linear) spreads the i range over isplit blocks that add their
 // raw partial sums into a zeroed y; linear_finalize_kernel then applies bias / activation.
 constexpr int LIN_IC = 256;
-__global__ __launch_bounds__(TPB) void linear_fwd_generic_kernel(const float* __restrict__ x, const LinGroup g, int M, int I, int isplit,
+__global__ __launch_bounds__(TPB) void linear_fwd_generic_kernel(const float* x, const LinGroup g, int M, int I, int isplit,
                                                           int act, float gain) {
   __shared__ float xs[LIN_IC * 33];
   __shared__ float ws[8 * LIN_IC];
@@ -45,6 +47,7 @@ __global__ __launch_bounds__(TPB) void linear_fwd_generic_kernel(const float* __
   const int o0 = blockIdx.x * 8;
   if (o0 >= O) return;
   const float* __restrict__ w = g.w[l];
+  if (g.xin[l]) { x = g.xin[l]; I = g.Iv[l]; }
   const int m = threadIdx.x & 31, ol = threadIdx.x >> 5;
   const int mt = blockIdx.y / isplit, sp = blockIdx.y - mt * isplit;
   const int m0 = mt * MT;
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(TPB) void linear_fwd_generic_kernel(const float* __
 // every block) as coalesced 16-byte loads, 16 FMAs per row; the 64 lanes' partial sums meet through LDS (padded rows, conflict-free
 // both ways).  The LDS-staged kernel above took 24 us for a 512 x 512 layer (a serial 512-step inner loop behind 80 scalar loads per
 // thread); 63 such launches per iteration made the linear layers 2.6 ms of the step.
-__global__ __launch_bounds__(TPB) void linear_fwd_kernel(const float* __restrict__ x, const LinGroup g, int M, int I, int isplit,
+__global__ __launch_bounds__(TPB) void linear_fwd_kernel(const float* x, const LinGroup g, int M, int I, int isplit,
                                                           int act, float gain) {
   // LF_MT rows per block (not the 32 of the other small-M kernels): with 32 rows a lane had 64 sixteen-byte loads of x to wait for
   // in batches and a 512 x 512 layer occupied 64 CUs for 18 us; 8 rows put all 16 loads in flight at once on 256 blocks
@@ -89,6 +92,7 @@ __global__ __launch_bounds__(TPB) void linear_fwd_kernel(const float* __restrict
   const int o0 = blockIdx.x * 8;
   if (o0 >= O) return;
   const float* __restrict__ w = g.w[l];
+  if (g.xin[l]) { x = g.xin[l]; I = g.Iv[l]; }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int mt = blockIdx.y / isplit, sp = blockIdx.y - mt * isplit;
   const int m0 = mt * LF_MT;
@@ -151,11 +155,12 @@ __global__ void linear_finalize_kernel(float* __restrict__ y, const float* __res
 // blocks add into a zeroed gx; a single-chunk launch stores directly.  (The first version looped over all of O in 8 blocks:
 // 53 us for a 512x512 layer.)
 constexpr int LIN_OC = 64;
-__global__ __launch_bounds__(TPB) void linear_bwd_data_kernel(const LinGroup g, float* __restrict__ gx, int M, int I, int nchunk,
+__global__ __launch_bounds__(TPB) void linear_bwd_data_kernel(const LinGroup g, float* gx, int M, int I, int nchunk,
                                                                int accumulate) {
   __shared__ float gs[LIN_OC * 32];
   const int l = blockIdx.y / nchunk, o0 = (blockIdx.y - l * nchunk) * LIN_OC, O = g.O[l];
   if (o0 >= O) return;
+  if (g.Iv[l]) I = g.Iv[l];
   const int oc = min(LIN_OC, O - o0);
   const float* __restrict__ gy = g.aux[l];
   const int il = threadIdx.x & 63, mg = threadIdx.x >> 6;
@@ -178,6 +183,7 @@ __global__ __launch_bounds__(TPB) void linear_bwd_data_kernel(const LinGroup g, 
     acc[4] += g1[0] * wv; acc[5] += g1[1] * wv; acc[6] += g1[2] * wv; acc[7] += g1[3] * wv;
   }
   const float sc = g.scale[l];
+  if (g.out[l]) gx = g.out[l];                                 // per-layer data gradient (layers with their own inputs)
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int mrow = m0 + mg * 8 + j;
@@ -192,13 +198,14 @@ __global__ __launch_bounds__(TPB) void linear_bwd_data_kernel(const LinGroup g, 
 // Block = 16 rows o x 256 columns i: the 16 x M slice of gy is staged in LDS once (broadcast reads), x is read coalesced and
 // reused for the 16 rows from registers.  (One block per row re-read x 512 times and was latency-bound: 18 us for 512 x 512.)
 constexpr int LW_OT = 16, LW_MC = 64;
-__global__ __launch_bounds__(TPB) void linear_wgrad_kernel(const LinGroup g, const float* __restrict__ x, int M, int I) {
+__global__ __launch_bounds__(TPB) void linear_wgrad_kernel(const LinGroup g, const float* x, int M, int I) {
   __shared__ float gs[LW_MC][LW_OT];
   const int l = blockIdx.z, O = g.O[l];
   const int o0 = blockIdx.y * LW_OT;
   if (o0 >= O) return;
   const int i = blockIdx.x * TPB + threadIdx.x;
   const float* __restrict__ gy = g.aux[l];
+  if (g.xin[l]) { x = g.xin[l]; I = g.Iv[l]; }
   float acc[LW_OT];
 #pragma unroll
   for (int r = 0; r < LW_OT; ++r) acc[r] = 0.f;
@@ -651,6 +658,48 @@ int lcgan_linear_group_bwd(const float* const* gy, const float* x, const float* 
   if (gb) {
     for (int l = 0; l < L; ++l) g.out[l] = gb[l];
     hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(maxO, TPB), L), dim3(TPB), 0, s, g, M);
+  }
+  return launch_status();
+}
+// L <= 24 linear layers with their OWN inputs x_l [M, I_l] and shapes [O_l, I_l] -- the layers at equal depth of the two mapping networks
+// (custom_layers.py:259-287; cnn.py:66-72), which the reference runs as two sequential chains -- in one launch forward and two backward
+// (all gx_l; all gw_l + gb_l).  Host arrays of L device pointers / sizes.
+int lcgan_linear_multi_fwd(const float* const* x, const float* const* w, const float* const* bias, float* const* y, const int* I, const int* O,
+                           const float* scale, const float* bias_scale, int L, int M, int act, float gain, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (M <= 0 || L <= 0 || L > LIN_MAXL) return LCGAN_EINVAL;
+  LinGroup g = {};
+  int maxO = 0, all8 = 1; double fl = 0;
+  for (int l = 0; l < L; ++l) {
+    if (I[l] <= 0 || I[l] >= 2048) return LCGAN_EINVAL;
+    g.xin[l] = x[l]; g.Iv[l] = I[l]; g.w[l] = w[l]; g.aux[l] = bias ? bias[l] : nullptr; g.out[l] = y[l]; g.O[l] = O[l]; g.scale[l] = scale[l];
+    g.bscale[l] = bias_scale[l]; maxO = std::max(maxO, O[l]); all8 &= (I[l] % 8 == 0); fl += (double)I[l] * O[l];
+  }
+  ProfScope p(KID_LINEAR, 2.0 * M * fl, 4.0 * fl, s);
+  return linear_group_fwd(x[0], g, L, maxO, M, all8 ? 8 : 7, act, gain, s);     // (the launch's I only selects the kernel: every layer carries its own)
+}
+int lcgan_linear_multi_bwd(const float* const* gy, const float* const* x, const float* const* w, const int* I, const int* O, const float* scale,
+                           const float* bias_scale, int L, int M, float* const* gx, float* const* gw, float* const* gb, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (M <= 0 || L <= 0 || L > LIN_MAXL) return LCGAN_EINVAL;
+  LinGroup g = {};
+  int maxO = 0, maxI = 0; double fl = 0;
+  for (int l = 0; l < L; ++l) {
+    g.w[l] = w[l]; g.aux[l] = gy[l]; g.xin[l] = x[l]; g.Iv[l] = I[l]; g.O[l] = O[l]; g.scale[l] = scale[l]; g.bscale[l] = bias_scale[l];
+    maxO = std::max(maxO, O[l]); maxI = std::max(maxI, I[l]); fl += (double)I[l] * O[l];
+  }
+  ProfScope p(KID_LINEAR, ((gx ? 2.0 : 0.0) + (gw ? 2.0 : 0.0)) * M * fl, 4.0 * fl, s);
+  if (gx) {
+    const int nchunk = cdiv(maxO, LIN_OC), acc = nchunk > 1 ? 1 : 0;
+    for (int l = 0; l < L; ++l) {
+      g.out[l] = gx[l];
+      if (acc) hipMemsetAsync(gx[l], 0, (size_t)M * I[l] * sizeof(float), s);
+    }
+    hipLaunchKernelGGL(linear_bwd_data_kernel, dim3(cdiv(maxI, 64), L * nchunk, cdiv(M, MT)), dim3(TPB), 0, s, g, gx[0], M, maxI, nchunk, acc);
+  }
+  if (gw) {
+    for (int l = 0; l < L; ++l) { g.out[l] = gw[l]; g.out2[l] = gb ? gb[l] : nullptr; }
+    hipLaunchKernelGGL(linear_wgrad_kernel, dim3(cdiv(maxI, TPB), cdiv(maxO, LW_OT), L), dim3(TPB), 0, s, g, x[0], M, maxI);
   }
   return launch_status();
 }

@@ -316,6 +316,26 @@ def mapping_matrices(nets):
     return list((Q * d.unsqueeze(1)).unbind(0))
 
 
+def mapping_forward(nets, zs, Ls=None):
+    """[net(z, L) for net, z, L in zip(nets, zs, Ls)] with the layers the networks have at equal depth evaluated together (ops.MultiLinearFn:
+    the reference's geometry and appearance mapping networks are twelve layers each, cnn.py:66-72 -- 12 launches per pass instead of 24)."""
+    nets = list(nets)
+    if Ls is None:
+        Ls = mapping_matrices(nets)
+    xs = [ops.LinearFn.apply(z.contiguous(), L.contiguous(), None, 1.0, 0.0, ACT_NONE, 1.0) for z, L in zip(zs, Ls)]   # x_b = L z_b (:283-285)
+    depth = max(n.num_layers for n in nets)
+    for i in range(depth):
+        live = [k for k, n in enumerate(nets) if i < n.num_layers]
+        layers = [nets[k].mlp[i] for k in live]
+        if len(live) > 1 and len({xs[k].shape[0] for k in live}) == 1:
+            for k, y in zip(live, ops.multi_linear([xs[k] for k in live], layers)):
+                xs[k] = y
+        else:
+            for k, l in zip(live, layers):
+                xs[k] = l(xs[k])
+    return xs
+
+
 class ProjectionHead(nn.Module):
     """reference custom_layers.py:290-306.  The LeakyReLU modules stay in the Sequential (state_dict indices 0,2,4) but
     are fused into the preceding linear kernel."""

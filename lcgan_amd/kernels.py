@@ -572,6 +572,43 @@ class HipKernels:
                    self._ptr_array(gbs), self._stream())
         return gx, gws, gbs
 
+    def linear_multi_fwd(self, xs, ws, biases, scales, bias_scales, act: int = ACT_NONE, gain: float = 1.0):
+        """L linear layers with their own inputs: [y_l = act(scale_l x_l w_l^T + bias_l bias_scale_l) gain] from one launch"""
+        import ctypes as C
+        self._chk(*xs, *ws, *biases)
+        M, L = xs[0].shape[0], len(ws)
+        Is, Os = [int(w.shape[1]) for w in ws], [int(w.shape[0]) for w in ws]
+        flat = torch.empty((M * sum(Os),), dtype=torch.float32, device=xs[0].device)
+        ys, off = [], 0
+        for O in Os:
+            ys.append(flat[off:off + M * O].view(M, O))
+            off += M * O
+        self._call("lcgan_linear_multi_fwd", self._ptr_array(xs), self._ptr_array(ws), self._ptr_array(biases), self._ptr_array(ys),
+                   (C.c_int * L)(*Is), (C.c_int * L)(*Os), (C.c_float * L)(*scales), (C.c_float * L)(*bias_scales), L, M, act, float(gain),
+                   self._stream())
+        return ys
+
+    def linear_multi_bwd(self, gys, xs, ws, scales, bias_scales, want_gx=True):
+        """-> ([gx_l [M,I_l]] | None, [gw_l [O_l,I_l]], [gb_l [O_l]]) from two launches"""
+        import ctypes as C
+        self._chk(*gys, *xs, *ws)
+        M, L = xs[0].shape[0], len(ws)
+        dev = xs[0].device
+        Is, Os = [int(w.shape[1]) for w in ws], [int(w.shape[0]) for w in ws]
+        flat = torch.empty((sum(M * I for I in Is) * int(want_gx) + sum(O * I + O for O, I in zip(Os, Is)),), dtype=torch.float32, device=dev)
+        gxs, gws, gbs, off = ([] if want_gx else None), [], [], 0
+        if want_gx:
+            for I in Is:
+                gxs.append(flat[off:off + M * I].view(M, I)); off += M * I
+        for O, I in zip(Os, Is):
+            gws.append(flat[off:off + O * I].view(O, I)); off += O * I
+        for O in Os:
+            gbs.append(flat[off:off + O]); off += O
+        self._call("lcgan_linear_multi_bwd", self._ptr_array(gys), self._ptr_array(xs), self._ptr_array(ws), (C.c_int * L)(*Is), (C.c_int * L)(*Os),
+                   (C.c_float * L)(*scales), (C.c_float * L)(*bias_scales), L, M, self._ptr_array(gxs) if want_gx else None,
+                   self._ptr_array(gws), self._ptr_array(gbs), self._stream())
+        return gxs, gws, gbs
+
     def act_bwd_f32(self, gy: Tensor, y: Tensor, act: int, gain: float) -> Tensor:
         self._chk(gy, y)
         gz = torch.empty_like(gy)

@@ -674,6 +674,37 @@ class GroupedLinearFn(Function):
         return tuple(out)
 
 
+class MultiLinearFn(Function):
+    """y_l = scale_l * x_l @ w_l^T + bias_l * bias_scale_l for L layers with their OWN inputs and shapes (the two mapping networks at equal
+    depth): one launch forward, two backward; first order only (the R1 double backward never reaches the generator)."""
+
+    @staticmethod
+    def forward(ctx, scales, bias_scales, *xwb):
+        L = len(scales)
+        xs, ws, bs = xwb[:L], xwb[L:2 * L], xwb[2 * L:]
+        ctx.save_for_backward(*xs, *ws)
+        ctx.cfg = (tuple(scales), tuple(bias_scales))
+        return tuple(_K().linear_multi_fwd([x.contiguous() for x in xs], ws, bs, scales, bias_scales, ACT_NONE, 1.0))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gys):
+        scales, bias_scales = ctx.cfg
+        L = len(scales)
+        saved = ctx.saved_tensors
+        xs, ws = saved[:L], saved[L:]
+        gys = [torch.zeros((x.shape[0], w.shape[0]), dtype=torch.float32, device=x.device) if g is None else g.contiguous()
+               for g, x, w in zip(gys, xs, ws)]
+        gxs, gws, gbs = _K().linear_multi_bwd(gys, [x.contiguous() for x in xs], ws, scales, bias_scales, want_gx=any(ctx.needs_input_grad[2:2 + L]))
+        return (None, None, *(gxs if gxs is not None else [None] * L), *gws, *gbs)
+
+
+def multi_linear(xs, linears):
+    """[m(x) for m, x in zip(linears, xs)] for EqualizedLinear modules, through MultiLinearFn"""
+    return list(MultiLinearFn.apply([m.weight.c for m in linears], [m.lr_mul for m in linears], *[x.contiguous() for x in xs],
+                                    *[m.weight.weight for m in linears], *[m.bias for m in linears]))
+
+
 def grouped_linear(x, linears):
     """[EqualizedLinear(x) for each module] through GroupedLinearFn (in slices of 24 layers)."""
     x = x.contiguous()

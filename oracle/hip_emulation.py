@@ -443,6 +443,13 @@ class EmulatedKernels:
     def linear_group_fwd(self, x, ws, biases, scales, bias_scales, act=0, gain=1.0):
         return [self.linear_fwd(x, w, b, sc, bs, act, gain) for w, b, sc, bs in zip(ws, biases, scales, bias_scales)]
 
+    def linear_multi_fwd(self, xs, ws, biases, scales, bias_scales, act=0, gain=1.0):
+        return [self.linear_fwd(x, w, b, sc, bs, act, gain) for x, w, b, sc, bs in zip(xs, ws, biases, scales, bias_scales)]
+
+    def linear_multi_bwd(self, gys, xs, ws, scales, bias_scales, want_gx=True):
+        gxs = [self.linear_bwd_data(g, w, sc) for g, w, sc in zip(gys, ws, scales)] if want_gx else None
+        return gxs, [self.linear_wgrad(g, x, sc) for g, x, sc in zip(gys, xs, scales)], [self.colsum(g, bs) for g, bs in zip(gys, bias_scales)]
+
     def linear_group_bwd(self, gys, x, ws, scales, bias_scales, want_gx=True):
         gx = None
         if want_gx:

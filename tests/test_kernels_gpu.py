@@ -887,6 +887,30 @@ def test_linear_group(H, M, I, Os):
     assert H.linear_group_bwd([t.cuda() for t in gys], x.cuda(), [w.cuda() for w in ws], scs, bss, want_gx=False)[0] is None
 
 
+@pytest.mark.parametrize("M,shapes", [(32, [(64, 64), (512, 512)]), (4, [(64, 64), (128, 64)]), (5, [(64, 96), (100, 130), (8, 24)]), (37, [(512, 256), (64, 64)])])
+def test_linear_multi(H, M, shapes):
+    """linear layers with their own inputs and shapes (the two mapping networks at equal depth) from shared launches"""
+    g = torch.Generator().manual_seed(93)
+    L = len(shapes)
+    xs = [torch.randn(M, I, generator=g) for I, _ in shapes]
+    ws = [torch.randn(O, I, generator=g) for I, O in shapes]
+    bs = [torch.randn(O, generator=g) for _, O in shapes]
+    scs = [1 / math.sqrt(I) * (1 + 0.1 * l) for l, (I, _) in enumerate(shapes)]
+    bss = [0.01 * (1 + l) for l in range(L)]
+    f32 = torch.float32
+    cu = lambda ts: [t.cuda() for t in ts]
+    for l, (y, e) in enumerate(zip(H.linear_multi_fwd(cu(xs), cu(ws), cu(bs), scs, bss), E.linear_multi_fwd(xs, ws, bs, scs, bss))):
+        check(y, e, f32, f"fwd {l}")
+    gys = [torch.randn(M, O, generator=g) for _, O in shapes]
+    gxs, gws, gbs = H.linear_multi_bwd(cu(gys), cu(xs), cu(ws), scs, bss)
+    exs, ews, ebs = E.linear_multi_bwd(gys, xs, ws, scs, bss)
+    for l in range(L):
+        check(gxs[l], exs[l], f32, f"gx {l}")
+        check(gws[l], ews[l], f32, f"gw {l}")
+        check(gbs[l], ebs[l], f32, f"gb {l}")
+    assert H.linear_multi_bwd(cu(gys), cu(xs), cu(ws), scs, bss, want_gx=False)[0] is None
+
+
 def test_demod_group(H):
     """demodulation vectors of several layers from one launch == the per-layer kernel"""
     g = torch.Generator().manual_seed(102)
