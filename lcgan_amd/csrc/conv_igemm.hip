@@ -3003,7 +3003,9 @@ int dispatch_igemm(const ConvArgs& a_in, int nphase, int dtype, hipStream_t s) {
   if (g_use_splitk && wgs <= 192 && nq_min >= 8) {
     int ns = std::min(nq_min / 4, (256 + wgs - 1) / wgs);
     if (ns > 1) {
-      const bool k8 = dtype == DT_BF16 && g_igemm_dma >= 3 && g_splitk_slabs > 0 && ns <= g_splitk_slabs && !a.pre && a.Cin % 32 == 0 && a.Kpad == a.Cin &&
+      // (... and only launches of >= 2048 output positions: below that the atomics are few and the slab's chain of device-scope round trips -- store,
+      //  counter, reload -- costs a 10-20 us launch 5-10 us more than the finalize launch it saves; measured per shape in the batch-4 iteration)
+      const bool k8 = dtype == DT_BF16 && g_igemm_dma >= 3 && g_splitk_slabs > 0 && ns <= g_splitk_slabs && (long long)a.M * nphase >= 2048 && !a.pre && a.Cin % 32 == 0 && a.Kpad == a.Cin &&
                       (long long)a.B * a.Hin * a.Win * a.Cin < (1ll << 31) && wgs <= SPLITK_MAX_TILES;      // (launch_igemm's conditions for conv_igemm8_kernel)
       if (k8) {
         int* cnt = nullptr;

@@ -451,7 +451,7 @@ def test_flow_wgrad_one_pass(H, case):
 
 @pytest.mark.parametrize("opts", [(2, 0), (3, 0), (3, 8), (4, 64)])
 @pytest.mark.parametrize("case", [(2, 8, 8, 64, 128, 3, 1), (8, 8, 8, 512, 512, 3, 1), (4, 4, 4, 512, 512, 3, 1), (3, 16, 16, 64, 96, 3, 2), (2, 8, 8, 128, 256, 1, 1),
-                                  (32, 16, 16, 128, 128, 3, 1)])
+                                  (32, 16, 16, 128, 128, 3, 1), (32, 8, 8, 512, 512, 3, 1), (4, 32, 32, 512, 256, 3, 1), (16, 32, 32, 256, 256, 3, 2)])
 def test_conv_igemm_dma_variants(H, case, opts):
     """the generic implicit-GEMM kernel's LDS-DMA loops: four waves (option 16 = 2), eight waves with three / four stages (3 / 4), split-K
     through atomics + finalize (option 19 = 0) or through per-split slabs finished by the last split to arrive (up to option 19 splits);
@@ -469,7 +469,7 @@ def test_conv_igemm_dma_variants(H, case, opts):
         res = feat((B, Hh // stride, W // stride, ceil8(Co)), dtype, 7, Co)
         got = H.conv_fwd(x.cuda(), pw_h, Co, k, stride, bias=bias.cuda(), act=1, gain=1.4, residual=res.cuda())
         check(got, E.conv_fwd(x, pw_e, Co, k, stride, bias=bias, act=1, gain=1.4, residual=res), dtype, "fwd")
-        if opts[1] >= 64:
+        if opts[1] >= 64 and B * (Hh // stride) * (W // stride) >= 2048:      # (smaller launches keep the atomics: see dispatch_igemm)
             again = H.conv_fwd(x.cuda(), pw_h, Co, k, stride, bias=bias.cuda(), act=1, gain=1.4, residual=res.cuda())
             assert torch.equal(got, again)
         g = feat((B, Hh // stride, W // stride, ceil8(Co)), dtype, 11, Co)
