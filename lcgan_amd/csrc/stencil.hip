@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const T* __restrict__ 
 #pragma unroll
     for (int u = 0; u < 4; ++u) en[u] = entries[k + u];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) t[u] = buf_load8<T>(gr, (unsigned)__umul24((unsigned)en[u].p, pitch) + voff);
+    for (int u = 0; u < 4; ++u) t[u] = buf_load8<T>(gr, (unsigned)en[u].p * pitch + voff);   // (a full 32-bit product: pixel indices pass 2^24 at 1024 x 1024, batch 32)
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(256) void warp_gather_kernel(const T* __restrict__ 
   }
   for (; k < end; ++k) {
     const WarpEntry en = entries[k];
-    const F8 t = buf_load8<T>(gr, (unsigned)__umul24((unsigned)en.p, pitch) + voff);
+    const F8 t = buf_load8<T>(gr, (unsigned)en.p * pitch + voff);
 #pragma unroll
     for (int j = 0; j < 8; ++j) s.v[j] += en.w * t.v[j];
   }
@@ -1544,7 +1544,7 @@ int lcgan_warp_bwd(const void* gy, const void* x, const void* flow, void* gx, vo
   const long long npix = (long long)B * H * W, n = npix * (C / 8);
   const double eb = dtype == DT_BF16 ? 2 : 4;
   // 32-bit byte offsets and 24-bit multiplies in the tap addressing (see warp_fwd_kernel)
-  if ((double)n * 8 * eb >= 4294967296.0 || (long long)W * C * 4 >= (1 << 24) || npix >= (1 << 24)) return LCGAN_EINVAL;
+  if ((double)n * 8 * eb >= 4294967296.0 || (long long)W * C * 4 >= (1 << 24) || (long long)B * H >= (1 << 24)) return LCGAN_EINVAL;
   const WarpDims dm = warp_dims(C, H, W);
   Tag tg("warp_bwd", B, H, W, C);
   ProfScope p(KID_WARP_BWD, 0, (double)n * 8 * 4 * eb + (double)npix * 16 * 8 * 2, s, tg.s);

@@ -703,6 +703,31 @@ def test_warp_bwd_rough_flow_large(H):
     check(gf_g, gf_r, dtype, "rough gflow")
 
 
+def test_warp_pixel_count_beyond_2_24(H):
+    """more than 2^24 pixels in one call (1024 x 1024 at batch 32 has 2^25): the forward and the backward of the LAST samples of a
+    big batch -- whose pixel indices are the large ones -- must equal the same samples run as a small batch (the 24-bit index
+    multiplies of the first round-3 version of the gather kernel refused such calls)"""
+    dtype = torch.bfloat16
+    B, Hh, W, C = 18, 1024, 1024, 8                              # 18.9 M pixels
+    g = torch.Generator(device="cuda").manual_seed(59)
+    x = torch.randn(B, Hh, W, C, device="cuda", generator=g).to(dtype)
+    gy = torch.randn(B, Hh, W, C, device="cuda", generator=g).to(dtype)
+    coarse = torch.randn(B, 2, 16, 16, device="cuda", generator=g)
+    flow = torch.zeros(B, Hh, W, 8, device="cuda")
+    flow[..., :2] = torch.tanh(torch.nn.functional.interpolate(coarse, size=(Hh, W), mode="bilinear", align_corners=False).permute(0, 2, 3, 1))
+    flow = flow.to(dtype)
+    y = H.warp_fwd(x, flow, 0.1)
+    gx, gf = H.warp_bwd(gy, x, flow, 0.1)
+    torch.cuda.synchronize()
+    tail = slice(B - 2, B)
+    y2 = H.warp_fwd(x[tail].contiguous(), flow[tail].contiguous(), 0.1)
+    gx2, gf2 = H.warp_bwd(gy[tail].contiguous(), x[tail].contiguous(), flow[tail].contiguous(), 0.1)
+    assert torch.equal(y[tail], y2)
+    assert torch.equal(gf[tail], gf2)
+    rel = float((gx[tail].float() - gx2.float()).norm() / gx2.float().norm())
+    assert rel <= 2e-3, rel                                      # (list order = arrival order of the fill pass: fp32 sums in another order)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("N,G,C", [(4, 4, 64), (8, 8, 64), (16, 8, 64), (32, 8, 64), (32, 4, 512), (8, 4, 20)])
 def test_mbstd(H, dtype, N, G, C):
