@@ -773,7 +773,7 @@ class ActBwdF32Fn(Function):
 # ---- demodulation vectors of a whole generator pass in one launch ------------------------------------------------------------------
 # Every modulated layer's style is known before the first convolution (the grouped affines), so Generator.forward has the d[b,o] of
 # all its layers computed by ONE kernel (lcgan_demod_group) and the Functions below pick theirs up here instead of launching
-# lcgan_demod_fwd each (19 launches per generator pass).  Keyed by the style tensor's storage; filled and cleared by Generator.forward.
+# lcgan_demod_fwd each (19 launches per generator pass).  Keyed by (layer weight, style tensor's storage); filled and cleared by Generator.forward.
 _demod_cache = {}
 
 
@@ -786,18 +786,23 @@ def precompute_demod(entries, need_lo: bool):
         c_eq = 1.0 / math.sqrt(Cin * k * k)
         wsq = _flow_prep(w, c_eq, need_lo)[2] if flow else _prep(w, c_eq, False, need_lo, want_wsq=True)[1]
         ss.append(s_.contiguous()); wsqs.append(wsq); osts.append(8 if flow else ceil8(O))
+    ws = [e[0] for e in entries]
     for i in range(0, len(ss), 24):
-        for s_, d in zip(ss[i:i + 24], K.demod_group(ss[i:i + 24], wsqs[i:i + 24], osts[i:i + 24])):
-            _demod_cache[(s_.data_ptr(), s_.shape[0], s_.shape[1], d.shape[1])] = d
+        for w_, s_, d in zip(ws[i:i + 24], ss[i:i + 24], K.demod_group(ss[i:i + 24], wsqs[i:i + 24], osts[i:i + 24])):
+            _demod_cache[(id(w_), s_.data_ptr(), s_.shape[0], s_.shape[1], d.shape[1])] = d
 
 
 def clear_demod():
     _demod_cache.clear()
 
 
-def _demod(K, s, wsq, ostride):
-    hit = _demod_cache.get((s.data_ptr(), s.shape[0], s.shape[1], ostride))
-    return hit if hit is not None else K.demod_fwd(s, wsq, ostride)
+def _demod(K, w, s, wsq, ostride):
+    """d[b,o] of layer `w` under style `s`: the vector Generator.forward precomputed for exactly this (weight, style) pair, else one launch"""
+    hit = _demod_cache.get((id(w), s.data_ptr(), s.shape[0], s.shape[1], ostride))
+    if hit is not None:
+        assert hit.shape == (s.shape[0], ostride), (hit.shape, s.shape, ostride)
+        return hit
+    return K.demod_fwd(s, wsq, ostride)
 
 
 class ModConvFn(Function):
@@ -812,7 +817,7 @@ class ModConvFn(Function):
         c_eq = 1.0 / math.sqrt(Cin * k * k)
         s = s.contiguous()
         pw, wsq = _prep(w, c_eq, False, _need_lo(x), want_wsq=True)             # [t][O][Cin] serves conv AND up-conv forward
-        d = _demod(K, s, wsq, ceil8(O))
+        d = _demod(K, w, s, wsq, ceil8(O))
         if up == 2:
             y = K.conv_bwd_data(x, pw, O, k, 2, pre=s, post=d, bias=bias, bias_scale=1.0, act=act, gain=gain)
         elif _use_fp8(x, k, 1):
@@ -872,7 +877,7 @@ class ModConvRGBFn(Function):
         c_eq = 1.0 / math.sqrt(Cin * k * k)
         s = s.contiguous()
         pw, wsq = _prep(w, c_eq, False, _need_lo(x), want_wsq=True)
-        d = _demod(K, s, wsq, ceil8(O))
+        d = _demod(K, w, s, wsq, ceil8(O))
         if _use_fp8(x, k, 1):
             pw8, _ = _prep(w, c_eq, False, False, fp8=True)
             y = K.conv_fwd_fp8(x, pw8, O, k, 1, pre=s, post=d, bias=bias, bias_scale=1.0, act=act, gain=gain)
@@ -935,7 +940,7 @@ class FlowConvFn(Function):
         c_eq = 1.0 / math.sqrt(Cin * k * k)
         s = s.contiguous()
         pw18, _, wsq = _flow_prep(w, c_eq, _need_lo(x))
-        d = _demod(K, s, wsq, 8)
+        d = _demod(K, w, s, wsq, 8)
         t = K.conv_fwd(x, pw18, 18, 1, 1, pre=s)                                 # [B,H,W,24]
         u = K.flow_col2im(t, d, bias)                                            # [B,2H,2W,8]
         ctx.save_for_backward(x, w, bias, s, d, wsq, u)

@@ -69,7 +69,10 @@ class TensorTable:
 class Adam:
     """torch.optim.Adam(params, lr, betas, eps) restricted to what worker.py:98-110 uses (no weight decay / amsgrad)."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float, betas=(0.0, 0.99), eps: float = 1e-8):
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float, betas=(0.0, 0.99), eps: float = 1e-8, on_zero_grad=None):
+        """on_zero_grad: called by zero_grad() -- DataParallel.reset_reduction of the network these parameters belong to, so that the
+        start of a step also clears whatever an aborted step left behind in the gradient buckets"""
+        self.on_zero_grad = on_zero_grad
         self.params: List[torch.nn.Parameter] = list(params)
         self.lr, self.beta1, self.beta2, self.eps = float(lr), float(betas[0]), float(betas[1]), float(eps)
         self.exp_avg = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in self.params]
@@ -78,6 +81,8 @@ class Adam:
         self._tables = {}                     # which parameters have a gradient (structural: a few sets per run) -> TensorTable
 
     def zero_grad(self, set_to_none: bool = True):
+        if self.on_zero_grad is not None:
+            self.on_zero_grad()
         for p in self.params:
             p.grad = None
 
@@ -138,17 +143,32 @@ class DataParallel(torch.nn.Module):
     reads the reduced values in place.  `sync_gradients()` after the backward launches what is left (buckets that hold parameters the
     iteration did not use never count down to zero) and returns a handle on all reductions.  Parameters whose grad is None on this rank
     are treated as unused -- the sets are structural in LC-GAN (projection heads on odd iterations, frozen layers), hence identical on
-    every rank; a bucket without any gradient is not reduced at all."""
+    every rank; a bucket without any gradient is not reduced at all.
+
+    Contract: ONE backward pass, then sync_gradients().  A gradient that arrives for a bucket already handed to the all-reduce (a
+    second backward before the sync: gradient accumulation, or the other network's parameters left with requires_grad=True) would be
+    added in place into a buffer a collective may still be reading and would never be reduced: the hook raises instead.
+    `reset_reduction()` (wired to the optimiser's zero_grad()) drops whatever a step that died between backward and sync left behind.
+
+    The ORDER of the collectives is the order in which autograd finishes the buckets; it is the same on every rank because every rank
+    runs the same graph (same code, same shapes, same grad-None sets), not because anything enforces it.  `check=True` (or
+    LCGAN_DDP_CHECK=1 in the environment) is the debug mode that verifies exactly that before any gradient collective is issued:
+    nothing is launched from the hooks, and sync_gradients() first all-reduces (min and max in one call) the bitmap of parameters that
+    received a gradient together with the order in which the buckets completed, and raises on EVERY rank -- naming the parameters --
+    when the ranks disagree, where the unchecked path would hang in RCCL or silently mix buckets."""
 
     BUCKET_BYTES = 25 << 20
 
-    def __init__(self, module: torch.nn.Module, process_group=None, broadcast: bool = True):
+    def __init__(self, module: torch.nn.Module, process_group=None, broadcast: bool = True, check: Optional[bool] = None):
         super().__init__()
+        import os
         self.module = module
         self._pg = process_group
         self._buckets: Optional[List[_Bucket]] = None
         self._works: list = []
         self._armed = False                    # counts of the running backward pass are initialised
+        self._order: list = []                 # bucket indices in the order their last gradient arrived (this backward pass)
+        self.check = bool(int(os.environ.get("LCGAN_DDP_CHECK", "0"))) if check is None else bool(check)
         if broadcast and self.world_size > 1:
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):     # DDP ctor broadcast of rank-0 state
@@ -169,6 +189,7 @@ class DataParallel(torch.nn.Module):
         torch.nn.Module.__init__(new)
         new.module = copy.deepcopy(self.module, memo)
         new._pg, new._buckets, new._works, new._armed = self._pg, None, [], False     # (the EMA copy never runs a backward pass)
+        new._order, new.check = [], self.check
         return new
 
     # ---- buckets ----------------------------------------------------------------------------------------------------------
@@ -205,15 +226,37 @@ class DataParallel(torch.nn.Module):
         for b in self._buckets:
             b.expected = sum(1 for p in b.params if p.requires_grad)
             b.fired, b.launched = 0, False
+        self._order = []
         self._armed = True
+
+    def reset_reduction(self) -> None:
+        """Start of a step (optimiser.zero_grad()): forget the bucket state of a step that never reached sync_gradients() -- an
+        exception between backward and sync -- after waiting for the reductions it had already issued (they read the flat buffer)."""
+        if self._buckets is None:
+            return
+        works, self._works = self._works, []
+        for w in works:
+            w.wait()
+        for b in self._buckets:
+            b.fired, b.launched = 0, False
+        self._order = []
+        self._armed = False
 
     def _on_grad(self, p: torch.nn.Parameter) -> None:
         if not self._armed:
             self._arm()
         b = self._bucket_of[id(p)]
+        if b.launched or (b.expected and b.fired >= b.expected):
+            raise RuntimeError(
+                "DataParallel: a gradient arrived for a bucket that was already handed to the all-reduce -- a second backward pass "
+                "before sync_gradients() (gradient accumulation, or parameters of the other network left with requires_grad=True). "
+                "It would be added in place into a buffer the collective may still be reading and never be reduced. Call "
+                "sync_gradients() after every backward pass (zero_grad() / reset_reduction() clears an aborted step).")
         b.fired += 1
-        if b.fired >= b.expected and not b.launched:
-            self._launch(b)
+        if b.fired == b.expected:
+            self._order.append(self._buckets.index(b))
+            if not self.check:
+                self._launch(b)
 
     @torch.no_grad()
     def _launch(self, b: _Bucket) -> None:
@@ -246,6 +289,8 @@ class DataParallel(torch.nn.Module):
             return _Done()
         if not self._armed:
             self._arm()                                         # (a backward pass that touched no parameter of this network)
+        if self.check:
+            self._verify_ranks_agree()
         for b in self._buckets:
             if not b.launched:
                 self._launch(b)
@@ -255,6 +300,27 @@ class DataParallel(torch.nn.Module):
             return handle
         handle.wait()
         return _Done()
+
+
+    def _verify_ranks_agree(self) -> None:
+        """debug mode (self.check): one all-reduce of [v, -v] under MAX gives max and min over the ranks of
+        v = (gradient-present bit per parameter, bucket completion order); any difference raises on every rank"""
+        params = [p for b in self._buckets for p in b.params]
+        nb = len(self._buckets)
+        v = [1 if p.grad is not None else 0 for p in params] + (self._order + [-1] * nb)[:nb]
+        t = torch.tensor(v + [-x for x in v], dtype=torch.int32, device=self._buckets[0].flat.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._pg)
+        t = t.cpu().tolist()
+        hi, lo = t[:len(v)], [-x for x in t[len(v):]]
+        if hi != lo:
+            names = {id(p): k for k, p in self.module.named_parameters()}
+            bad = [names.get(id(p), "?") for i, p in enumerate(params) if hi[i] != lo[i]]
+            order_differs = hi[len(params):] != lo[len(params):]
+            raise RuntimeError(
+                f"DataParallel(check): the ranks disagree on this step's gradients (rank {dist.get_rank(self._pg)}): "
+                f"{len(bad)} parameter(s) have a gradient on some ranks and none on others {bad[:8]}"
+                + ("; the buckets completed in a different order" if order_differs else "")
+                + ". The unchecked path would issue mismatched collectives here.")
 
 
 class _Works:

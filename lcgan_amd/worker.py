@@ -161,8 +161,8 @@ class WORKER(object):
         generator = DataParallel(generator, self.group)
         discriminator = DataParallel(discriminator, self.group)
         betas = (self.args.beta1, self.args.beta2)
-        g_optimizer = Adam(g_parameters, lr=self.args.g_lr, betas=betas, eps=1e-8)
-        d_optimizer = Adam(d_parameters, lr=self.args.d_lr, betas=betas, eps=1e-8)
+        g_optimizer = Adam(g_parameters, lr=self.args.g_lr, betas=betas, eps=1e-8, on_zero_grad=generator.reset_reduction)
+        d_optimizer = Adam(d_parameters, lr=self.args.d_lr, betas=betas, eps=1e-8, on_zero_grad=discriminator.reset_reduction)
         return generator, discriminator, g_optimizer, d_optimizer
 
     def freeze_discriminator(self, freeze_up_to_index=5):

@@ -162,3 +162,66 @@ def test_deferred_allreduce_equals_synchronous(tmp_path):
                 continue                                        # per-rank buffers
             assert torch.equal(a0[net][k], a1[net][k]), (net, k)
             assert torch.equal(a0[net][k], b0[net][k]), (net, k)
+
+
+def _guard_main(rank, world, port, out_dir):
+    """DataParallel's contract on a toy module: one backward per sync (a second one raises instead of corrupting a bucket in flight),
+    zero_grad() clears an aborted step, check mode verifies the ranks' gradient sets before any collective and equals the unchecked path."""
+    import lcgan_amd.kernels as KM
+    from oracle.hip_emulation import EmulatedKernels
+    from tests.helpers import install_backend
+    from lcgan_amd.optim import Adam, DataParallel
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    install_backend(EmulatedKernels())
+    DataParallel.BUCKET_BYTES = 64 * 4                     # 64 floats per bucket: the 4 layers below land in 4 buckets
+
+    def make(check):
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(*[torch.nn.Linear(8, 8, bias=False) for _ in range(4)])
+        dp = DataParallel(net, None, check=check)
+        return net, dp, Adam(list(net.parameters()), lr=1e-2, on_zero_grad=dp.reset_reduction)
+
+    x = torch.full((2, 8), float(rank + 1))
+    # (1) one backward, one sync: mean gradients, identical with and without check mode
+    grads = {}
+    for check in (False, True):
+        net, dp, opt = make(check)
+        opt.zero_grad()
+        dp(x).sum().backward()
+        assert (len(dp._works) > 0) == (not check)         # check mode launches nothing from the hooks
+        dp.sync_gradients()
+        grads[check] = [p.grad.clone() for p in net.parameters()]
+    for a, b in zip(grads[False], grads[True]):
+        assert torch.equal(a, b)
+    # (2) a second backward before the sync raises from the hook (both modes)
+    for check in (False, True):
+        net, dp, opt = make(check)
+        opt.zero_grad()
+        dp(x).sum().backward()
+        with pytest.raises(RuntimeError, match="second backward"):
+            dp(x).sum().backward()
+        # (3) ... and the next step's zero_grad() recovers: buckets re-armed, reductions of the dead step drained
+        opt.zero_grad()
+        assert not dp._works and not dp._armed and all(not b.launched and b.fired == 0 for b in dp._buckets)
+        dp(x).sum().backward()
+        dp.sync_gradients()
+        for a, p in zip(grads[False], net.parameters()):
+            assert torch.allclose(a, p.grad)
+    # (4) a rank-local grad=None set (rank 1 freezes a layer the others train): check mode raises on EVERY rank, naming the parameter
+    net, dp, opt = make(True)
+    if rank == 1:
+        net[1].weight.requires_grad = False
+    opt.zero_grad()
+    dp(x).sum().backward()
+    with pytest.raises(RuntimeError, match=r"ranks disagree.*1\.weight"):
+        dp.sync_gradients()
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(out_dir, f"guard{rank}.ok"), "w").close()
+
+
+def test_data_parallel_guards(tmp_path):
+    world = 2
+    mp.spawn(_guard_main, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"guard{r}.ok").exists() for r in range(world))
