@@ -130,14 +130,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    ndev = torch.cuda.device_count()
-    dev_index = local_rank % max(ndev, 1)                  # (ranks > devices only happens in the single-GPU dry run below)
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    # LCGAN_BENCH_DEVICE=cpu exists for tests/test_bench_gloo.py only: it walks this file's world > 1 control flow (collective counts,
+    # lock-step of the ranks) on the host with the TESTS' kernel emulation installed.  The product has no CPU kernels: without that
+    # injection the first kernel call raises.
+    on_gpu = os.environ.get("LCGAN_BENCH_DEVICE", "cuda") != "cpu"
+    if on_gpu:
+        ndev = torch.cuda.device_count()
+        dev_index = local_rank % max(ndev, 1)              # (ranks > devices only happens in the single-GPU dry run below)
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
+    else:
+        dev = torch.device("cpu")
+
+    def dsync():
+        if on_gpu:
+            torch.cuda.synchronize()
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("LCGAN_DIST_BACKEND", "nccl")      # "nccl" == RCCL; "gloo" lets two ranks share one GPU for a dry run
-        if backend == "nccl":
+        if backend == "nccl" and on_gpu:
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
@@ -146,7 +157,7 @@ def main():
     from lcgan_amd.config import default_args as make_args
     config.set_feature_dtype(torch.float32 if a.dtype == "f32" else torch.bfloat16)
     config.set_conv_operands("fp8" if a.dtype == "fp8" else "bf16")
-    assert kernels.backend_name() == "hip"
+    assert kernels.backend_name() == "hip" or not on_gpu
     extra = dict(freezeD_start=0, freezeD_layer=a.freezeD_layer) if a.freezeD_layer >= 0 else {}
     args = make_args(a.res, a.batch, **extra)
     torch.manual_seed(0)                                   # identical reference-style init on every rank
@@ -159,7 +170,7 @@ def main():
     def sync():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        dsync()
 
     for i in range(a.warmup):
         loader.train_iteration(w, args, epoch_of(i))
@@ -216,10 +227,11 @@ def main():
         K = kernels.K
         K.prof_enable(True)
         loader.train_iteration(w, args, epoch_of(a.warmup + a.steps))
-        torch.cuda.synchronize()
+        dsync()
         prof = K.prof_collect()
         K.prof_enable(False)
-        ig, wg = prof["conv_igemm"], prof["conv_wgrad"]
+        none = {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "count": 0}
+        ig, wg = prof.get("conv_igemm", none), prof.get("conv_wgrad", none)
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         # `traffic` (HBM bytes per launch) needs PMC passes under rocprofv3 and cannot be measured inside this run: the separately
         # profiled figure of the same command (scripts/pmc_traffic.py -> profiles/r03_pmc_traffic.json, FETCH_SIZE x2 on gfx950) is quoted
@@ -243,7 +255,7 @@ def main():
         if a.launch_table:                                  # per-launch in-iteration table: shape -> us -> TFLOP/s (profiles/*_launch_table.csv)
             K.prof_enable(True)
             loader.train_iteration(w, args, epoch_of(a.warmup + a.steps + 1))
-            torch.cuda.synchronize()
+            dsync()
             K.prof_dump(a.launch_table)
             K.prof_enable(False)
     elif world > 1 and not a.no_roofline:
@@ -255,7 +267,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(a.res, full_cycle=a.cpu_baseline_cycle)
     if world > 1:
         w.flush()                                          # the roofline iteration's postponed all-reduce wait + Adam
-        torch.cuda.synchronize()
+        dsync()
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
