@@ -75,6 +75,28 @@ constexpr int TILE = BM * LDS_ROW;        // elements per staged operand tile
 
 struct TapTable { int n; int dy[9]; int dx[9]; int wt[9]; };
 
+// ---- split-K slab exchange: what orders it ---------------------------------------------------------------------------------------
+// Partial tiles cross XCDs (non-coherent L2s) as RELAXED agent-scope atomic stores / loads (`sc1`: written through, read past the local
+// L2) around a RELAXED agent-scope arrival counter.  Two different things make that correct, and neither is "the compiler happens to keep
+// relaxed accesses in program order":
+//   * language level: a release fence sits between a thread's slab stores and the counter add its workgroup makes on its behalf, and an
+//     acquire fence between that add (whose returned value names the last arriver) and the slab loads.  Fences order ALL atomic accesses
+//     of the thread across them whatever their own ordering (C++ [atomics.fences]), and the workgroup barriers carry the happens-before
+//     from every storing thread to the adding lane and from it to every loading thread.  Workgroup scope is enough for that (the
+//     cross-workgroup edge is the counter's own modification order) and costs only waitcnts here; an AGENT-scope release / acquire would
+//     emit `buffer_wbl2 sc1` / `buffer_inv sc1` per wave: a write-back / invalidate of the whole L2, measured at +55 us per launch with
+//     __threadfence(), for data that never sits dirty in L2.
+//   * hardware level: `s_waitcnt vmcnt(0)` retires the write-through stores at the memory side before the barrier releases the adding
+//     lane (MI355X_MICROARCH.md, inter-workgroup visibility: "16-B sc1 stores + asm vmcnt(0) + agent-scope atomic add; the workgroup
+//     whose add came last loads after a workgroup barrier that wave then joins").  The asm carries a "memory" clobber as well.
+// tests: test_conv_igemm_dma_variants asserts run-to-run bit identity of split launches (a lost partial would break it).
+#define SLAB_PUBLISH_FENCE()                                                                                          \
+  do {                                                                                                                \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                                                            \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                  \
+  } while (0)
+#define SLAB_CONSUME_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup")
+
 struct ConvArgs {
   const void* x; const __bf16* w; size_t w_part; void* y;   // w: [P][taps][N][Kpad], w_part = elements per part
   const float* pre; const float* post; const float* bias; const void* residual;
@@ -539,7 +561,7 @@ __global__ __launch_bounds__(512) void conv_igemm8_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         __hip_atomic_store(mine + (ni * 16 + r) * 512 + tid, acc[ni][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SLAB_PUBLISH_FENCE();
     __syncthreads();
     if (tid == 0) {
       const int old = __hip_atomic_fetch_add(a.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -548,6 +570,7 @@ __global__ __launch_bounds__(512) void conv_igemm8_kernel(ConvArgs a) {
       s_last = last;
     }
     __syncthreads();
+    SLAB_CONSUME_FENCE();
     if (!s_last) return;
     f32x16 tot[2];
 #pragma unroll
@@ -1327,7 +1350,7 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             __hip_atomic_store(mine + ((mi * 2 + ni) * 16 + r) * 512 + tid, acc[mi][ni][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      SLAB_PUBLISH_FENCE();
       __syncthreads();
       if (tid == 0) {
         const int old = __hip_atomic_fetch_add(a.cnt + tileid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1336,6 +1359,7 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
         *flag = last;
       }
       __syncthreads();
+      SLAB_CONSUME_FENCE();
       const int last = *flag;
       __syncthreads();                                           // (the epilogue reuses this LDS)
       if (!last) return;

@@ -167,6 +167,49 @@ def test_forward_vs_golden(f32_mode, res_):
         assert rel(D(img, False)[0], Fw["logit_fake"]) <= TOL
 
 
+# Stated bounds of the BENCHMARK dtype (bf16 feature maps, fp32 accumulation) against the reference's forward goldens, relative L2 over the
+# compared values: 2-3x the errors this test achieves (profiles/r04_parity_achieved.json).  bf16 rounds every feature map to 8
+# mantissa bits (2^-9 relative), ~30 roundings between the latents and a discriminator output.
+BF16_FWD_TOL = {"img": 2e-2, "img_trunc": 2e-2, "logit": 4e-2, "emb": 4e-2, "logit_fake": 6e-2}
+
+
+def rel_l2(a, b):
+    a = torch.as_tensor(np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a), dtype=torch.float64)
+    b = torch.as_tensor(np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b), dtype=torch.float64)
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("res_", [256, 512, 1024])
+def test_forward_vs_golden_bf16(res_):
+    """The same networks and goldens in the dtype bench.py measures (bf16): image slice, truncated image, logits and both embeddings of
+    the reference at 256 / 512 / 1024 (BASELINE configs 2 / 3 / 4; cnn.py:33-43, 89-115).  Errors are recorded, bounds stated above."""
+    from lcgan_amd import cnn, config, kernels
+    assert kernels.backend_name() == "hip"
+    Fw = np.load(os.path.join(GOLD, f"forward_r{res_}.npz"))
+    res, B, st = int(Fw["res"]), int(Fw["B"]), int(Fw["stride"])
+    args = make_args(res, B)
+    with config.feature_dtype_as(torch.bfloat16):
+        G, D = cnn.Generator(args).to(DEV), cnn.Discriminator(args).to(DEV)
+        G.load_state_dict({k: v.to(DEV) for k, v in seeded_state(O.g_param_shapes(res), 1001).items()})
+        D.load_state_dict({k: v.to(DEV) for k, v in seeded_state(O.d_param_shapes(res), 1002).items()})
+        z1, z2 = seeded_tensor((B, 64), 3000).to(DEV), seeded_tensor((B, 64), 3001).to(DEV)
+        with torch.no_grad():
+            img = G(z1, z2)
+            e = {"img": rel_l2(img[:, :, ::st, ::st], Fw["img/slice"]),
+                 "img_abssum": abs(float(img.double().abs().sum()) - float(Fw["img/abssum"])) / float(Fw["img/abssum"]),
+                 "img_trunc": rel_l2(G(z1, z2, 0.7)[:, :, ::st, ::st], Fw["img_trunc/slice"])}
+            assert rel(G.avg_latent1, Fw["avg_latent1"]) <= TOL and rel(G.avg_latent2, Fw["avg_latent2"]) <= TOL   # (mapping networks are fp32)
+            real = seeded_tensor((B, 3, res, res), 3002, "uniform_pm1").to(DEV)
+            logit, ge, ae = D(real, True)
+            e["logit"] = rel_l2(logit, Fw["logit"])
+            e["emb"] = max(rel_l2(ge, Fw["geo_emb"]), rel_l2(ae, Fw["app_emb"]))
+            e["logit_fake"] = rel_l2(D(img, False)[0], Fw["logit_fake"])
+    record(f"bf16_forward_r{res_}", **e)
+    for k, tol in BF16_FWD_TOL.items():
+        assert e[k] <= tol, (k, e[k], tol)
+    assert e["img_abssum"] <= 5e-3
+
+
 def test_adam_and_ema_kernels_vs_torch():
     from lcgan_amd.ema import Ema
     from lcgan_amd.optim import Adam
