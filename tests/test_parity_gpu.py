@@ -170,7 +170,7 @@ def test_forward_vs_golden(f32_mode, res_):
 # Stated bounds of the BENCHMARK dtype (bf16 feature maps, fp32 accumulation) against the reference's forward goldens, relative L2 over the
 # compared values: 2-3x the errors this test achieves (profiles/r04_parity_achieved.json).  bf16 rounds every feature map to 8
 # mantissa bits (2^-9 relative), ~30 roundings between the latents and a discriminator output.
-BF16_FWD_TOL = {"img": 2e-2, "img_trunc": 2e-2, "logit": 4e-2, "emb": 4e-2, "logit_fake": 6e-2}
+BF16_FWD_TOL = {"img": 1e-2, "img_trunc": 1e-2, "logit": 1.5e-2, "emb": 1.2e-2, "logit_fake": 2e-2}   # achieved: 4.1e-3 / 3.7e-3 / 5.6e-3 / 4.6e-3 / 8.2e-3 (worst of the three resolutions)
 
 
 def rel_l2(a, b):
