@@ -95,6 +95,9 @@ int lcgan_act_bwd_reduce(const void* gy, const void* y, void* gz, const float* b
                          float* gbias, float* gdq, int B, int HW, int C, int Clog, int act, float gain, int dtype, void* stream);
 /* style gradient: gs[b,c] += sum_p x*u ; u <- s[b,c]*u in place   (autograd of custom_layers.py:62-64) */
 int lcgan_scale_reduce(void* u, const void* x, const float* s, float* gs, int B, int HW, int C, int dtype, void* stream);
+/* ... with u <- s*u + res (res may be NULL): the data gradient another consumer of the same tensor already produced joins here
+ * (autograd's accumulation of custom_layers.py:145-153: a SynthesisBlock's input feeds skip_layer, flow_layer and modulated_conv0) */
+int lcgan_scale_reduce_res(void* u, const void* x, const float* s, float* gs, const void* res, int B, int HW, int C, int dtype, void* stream);
 /* bicubic feature warp: get_coordinates + grid_sample(bicubic, zeros, align_corners=False), custom_layers.py:127-134,162-165
  * flow [B,H,W,8] (ch 0 = x, ch 1 = y).  Backward = exact pixel-level CSR transpose (count, scan, fill) + gather, no float
  * atomics, any flow field; workspaces (contents irrelevant on entry), npix = B*H*W (16*npix < 2^31):

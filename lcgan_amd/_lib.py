@@ -31,6 +31,7 @@ SIGNATURES = {
     "lcgan_avgpool2_bwd": [P, P, I, I, I, I, I, P],
     "lcgan_act_bwd_reduce": [P, P, P, P, F, P, P, I, I, I, I, I, F, I, P],
     "lcgan_scale_reduce": [P, P, P, P, I, I, I, I, P],
+    "lcgan_scale_reduce_res": [P, P, P, P, P, I, I, I, I, P],
     "lcgan_warp_fwd": [P, P, P, I, I, I, I, F, I, P],
     "lcgan_warp_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, F, I, P],
     "lcgan_cast_from_f32": [P, P, LL, I, P],

@@ -32,6 +32,18 @@ def set_flow_gemm(on: bool) -> None:
     _flow_gemm = bool(on)
 
 
+_synth_fork = _os.environ.get("LCGAN_SYNTH_FORK", "1") != "0"   # A/B switch: a SynthesisBlock's three consumers of its input as one autograd node (ops.SynthForkFn)
+
+
+def synth_fork() -> bool:
+    return _synth_fork
+
+
+def set_synth_fork(on: bool) -> None:
+    global _synth_fork
+    _synth_fork = bool(on)
+
+
 def set_feature_dtype(dtype: torch.dtype) -> None:
     global _feature_dtype
     if dtype not in (torch.bfloat16, torch.float32):

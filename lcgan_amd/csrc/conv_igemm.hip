@@ -25,6 +25,7 @@
 #include <cstdio>
 
 extern "C" int lcgan_scale_reduce(void* u, const void* x, const float* sc, float* gs, int B, int HW, int C, int dtype, void* stream);
+extern "C" int lcgan_scale_reduce_res(void* u, const void* x, const float* sc, float* gs, const void* res, int B, int HW, int C, int dtype, void* stream);
 extern "C" int lcgan_avgpool2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
 
 namespace {
@@ -886,10 +887,16 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
     auto dma_stage = [&](int h, int buf) {
       char* S = smem + buf * S2_STAGE;
       const int cofs = __builtin_amdgcn_readfirstlane(h * 32);   // byte offset of the half-chunk's first channel
+#if defined(HALO_EXP) && (HALO_EXP == 4 || HALO_EXP == 5)
+      if (h == 0)
+#endif
 #pragma unroll
       for (int k = 0; k < 6; ++k)
         if (widu + 8 * k < HPIECES)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(S + (widu + 8 * k) * 1024), 16, hvo[k], cofs, 0, 0);
+#if defined(HALO_EXP) && (HALO_EXP == 3 || HALO_EXP == 5)
+      if (h == 0)
+#endif
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
         const int i = widu + 8 * k;
@@ -987,13 +994,15 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
       hch[k] = (dslot ^ (((pi % DMA_HP) >> 2) & 3)) * 8;
     }
     int h_c0 = 0;
-    auto dma_halo = [&](int c0, int buf) {
+    auto dma_halo_piece = [&](int c0, int buf, int k) {
       h_c0 = c0;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(Hb + buf * DMA_HBUF + (widu + 8 * k) * 1024), 16, hvo[k],
+                                               __builtin_amdgcn_readfirstlane(c0 * 2), 0, 0);
+    };
+    auto dma_halo = [&](int c0, int buf) {
 #pragma unroll
       for (int k = 0; k < 3; ++k)
-        if (hdo[k])
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(Hb + buf * DMA_HBUF + (widu + 8 * k) * 1024), 16, hvo[k],
-                                                   __builtin_amdgcn_readfirstlane(c0 * 2), 0, 0);
+        if (hdo[k]) dma_halo_piece(c0, buf, k);
     };
     auto scale_inplace = [&](int buf, bool wait) {
       if (wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces have landed (no wait needed one barrier after their issue)
@@ -1022,6 +1031,13 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
     // under the first tap's MFMAs (16 MFMAs per wave between barriers)
     constexpr int TP = DMA;
     const int ngroups = (ntaps + TP - 1) / TP, total = ngroups * nchunks;
+    // SPREAD (chunks of >= 4 steps: the 3 x 3 geometries): the step barrier no longer drains every DMA of the wave.  The halo image of the
+    // NEXT chunk comes from HBM (~2 us) while a step is ~1 us: issued whole in step 0 and waited for by that step's vmcnt(0), it stalled
+    // one barrier per chunk for an HBM round trip (builds that skip the halo fetch ran 16-25 % faster, -DHALO_EXP=4).  Now its pieces are
+    // issued BEHIND the step's weight tiles -- two in step 0, the third in step 1 -- and the barrier waits with a COUNTED vmcnt that
+    // leaves exactly those newest pieces in flight (vector memory returns in issue order): the weight tiles of the next step have
+    // landed, the halo pieces get one more step, and all of them are in LDS at the barrier of step 2 (MOD scales them in step 3).
+    const bool spread = ngroups >= 4 && !(a.dbg & 16);                // (option 3, bit 16: the round-3 schedule, for A/B runs)
     auto dma_b = [&](int cc, int g, int buf) {
 #pragma unroll
       for (int j = 0; j < TP; ++j) {
@@ -1100,15 +1116,61 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
         for (int ni = 0; ni < 4; ++ni)
           acc16[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af16[mi], bf16[ni], acc16[mi][ni], 0, 0, 0);
     };
+#ifdef HALO_STAMPS
+    unsigned long long dsA = 0, dsB = 0, dsC = 0, dsD = 0, dst0 = 0, dst1 = 0, dst2 = 0, dst3 = 0, dst4 = 0;
+#endif
     auto step = [&](int q, auto bufc) {
       constexpr int buf = decltype(bufc)::value;
+#ifdef HALO_STAMPS
+      STAMP(dst0)
+#endif
       if constexpr (MOD) {
         // the next chunk's halo was issued in step g == 0 and that step's barrier waited for it: it is scaled at the top of step 1,
         // under this step's MFMAs, not in the chunk's last step where every wave would do it right in front of the barrier
-        if (ngroups > 1 && g == 1 && c + 1 < nchunks) scale_inplace((c + 1) & 1, false);
+        // (spread issue: the last piece has landed at the barrier of step 2 -> scaled at the top of step 3)
+        if (ngroups > 1 && g == (spread ? 3 : 1) && c + 1 < nchunks) scale_inplace((c + 1) & 1, false);
       }
+      // HALO_EXP 3 / 4 / 5 (timing experiments, wrong results): the weight tiles / the halo images / both are not fetched after the
+      // first stage -- how much of a step is the L2 -> LDS fill stream
+#if defined(HALO_EXP) && (HALO_EXP == 3 || HALO_EXP == 5)
+      if (q + 1 < total) advance();
+#else
       if (q + 1 < total) { dma_b(lc, lg, buf ^ 1); advance(); }
-      if (g == 0 && c + 1 < nchunks) dma_halo((c + 1) * BK, (c + 1) & 1);
+#endif
+      int pend = 0;                                              // halo pieces issued in this step (wave-uniform)
+#if !(defined(HALO_EXP) && (HALO_EXP == 4 || HALO_EXP == 5))
+      if (spread) {
+        if (c + 1 < nchunks) {
+          if (g == 0) {
+            if (hdo[0]) { dma_halo_piece((c + 1) * BK, (c + 1) & 1, 0); ++pend; }
+            if (hdo[1]) { dma_halo_piece((c + 1) * BK, (c + 1) & 1, 1); ++pend; }
+          } else if (g == 1 && hdo[2]) { dma_halo_piece((c + 1) * BK, (c + 1) & 1, 2); ++pend; }
+        }
+      } else if (g == 0 && c + 1 < nchunks) dma_halo((c + 1) * BK, (c + 1) & 1);
+#endif
+      auto step_barrier = [&]() {
+#ifdef HALO_STAMPS
+        STAMP(dst2)
+        if (spread && pend == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (spread && pend == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(dst3)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        STAMP(dst4)
+        dsA += dst1 - dst0; dsB += dst2 - dst1; dsC += dst3 - dst2; dsD += dst4 - dst3;
+#else
+        if (spread) {
+          if (pend == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          else if (pend == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        } else {
+          __syncthreads();                                       // (waits for this step's DMA: vmcnt(0), then the barrier)
+        }
+#endif
+      };
       const int t0 = g * TP;
       if constexpr (M16) {
         readsA16(t0, 0); readsA16(t0, 1); readsB16(buf * TP * DMA_BBUF);
@@ -1127,12 +1189,15 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
         if constexpr (MOD) {
           if (ngroups == 1 && c + 1 < nchunks) scale_inplace((c + 1) & 1, true);
         }
-        __syncthreads();
+        step_barrier();
         if (++g == ngroups) { g = 0; ++c; }
         return;
       }
       frag_reads(t0, buf * TP * DMA_BBUF, 0);
       frag_reads(t0, buf * TP * DMA_BBUF, 1);
+#ifdef HALO_STAMPS
+      STAMP(dst1)
+#endif
 #pragma unroll
       for (int j = 1; j < TP; ++j)
         if (t0 + j < ntaps) {
@@ -1149,13 +1214,19 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
       if constexpr (MOD) {
         if (ngroups == 1 && c + 1 < nchunks) scale_inplace((c + 1) & 1, true);
       }
-      __syncthreads();                                           // (waits for this step's DMA: vmcnt(0), then the barrier)
+      step_barrier();
       if (++g == ngroups) { g = 0; ++c; }
     };
     for (int q = 0; q < total; q += 2) {
       step(q, std::integral_constant<int, 0>{});
       if (q + 1 < total) step(q + 1, std::integral_constant<int, 1>{});
     }
+#ifdef HALO_STAMPS
+    if (!M16 && lane == 0 && blockIdx.x < 2048 && blockIdx.z == 0 && blockIdx.y == 0) {
+      unsigned long long* o = g_halo_stamps + ((size_t)blockIdx.x * 8 + wid) * 5;
+      o[0] = dsA; o[1] = dsB; o[2] = dsC; o[3] = dsD; o[4] = total;
+    }
+#endif
   } else if constexpr (PAIR) {
     // ---- weight tiles of TWO taps per step (one barrier per tap pair): 2 x 128 rows x 4 vectors, two items per thread ----
     const int ngroups = (ntaps + 1) >> 1, total = ngroups * nchunks;
@@ -1517,6 +1588,34 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
   }
   __syncthreads();
   if (SR && tid < BN && n0 + tid < a.Cout) atomicAdd(a.gs + (size_t)b * a.Cout + n0 + tid, colbuf[tid]);
+  if (SR && a.residual) {
+    // style-gradient epilogue + a full-resolution residual: the gradient another consumer of the same tensor has already produced
+    // (ops.SynthForkFn chains the data gradients of a generator block's three consumers) is added as the finished tile goes out --
+    // bf16(bf16(s * u) + r), the value the separate `add_` pass it replaces would have stored
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)a.residual, 0, (int)(2u * (unsigned)(a.B * a.Hout * a.Wout * a.Cout)), 0x00020000);
+    bf16x8 rr[8];
+    unsigned ro[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int idx = tid + k * 512;
+      const int row = idx >> 4, vv = idx & 15;
+      const int py = ty * HT + (row >> 4), px = tx * HT + (row & 15);
+      const int n = n0 + vv * 8;
+      const int oy = py * a.out_mul + (phase >> 1), ox = px * a.out_mul + (phase & 1);
+      ro[k] = (py < a.Hm && px < a.Wm && n < a.Cout) ? 2u * (unsigned)(((b * a.Hout + oy) * a.Wout + ox) * a.Cout + n) : 0xffffffffu;
+      rr[k] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rres, ro[k], 0, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int idx = tid + k * 512;
+      if (ro[k] == 0xffffffffu) continue;
+      const bf16x8 t = *(const bf16x8*)(ot + (idx >> 4) * OROW + (idx & 15) * 8);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (__bf16)((float)t[j] + (float)rr[k][j]);
+      *(bf16x8*)((char*)a.y + ro[k]) = o;
+    }
+  } else {
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int idx = tid + k * 512;                                 // 256 rows x 16 vectors
@@ -1526,6 +1625,7 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
     if (py >= a.Hm || px >= a.Wm || n >= a.Cout) continue;
     const int oy = py * a.out_mul + (phase >> 1), ox = px * a.out_mul + (phase & 1);
     *(bf16x8*)(a.y + ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n) = *(const bf16x8*)(ot + row * OROW + vv * 8);
+  }
   }
   if constexpr (EPI == 1) {
     // by-product of a DiscriminatorBlock's closing 1x1 convolution (custom_layers.py:203,209): avg_pool2d(out, 2), which the NEXT
@@ -1755,7 +1855,14 @@ __global__ __launch_bounds__(512, RW == 2 ? 4 : 2) void conv_halo_narrow_kernel(
     const int n = n0 + vv * 8;
     if (py >= a.Hm || px >= a.Wm || n >= a.Cout) continue;
     const int oy = py * a.out_mul + (phase >> 1), ox = px * a.out_mul + (phase & 1);
-    *(bf16x8*)(a.y + ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n) = *(const bf16x8*)(ot + row * OROW + vv * 8);
+    const size_t off = ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n;
+    bf16x8 o = *(const bf16x8*)(ot + row * OROW + vv * 8);
+    if (SR && a.residual) {                                        // (see conv_halo_kernel: residual of the style-gradient epilogue)
+      const bf16x8 rr = *(const bf16x8*)(a.residual + off);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (__bf16)((float)o[j] + (float)rr[j]);
+    }
+    *(bf16x8*)(a.y + off) = o;
   }
 }
 
@@ -3042,12 +3149,12 @@ int dispatch_igemm(const ConvArgs& a_in, int nphase, int dtype, hipStream_t s) {
     }
   }
   // generic path: the fused style-gradient reduction (xs, gs) runs as its own pass over the unscaled output
-  const void* xs = a.xs; float* gs = a.gs; const float* sr_scale = a.post;
-  if (xs) { a.post = nullptr; a.xs = nullptr; a.gs = nullptr; }
+  const void* xs = a.xs; float* gs = a.gs; const float* sr_scale = a.post; const void* sr_res = a.residual;
+  if (xs) { a.post = nullptr; a.xs = nullptr; a.gs = nullptr; a.residual = nullptr; }      // (a residual of the style-gradient form joins AFTER the scale)
   int rc = LCGAN_EINVAL;
   if (dtype == DT_BF16) rc = launch_igemm<__bf16, 1>(a, nphase, s);
   else if (dtype == DT_F32) rc = launch_igemm<float, 3>(a, nphase, s);
-  if (xs && rc == LCGAN_OK) rc = lcgan_scale_reduce(a.y, xs, sr_scale, gs, a.B, a.Hout * a.Wout, a.Cout, dtype, s);
+  if (xs && rc == LCGAN_OK) rc = lcgan_scale_reduce_res(a.y, xs, sr_scale, gs, sr_res, a.B, a.Hout * a.Wout, a.Cout, dtype, s);
   return rc;
 }
 
@@ -3145,7 +3252,7 @@ int lcgan_conv_fwd(const void* x, const void* wp, void* y,
                    int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || (Cin & 7) || (Cout & 7) || N > Cout) return LCGAN_EINVAL;
-  if (xs && (!gs || !post || residual || bias || act != ACT_NONE || gain != 1.f)) return LCGAN_EINVAL;
+  if (xs && (!gs || !post || (residual && residual_half) || bias || act != ACT_NONE || gain != 1.f)) return LCGAN_EINVAL;
   ConvArgs a = {};
   a.xs = xs; a.gs = xs ? gs : nullptr;
   a.pool_out = pool_out;
@@ -3190,7 +3297,7 @@ int lcgan_conv_bwd_data(const void* g, const void* wpT, void* gx,
   hipStream_t s = (hipStream_t)stream;
   if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || (Cg & 7) || (Cout & 7) || N > Cout) return LCGAN_EINVAL;
   if (stride == 2 && k != 3) return LCGAN_EINVAL;
-  if (xs && (!gs || !post || residual || bias || act != ACT_NONE || gain != 1.f)) return LCGAN_EINVAL;
+  if (xs && (!gs || !post || (residual && residual_half) || bias || act != ACT_NONE || gain != 1.f)) return LCGAN_EINVAL;
   ConvArgs a = {};
   a.xs = xs; a.gs = xs ? gs : nullptr;
   a.x = g; a.w = (const __bf16*)wpT; a.y = gx;

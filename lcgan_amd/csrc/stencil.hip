@@ -400,7 +400,7 @@ __global__ void act_bwd_reduce_kernel(const T* __restrict__ gy, const T* __restr
 // ------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void scale_reduce_kernel(T* __restrict__ u, const T* __restrict__ x, const float* __restrict__ s,
-                                    float* __restrict__ gs, int HW, int C, int P) {
+                                    float* __restrict__ gs, const T* __restrict__ res, int HW, int C, int P) {
   __shared__ float red[TPB * 8];
   const int nvec = C >> 3;
   const int groups = TPB / nvec;
@@ -420,6 +420,11 @@ __global__ void scale_reduce_kernel(T* __restrict__ u, const T* __restrict__ x, 
       const F8 xx = Feat<T>::load(x + off);
 #pragma unroll
       for (int j = 0; j < 8; ++j) { acc[j] += uu.v[j] * xx.v[j]; uu.v[j] *= sv[j]; }
+      if (res) {                                                   // u <- s * u + res (the gradient of another consumer of the same tensor)
+        const F8 rr = Feat<T>::load(res + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) uu.v[j] = Feat<T>::rnd(uu.v[j]) + rr.v[j];
+      }
       Feat<T>::store(u + off, uu);
     }
   }
@@ -1507,15 +1512,18 @@ int lcgan_act_bwd_reduce(const void* gy, const void* y, void* gz, const float* b
   return launch_status();
 }
 
-// u <- s * u in place; gs[b][c] += sum_p x * u(old)
-int lcgan_scale_reduce(void* u, const void* x, const float* sc, float* gs, int B, int HW, int C, int dtype, void* stream) {
+// u <- s * u (+ res) in place; gs[b][c] += sum_p x * u(old)
+int lcgan_scale_reduce_res(void* u, const void* x, const float* sc, float* gs, const void* res, int B, int HW, int C, int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if ((C & 7) || C / 8 > TPB) return LCGAN_EINVAL;
   const int P = reduce_P(HW, B);
   dim3 grid(cdiv(HW, P), B);
-  ProfScope p(KID_SCALE_REDUCE, 0, (double)B * HW * C * 3 * (dtype == DT_BF16 ? 2 : 4), s);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(scale_reduce_kernel<T>, grid, dim3(TPB), 0, s, (T*)u, (const T*)x, sc, gs, HW, C, P));
+  ProfScope p(KID_SCALE_REDUCE, 0, (double)B * HW * C * (res ? 4 : 3) * (dtype == DT_BF16 ? 2 : 4), s);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(scale_reduce_kernel<T>, grid, dim3(TPB), 0, s, (T*)u, (const T*)x, sc, gs, (const T*)res, HW, C, P));
   return launch_status();
+}
+int lcgan_scale_reduce(void* u, const void* x, const float* sc, float* gs, int B, int HW, int C, int dtype, void* stream) {
+  return lcgan_scale_reduce_res(u, x, sc, gs, nullptr, B, HW, C, dtype, stream);
 }
 
 // flow: [B,H,W,8] (channel 0 = x, 1 = y displacement in normalised units before * scale)

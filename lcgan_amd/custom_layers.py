@@ -176,13 +176,27 @@ class SynthesisBlock(nn.Module):
     def forward(self, x, g_latent, a_latent, styles=(None, None, None)):
         (g_lat,) = _split_latents(g_latent, 1)
         a0, a1 = _split_latents(a_latent, 2)
-        # flow field: up-conv (2 channels, padded to 8) -> box filter -> tanh                 :149-151
-        flow = ops.Box3ActFn.apply(self.flow_layer(x, g_lat, style=styles[0]), ACT_TANH, 1.0)
-        # main branch: up-conv -> box filter -> lrelu*sqrt2 -> conv -> lrelu                    :153-158
-        h = ops.Box3ActFn.apply(self.modulated_conv0(x, a0, style=styles[1]), ACT_LRELU, SQRT2)
-        h = self.modulated_conv1(h, a1, ACT_LRELU, 1.0, style=styles[2])
-        # skip branch: 1x1 conv * sqrt(.5) at low res, then nearest x2 + box filter fused with the add     :145-147,159
-        skip = self.skip_layer(x, ACT_NONE, SQRT_HALF)
+        fl, c0, sk = self.flow_layer, self.modulated_conv0, self.skip_layer
+        if (config.synth_fork() and config.flow_gemm() and config.conv_operands() == "bf16" and fl.modulated_conv.out_features == 2
+                and sk.no_bias and sk.kernel_size == 1 and c0.modulated_conv.kernel_size == 3):
+            # the three consumers of x as ONE autograd node: their data gradients chain through the convolution epilogues instead of
+            # being summed by two add passes of autograd's (ops.SynthForkFn)
+            sf = fl.linear(g_lat) if styles[0] is None else styles[0]
+            s0 = c0.linear(a0) if styles[1] is None else styles[1]
+            u, y0, skip = ops.SynthForkFn.apply(x, fl.modulated_conv.weight.weight, fl.modulated_conv.bias, sf,
+                                                c0.modulated_conv.weight.weight, c0.modulated_conv.bias, s0,
+                                                sk.weight.weight, sk.weight.c * SQRT_HALF)
+            flow = ops.Box3ActFn.apply(u, ACT_TANH, 1.0)                             # :150-151
+            h = ops.Box3ActFn.apply(y0, ACT_LRELU, SQRT2)                            # :154-155
+        else:
+            # flow field: up-conv (2 channels, padded to 8) -> box filter -> tanh                 :149-151
+            flow = ops.Box3ActFn.apply(fl(x, g_lat, style=styles[0]), ACT_TANH, 1.0)
+            # main branch: up-conv -> box filter -> lrelu*sqrt2                                      :153-155
+            h = ops.Box3ActFn.apply(c0(x, a0, style=styles[1]), ACT_LRELU, SQRT2)
+            # skip branch: 1x1 conv * sqrt(.5) at low res                                            :145
+            skip = sk(x, ACT_NONE, SQRT_HALF)
+        h = self.modulated_conv1(h, a1, ACT_LRELU, 1.0, style=styles[2])           # conv -> lrelu  :157-158
+        # nearest x2 + box filter of the skip branch fused with the add                              :146-147,159
         y = ops.Up2BoxAddFn.apply(skip, h)
         # bicubic feature warp                                                                   :162-165
         return ops.WarpFn.apply(y, flow, float(self.max_flow_scale))

@@ -182,7 +182,7 @@ class HipKernels:
     def conv_fwd(self, x: Tensor, pw: PreparedWeight, N: int, k: int, stride: int, pre=None, post=None, bias=None,
                  bias_scale: float = 1.0, act: int = ACT_NONE, gain: float = 1.0, residual=None, residual_half: bool = False,
                  xs: Optional[Tensor] = None, pool: bool = False):
-        """xs given (needs post, no bias/act/residual): returns (y = post * u, gs[b,n] = sum_pixels xs * u), u = the unscaled result;
+        """xs given (needs post, no bias/act): returns (y = post * u [+ residual], gs[b,n] = sum_pixels xs * u), u = the unscaled result;
         pool: returns (y, avg_pool2d(y, 2)) -- the by-product a DiscriminatorBlock's closing convolution leaves for the next block"""
         self._chk(x, pre, post, bias, residual, xs)
         B, H, W, Cin = x.shape

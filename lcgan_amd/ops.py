@@ -832,30 +832,35 @@ class ModConvFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        K = _K()
         x, w, bias, s, d, wsq, y = ctx.saved_tensors
         up, act, gain, c_eq = ctx.cfg
-        O = w.shape[0]
-        gy = gy.contiguous()
-        # activation backward + bias gradient + demod statistic  gdq[b,o] = sum_p gz * (ypre - bias)
-        gz, gb, gdq = K.act_bwd_reduce(gy, y, act, gain, O, want_gz=(act != ACT_NONE), bias=bias, bias_scale=1.0,
-                                       want_gbias=True, want_gdq=True)
-        if gz is None:
-            gz = gy
-        gx, gw, gs = _modconv_bwd_tail(x, w, s, d, wsq, gz, gdq, up, c_eq)
+        gx, gw, gb, gs = _modconv_backward(x, w, bias, s, d, wsq, y, up, act, gain, c_eq, gy)
         return gx, gw, gb, gs, None, None, None
 
 
-def _modconv_bwd_tail(x, w, s, d, wsq, gz, gdq, up, c_eq):
-    """from the pre-activation gradient gz of a modulated convolution to (gx, gw, gs)"""
+def _modconv_backward(x, w, bias, s, d, wsq, y, up, act, gain, c_eq, gy, residual=None):
+    """backward of ModConvFn: (gx [+ residual], gw, gbias, gs)"""
+    # activation backward + bias gradient + demod statistic  gdq[b,o] = sum_p gz * (ypre - bias)
+    gy = gy.contiguous()
+    gz, gb, gdq = _K().act_bwd_reduce(gy, y, act, gain, w.shape[0], want_gz=(act != ACT_NONE), bias=bias, bias_scale=1.0,
+                                      want_gbias=True, want_gdq=True)
+    if gz is None:
+        gz = gy
+    gx, gw, gs = _modconv_bwd_tail(x, w, s, d, wsq, gz, gdq, up, c_eq, residual)
+    return gx, gw, gb, gs
+
+
+def _modconv_bwd_tail(x, w, s, d, wsq, gz, gdq, up, c_eq, residual=None):
+    """from the pre-activation gradient gz of a modulated convolution to (gx [+ residual], gw, gs); residual: the gradient another
+    consumer of x already produced -- it joins in the data-gradient launch's epilogue instead of an add pass of autograd's"""
     K = _K()
     O, Cin, k, _ = w.shape
     pwT, _ = _prep(w, c_eq, True, _need_lo(x))                               # [t][Cin][O]
     # data gradient u = conv^T(d * gz); gx = s * u and gs = sum_p x * u leave the same launch (epilogue of the conv kernel)
     if up == 2:
-        gx, gs = K.conv_fwd(gz, pwT, Cin, k, 2, pre=d, post=s, xs=x)         # adjoint of the transposed conv
+        gx, gs = K.conv_fwd(gz, pwT, Cin, k, 2, pre=d, post=s, xs=x, residual=residual)         # adjoint of the transposed conv
     else:
-        gx, gs = K.conv_bwd_data(gz, pwT, Cin, k, 1, pre=d, post=s, xs=x)
+        gx, gs = K.conv_bwd_data(gz, pwT, Cin, k, 1, pre=d, post=s, xs=x, residual=residual)
     gwsq = K.demod_bwd(gdq, d, s, wsq, gs)                                   # gs += demod path
     if up == 2:
         gw = K.conv_wgrad_unprep(gz, x, Cin, O, k, 2, c_eq, transposed=True, pre_x=d, pre_g=s, w=w, gwsq=gwsq)    # gwp [t][Cin][O]
@@ -950,19 +955,78 @@ class FlowConvFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gu):
-        K = _K()
         x, w, bias, s, d, wsq, u = ctx.saved_tensors
-        c_eq = ctx.c_eq
-        Cin = w.shape[1]
-        gu = gu.contiguous()
-        _, gb, gdq = K.act_bwd_reduce(gu, u, ACT_NONE, 1.0, 2, want_gz=False, bias=bias, bias_scale=1.0, want_gbias=True, want_gdq=True)
-        _, pw18T, _ = _flow_prep(w, c_eq, _need_lo(x))
-        gt = K.flow_im2col(gu, d)                                                # [B,H,W,24], demodulation folded in
-        gx, gs = K.conv_bwd_data(gt, pw18T, Cin, 1, 1, post=s, xs=x)             # gx = s * (gt @ W18), gs = sum_p x * (gt @ W18)
-        gwsq = K.demod_bwd(gdq, d, s, wsq, gs)                                   # gs += demod path
-        gw18 = K.conv_wgrad(x, gt, 18, Cin, 1, 1, pre_x=s)                       # [1][18][Cin], row (ky*3+kx)*2+o == the prepared layout [9][2][Cin]
-        gw = K.unprep_wgrad(gw18.view(9, 2, Cin), 2, Cin, 3, c_eq, False, w=w.detach(), gwsq=gwsq)      # + the demodulation term, one launch
-        return gx, gw, gb, gs
+        return _flow_backward(x, w, bias, s, d, wsq, u, ctx.c_eq, gu)
+
+
+def _flow_backward(x, w, bias, s, d, wsq, u, c_eq, gu, residual=None):
+    """backward of FlowConvFn: (gx [+ residual], gw, gbias, gs)"""
+    K = _K()
+    Cin = w.shape[1]
+    gu = gu.contiguous()
+    _, gb, gdq = K.act_bwd_reduce(gu, u, ACT_NONE, 1.0, 2, want_gz=False, bias=bias, bias_scale=1.0, want_gbias=True, want_gdq=True)
+    _, pw18T, _ = _flow_prep(w, c_eq, _need_lo(x))
+    gt = K.flow_im2col(gu, d)                                                # [B,H,W,24], demodulation folded in
+    gx, gs = K.conv_bwd_data(gt, pw18T, Cin, 1, 1, post=s, xs=x, residual=residual)   # gx = s * (gt @ W18) [+ residual], gs = sum_p x * (gt @ W18)
+    gwsq = K.demod_bwd(gdq, d, s, wsq, gs)                                   # gs += demod path
+    gw18 = K.conv_wgrad(x, gt, 18, Cin, 1, 1, pre_x=s)                       # [1][18][Cin], row (ky*3+kx)*2+o == the prepared layout [9][2][Cin]
+    gw = K.unprep_wgrad(gw18.view(9, 2, Cin), 2, Cin, 3, c_eq, False, w=w.detach(), gwsq=gwsq)      # + the demodulation term, one launch
+    return gx, gw, gb, gs
+
+
+class SynthForkFn(Function):
+    """The three consumers of a SynthesisBlock's input x as ONE autograd node (custom_layers.py:145-153):
+         skip = conv1x1(x, Wk * wscale)                      skip_layer (the sqrt(.5) gain folded into wscale)   :145
+         u    = FlowConvFn(x, Wf, bf, sf)                    flow_layer: ModulatedConv2d(C -> 2, k 3, up 2)      :149
+         y0   = ModConvFn(x, W0, b0, s0, up 2, no act)       modulated_conv0                                     :153
+    As three nodes autograd sums their three data gradients with two full-size add passes per block and backward pass
+    (0.66 ms per iteration at 256 x 256, batch 32).  Owning the fork, the backward CHAINS them: the 1x1 data gradient first, then
+    the flow layer's and the up-convolution's data-gradient launches each take the running sum as the residual of their epilogue
+    (lcgan_conv_fwd / lcgan_conv_bwd_data with xs AND residual) -- the same bf16 values the add passes produced, no extra pass.
+    First order only (the R1 double backward never reaches the generator)."""
+
+    @staticmethod
+    def forward(ctx, x, wf, bf, sf, w0, b0, s0, wk, wscale):
+        K = _K()
+        lo = _need_lo(x)
+        Cin = x.shape[-1]
+        # flow layer (FlowConvFn.forward)
+        cf = 1.0 / math.sqrt(wf.shape[1] * 9)
+        sf = sf.contiguous()
+        pw18, _, wsqf = _flow_prep(wf, cf, lo)
+        df = _demod(K, wf, sf, wsqf, 8)
+        u = K.flow_col2im(K.conv_fwd(x, pw18, 18, 1, 1, pre=sf), df, bf)
+        # up-convolution (ModConvFn.forward, up = 2, no activation)
+        O = w0.shape[0]
+        c0 = 1.0 / math.sqrt(w0.shape[1] * 9)
+        s0 = s0.contiguous()
+        pw0, wsq0 = _prep(w0, c0, False, lo, want_wsq=True)
+        d0 = _demod(K, w0, s0, wsq0, ceil8(O))
+        y0 = K.conv_bwd_data(x, pw0, O, 3, 2, pre=s0, post=d0, bias=b0, bias_scale=1.0, act=ACT_NONE, gain=1.0)
+        # skip branch (Conv2dFn.forward, k = 1, no bias, no activation)
+        pwk, _ = _prep(wk, wscale, False, lo)
+        skip = K.conv_fwd(x, pwk, wk.shape[0], 1, 1)
+        ctx.save_for_backward(x, wf, bf, sf, df, wsqf, u, w0, b0, s0, d0, wsq0, y0, wk)
+        ctx.cfg = (cf, c0, wscale)
+        return u, y0, skip
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gu, gy0, gskip):
+        K = _K()
+        x, wf, bf, sf, df, wsqf, u, w0, b0, s0, d0, wsq0, y0, wk = ctx.saved_tensors
+        cf, c0, wscale = ctx.cfg
+        gx = gwk = gwf = gbf = gsf = gw0 = gb0 = gs0 = None
+        if gskip is not None:
+            gskip = gskip.contiguous()
+            pwkT, _ = _prep(wk, wscale, True, _need_lo(x))
+            gx = K.conv_bwd_data(gskip, pwkT, wk.shape[1], 1, 1)
+            gwk = K.conv_wgrad_unprep(x, gskip, wk.shape[0], wk.shape[1], 1, 1, wscale)
+        if gu is not None:
+            gx, gwf, gbf, gsf = _flow_backward(x, wf, bf, sf, df, wsqf, u, cf, gu, residual=gx)
+        if gy0 is not None:
+            gx, gw0, gb0, gs0 = _modconv_backward(x, w0, b0, s0, d0, wsq0, y0, 2, ACT_NONE, 1.0, c0, gy0, residual=gx)
+        return gx, gwf, gbf, gsf, gw0, gb0, gs0, gwk, None
 
 
 class Box3ActFn(Function):

@@ -132,10 +132,13 @@ class EmulatedKernels:
             return residual
         return nhwc(F.interpolate(nchw(residual), scale_factor=2, mode="nearest") * 0.25, torch.float32)
 
-    def _sr(self, u, post, xs, dtype):
-        """fused style-gradient reduction: (post * u, sum_pixels xs * u) from the UNSCALED fp32 result u (NHWC f32)"""
+    def _sr(self, u, post, xs, dtype, residual=None):
+        """fused style-gradient reduction: (post * u [+ residual], sum_pixels xs * u) from the UNSCALED fp32 result u (NHWC f32)"""
         gs = (u * xs.float()).sum(dim=(1, 2))
-        return (u * post[:, None, None, :u.shape[-1]]).to(dtype), gs
+        y = (u * post[:, None, None, :u.shape[-1]]).to(dtype)
+        if residual is not None:                              # joins the stored (rounded) value, like the add_ pass it replaces
+            y = (y.float() + residual.float()).to(dtype)
+        return y, gs
 
     def conv_fwd(self, x, pw, N, k, stride, pre=None, post=None, bias=None, bias_scale=1.0, act=ACT_NONE, gain=1.0, residual=None,
                  residual_half=False, xs=None, pool=False):
@@ -149,7 +152,7 @@ class EmulatedKernels:
             xin = rb(xin * pre[:, :Kc, None, None], x.dtype)
         v = F.conv2d(xin, pw.P4, stride=stride, padding=k // 2)
         if xs is not None:
-            return self._sr(nhwc(v, torch.float32, ceil8(N)), post, xs, x.dtype)
+            return self._sr(nhwc(v, torch.float32, ceil8(N)), post, xs, x.dtype, residual)
         return self._epilogue(v, N, post, bias, bias_scale, act, gain, residual, x.dtype)
 
     def conv_bwd_data(self, g, pw, N, k, stride, pre=None, post=None, bias=None, bias_scale=1.0, act=ACT_NONE, gain=1.0, residual=None,
@@ -161,7 +164,7 @@ class EmulatedKernels:
             gs = rb(gs * pre[:, :Kc, None, None], g.dtype)
         v = F.conv_transpose2d(gs, pw.P4.permute(1, 0, 2, 3), stride=stride, padding=k // 2, output_padding=stride - 1)
         if xs is not None:
-            return self._sr(nhwc(v, torch.float32, ceil8(N)), post, xs, g.dtype)
+            return self._sr(nhwc(v, torch.float32, ceil8(N)), post, xs, g.dtype, residual)
         return self._epilogue(v, N, post, bias, bias_scale, act, gain, residual, g.dtype)
 
     # ---- MX-fp8 convolution path (csrc/conv_fp8.hip): the same quantisation rule, then exact fp32 products --------------------

@@ -6,6 +6,8 @@ import numpy as np, torch
 from scripts.ab_conv import kernels_for
 K = kernels_for(sys.argv[1])
 K.lib.lcgan_halo_stamps.argtypes = [C.c_void_p]
+for kv in filter(None, (sys.argv[2] if len(sys.argv) > 2 else "").split(",")):     # e.g. "3=16": lcgan_set_option pairs
+    K.lib.lcgan_set_option(*map(int, kv.split("=")))
 B = 32
 for (Hh, Ci, Co, st) in [(256, 128, 128, 1), (128, 256, 256, 1), (64, 512, 512, 1)]:
     x = torch.randn(B, Hh, Hh, Ci, device="cuda").bfloat16()
@@ -18,10 +20,10 @@ for (Hh, Ci, Co, st) in [(256, 128, 128, 1), (128, 256, 256, 1), (64, 512, 512, 
     assert K.lib.lcgan_halo_stamps(buf) == 0
     a = np.array(buf[:], dtype=np.float64).reshape(2048, 8, 5)
     steps = a[0, 0, 4]
-    ntiles = B * ((Hh // st + 15) // 16) ** 2
+    ntiles = B * ((Hh // st + 15) // 16) ** 2 * ((Co + 127) // 128)       # (the 1-D grid holds tiles x channel blocks)
     a = a[:min(ntiles, 2048)]                                  # (rows beyond this launch's grid hold an earlier launch)
     per = a[:, :, :4] / steps                                  # cycles per step and segment, per (workgroup, wave)
     med = np.median(per.reshape(-1, 4), axis=0)
     early, late = np.median(per[:, :4].reshape(-1, 4), axis=0), np.median(per[:, 4:].reshape(-1, 4), axis=0)
-    print(f"{Hh}^2 {Ci}->{Co}: steps {steps:.0f}; cycles/step  reads-landed {med[0]:.0f}  mfma-issue {med[1]:.0f}  store->barrier {med[2]:.0f}  barrier-wait {med[3]:.0f}  total {med.sum():.0f}")
+    print(f"{Hh}^2 {Ci}->{Co}: steps {steps:.0f}; cycles/step  [DMA issue + first fragments landed] {med[0]:.0f}  [MFMA issue + interleaved reads] {med[1]:.0f}  [vmcnt wait] {med[2]:.0f}  [barrier wait] {med[3]:.0f}  total {med.sum():.0f}")
     print(f"      waves 0-3: {early.round()}   waves 4-7: {late.round()}")

@@ -228,6 +228,8 @@ def test_conv_per_sample_weights(H, case):
                 y = fn_h(x.cuda(), pw_h, Co, k, st, pre=pre.cuda(), post=post.cuda())
                 yr = fn_h(x.cuda(), pw_h, Co, k, st, pre=pre.cuda(), post=post.cuda(), residual=xs.cuda()) if kind != "up" else None
                 yg, gs = fn_h(x.cuda(), pw_h, Co, k, st, pre=pre.cuda(), post=post.cuda(), xs=xs.cuda())
+                ygr, _ = fn_h(x.cuda(), pw_h, Co, k, st, pre=pre.cuda(), post=post.cuda(), xs=xs.cuda(), residual=xs.cuda())
+                assert torch.equal(ygr, (yg.float() + xs.cuda().float()).to(dtype)), f"option 18 = {mb}: fused y + residual != add pass"
                 outs[mb] = (y, yr, yg, gs)
             finally:
                 H.lib.lcgan_set_option(18, old18)
@@ -241,6 +243,18 @@ def test_conv_per_sample_weights(H, case):
         check(yg, yg_e, dtype, f"option 18 = {mb}: fused y", l2_scale=2.0)
         check(gs, gs_e, dtype, f"option 18 = {mb}: fused gs", l2_scale=3.0)
     check(outs[80][0], outs[0][0].cpu(), dtype, "per-sample weights vs in-LDS scaling", l2_scale=2.0)
+
+
+def _same_as_add_pass(y_r, y_plain, r, dtype, what):
+    """the residual of the style-gradient epilogue must give what a separate add pass over the stored result gives: bit for bit where
+    the launch is deterministic (halo kernels, slab split-K); launches that meet their split-K partials through float atomics differ from
+    run to run in the last bit of u, i.e. by one rounding step of the stored value"""
+    want = (y_plain.float() + r.float()).to(dtype)
+    if torch.equal(y_r, want):
+        return
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -22
+    err = float((y_r.float() - want.float()).abs().max()) / float(want.float().abs().max())
+    assert err <= ulp, f"{what}: differs from the add pass by {err:.2e} (> one rounding step {ulp:.1e})"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -270,6 +284,12 @@ def test_conv_fwd(H, dtype, case):
     y_e, gs_e = E.conv_fwd(x, pw_e, Co, k, stride, pre=pre, post=post, xs=res)
     check(y_h, y_e, dtype, "fused y", l2_scale=2.0)        # generic path: u is rounded to bf16 BEFORE the style scale (two roundings)
     check(gs_h, gs_e, dtype, "fused gs", l2_scale=3.0)     # generic path reduces the bf16-rounded u; few values, cancelling sums
+    # ... and with a residual joining the same epilogue (ops.SynthForkFn): exactly the value a separate add pass would store
+    r2 = feat(tuple(ref0.shape), dtype, 7, Co)
+    y_r, gs_r = H.conv_fwd(x.cuda(), pw_h, Co, k, stride, pre=pre.cuda(), post=post.cuda(), xs=res.cuda(), residual=r2.cuda())
+    _same_as_add_pass(y_r, y_h, r2.cuda(), dtype, "fused y + residual")
+    check(gs_r, gs_h.cpu(), dtype, "fused gs with residual", l2_scale=3.0)     # (same reduction; split-K atomics differ from run to run in u's last bit)
+    check(y_r, E.conv_fwd(x, pw_e, Co, k, stride, pre=pre, post=post, xs=res, residual=r2)[0], dtype, "fused y + residual", l2_scale=2.0)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -297,6 +317,10 @@ def test_conv_bwd_data(H, dtype, case):
     gx_e, gs_e = E.conv_bwd_data(g, pw_e, Ci, k, stride, pre=pre, post=post, xs=xs)
     check(gx_h, gx_e, dtype, "fused gx", l2_scale=2.0)     # generic path: u is rounded to bf16 BEFORE the style scale (two roundings)
     check(gs_h, gs_e, dtype, "fused gs", l2_scale=3.0)     # generic path reduces the bf16-rounded u; few values, cancelling sums
+    r2 = feat((B, Hh, W, ceil8(Ci)), dtype, 18, Ci)        # a residual joining the style-gradient epilogue (ops.SynthForkFn)
+    gx_r, gs_r = H.conv_bwd_data(g.cuda(), pw_h, Ci, k, stride, pre=pre.cuda(), post=post.cuda(), xs=xs.cuda(), residual=r2.cuda())
+    _same_as_add_pass(gx_r, gx_h, r2.cuda(), dtype, "fused gx + residual")
+    check(gs_r, gs_h.cpu(), dtype, "fused gs with residual", l2_scale=3.0)
     if Hh % 2 == 0 and W % 2 == 0:         # pooled-branch gradient folded into the epilogue (0.25 * nearest-x2 of a half-res tensor)
         rh = feat((B, Hh // 2, W // 2, ceil8(Ci)), dtype, 16, Ci)
         check(H.conv_bwd_data(g.cuda(), pw_h, Ci, k, stride, residual=rh.cuda(), residual_half=True),
