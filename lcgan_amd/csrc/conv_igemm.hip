@@ -1031,13 +1031,14 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
     // under the first tap's MFMAs (16 MFMAs per wave between barriers)
     constexpr int TP = DMA;
     const int ngroups = (ntaps + TP - 1) / TP, total = ngroups * nchunks;
-    // SPREAD (chunks of >= 4 steps: the 3 x 3 geometries): the step barrier no longer drains every DMA of the wave.  The halo image of the
-    // NEXT chunk comes from HBM (~2 us) while a step is ~1 us: issued whole in step 0 and waited for by that step's vmcnt(0), it stalled
-    // one barrier per chunk for an HBM round trip (builds that skip the halo fetch ran 16-25 % faster, -DHALO_EXP=4).  Now its pieces are
-    // issued BEHIND the step's weight tiles -- two in step 0, the third in step 1 -- and the barrier waits with a COUNTED vmcnt that
-    // leaves exactly those newest pieces in flight (vector memory returns in issue order): the weight tiles of the next step have
-    // landed, the halo pieces get one more step, and all of them are in LDS at the barrier of step 2 (MOD scales them in step 3).
-    const bool spread = ngroups >= 4 && !(a.dbg & 16);                // (option 3, bit 16: the round-3 schedule, for A/B runs)
+    // SPREAD (option 3, bit 16; OFF: measured 1.5-3 % SLOWER than draining everything at every barrier, ab_multi "3=16" vs ""): the halo
+    // image of the next chunk issued as pieces BEHIND the step's weight tiles -- two in step 0, the third in step 1 -- with the step
+    // barrier waiting on a COUNTED vmcnt that leaves exactly those newest pieces in flight.  The idea came from builds that skip the halo
+    // fetch (-DHALO_EXP=4) running 16-25 % faster; the in-loop stamps (scripts/halo_stamps.py) then showed why it does not pay: a step is
+    // ~2 300 cycles for 2 048 cycles of MFMA work per SIMD, the vmcnt wait is ~180 of them and the barrier wait ~450 with or without the
+    // spread issue -- the loop is matrix-pipe-bound at the clock the chip holds under this load, and the EXP builds ran faster because
+    // stale LDS operands draw less power, not because the waits went away.
+    const bool spread = ngroups >= 4 && (a.dbg & 16);
     auto dma_b = [&](int cc, int g, int buf) {
 #pragma unroll
       for (int j = 0; j < TP; ++j) {
