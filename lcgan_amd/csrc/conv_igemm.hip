@@ -2637,9 +2637,13 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad3_dma_kernel(WgradArgs a) {
     xhc[k] = (hc < XW && c0 + ch < a.Cx) ? hc - 1 : -0x40000000;     // column relative to the segment origin (padding: -1)
     xoffs[k] = 2 * ((hc - 1) * a.Cx + c0 + ch);
   }
+  // chunk q -> (sample b, image row row0, segment seg): decoded ONCE; the loop below walks the chunks in order and steps the three
+  // counters (the four integer divisions per chunk were most of the ~570 cycles a wave spent issuing a chunk's DMA: scripts/wgrad_stamps.py)
+  int d_seg = q_begin % segs, d_row = (q_begin / segs) % rgroups, d_b = (q_begin / segs) / rgroups;
   auto dma = [&](int q, int buf) {
-    const int seg = q % segs, t = q / segs;
-    const int row0 = t % rgroups, b = t / rgroups, j0 = seg * SEG;
+    (void)q;
+    const int seg = d_seg, row0 = d_row, b = d_b, j0 = seg * SEG;
+    if (++d_seg == segs) { d_seg = 0; if (++d_row == rgroups) { d_row = 0; ++d_b; } }
     char* G = smem + buf * STAGE_B;
     const int gbase = 2 * (((b * a.Hm + row0) * a.Wm + j0) * a.Cg);
 #pragma unroll
@@ -2704,6 +2708,30 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad3_dma_kernel(WgradArgs a) {
 
   dma(q_begin, 0);
   __syncthreads();
+#ifdef HALO_STAMPS
+  // diagnostic build: per wave, cycle sums of a chunk's segments -- [DMA issue] [fragment reads + 24 MFMAs issued] [vmcnt wait] [barrier wait]
+  unsigned long long wsA = 0, wsB = 0, wsC = 0, wsD = 0, wt0 = 0, wt1 = 0, wt2 = 0, wt3 = 0, wt4 = 0;
+  auto chunk = [&](int q, int nb, int cb) {
+    STAMP(wt0)
+    if (q + 1 < q_end) dma(q + 1, nb);
+    STAMP(wt1)
+    compute(cb);
+    STAMP(wt2)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(wt3)
+    __syncthreads();
+    STAMP(wt4)
+    wsA += wt1 - wt0; wsB += wt2 - wt1; wsC += wt3 - wt2; wsD += wt4 - wt3;
+  };
+  for (int q = q_begin; q < q_end; q += 2) {
+    chunk(q, 1, 0);
+    if (q + 1 < q_end) chunk(q + 1, 0, 1);
+  }
+  if (lane == 0 && blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z) < 2048) {
+    unsigned long long* o = g_halo_stamps + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + wid) * 5;
+    o[0] = wsA; o[1] = wsB; o[2] = wsC; o[3] = wsD; o[4] = q_end - q_begin;
+  }
+#else
   for (int q = q_begin; q < q_end; q += 2) {
     if (q + 1 < q_end) dma(q + 1, 1);
     compute(0);
@@ -2714,6 +2742,7 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad3_dma_kernel(WgradArgs a) {
       __syncthreads();
     }
   }
+#endif
 
 #pragma unroll
   for (int kx = 0; kx < NKX; ++kx)
