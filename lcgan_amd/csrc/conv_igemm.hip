@@ -658,6 +658,11 @@ struct HaloArgs {
 // diagnostic build (scripts/halo_stamps.py; never the shipped library): per wave of the first 2048 workgroups, cycle sums of the four
 // segments of a main-loop step -- [barrier exit -> fragments landed] [MFMA issue] [tile store -> barrier arrival] [barrier wait]
 __device__ unsigned long long g_halo_stamps[2048 * 8 * 5];
+__device__ unsigned long long g_halo_clock[2048 * 8 * 2];     // per wave: (s_memtime, s_memrealtime [100 MHz]) deltas over the main loop -> the clock the chip held
+#define STAMP_RT(var)                                                                                               \
+  __builtin_amdgcn_sched_barrier(0);                                                                                \
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                                   \
+  __builtin_amdgcn_sched_barrier(0);
 #define STAMP(var)                                                                                                  \
   __builtin_amdgcn_sched_barrier(0);                                                                                \
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                                       \
@@ -1218,14 +1223,20 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
       step_barrier();
       if (++g == ngroups) { g = 0; ++c; }
     };
+#ifdef HALO_STAMPS
+    unsigned long long ck0 = 0, ck1 = 0, rt0 = 0, rt1 = 0;
+    STAMP(ck0) STAMP_RT(rt0)
+#endif
     for (int q = 0; q < total; q += 2) {
       step(q, std::integral_constant<int, 0>{});
       if (q + 1 < total) step(q + 1, std::integral_constant<int, 1>{});
     }
 #ifdef HALO_STAMPS
+    STAMP(ck1) STAMP_RT(rt1)
     if (!M16 && lane == 0 && blockIdx.x < 2048 && blockIdx.z == 0 && blockIdx.y == 0) {
       unsigned long long* o = g_halo_stamps + ((size_t)blockIdx.x * 8 + wid) * 5;
       o[0] = dsA; o[1] = dsB; o[2] = dsC; o[3] = dsD; o[4] = total;
+      g_halo_clock[((size_t)blockIdx.x * 8 + wid) * 2] = ck1 - ck0; g_halo_clock[((size_t)blockIdx.x * 8 + wid) * 2 + 1] = rt1 - rt0;
     }
 #endif
   } else if constexpr (PAIR) {
@@ -3225,6 +3236,9 @@ int lcgan_set_option(int option, int value) {
 }
 
 #ifdef HALO_STAMPS
+int lcgan_halo_clock(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_clock), sizeof(unsigned long long) * 2048 * 8 * 2) == hipSuccess ? LCGAN_OK : LCGAN_ELAUNCH;
+}
 int lcgan_halo_stamps(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_stamps), sizeof(unsigned long long) * 2048 * 8 * 5) == hipSuccess ? LCGAN_OK : LCGAN_ELAUNCH;
 }

@@ -16,7 +16,10 @@ with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=T
     torch.cuda.synchronize()
 cnt = collections.Counter()
 for ev in prof.events():
-    if ev.name in ("aten::fill_", "aten::zero_", "aten::copy_", "aten::add", "aten::add_", "aten::mul", "aten::clone", "aten::contiguous"):
+    if ev.name.startswith("aten::") and ev.name not in ("aten::empty", "aten::empty_like", "aten::view", "aten::as_strided", "aten::empty_strided", "aten::detach", "aten::alias",
+                                                        "aten::reshape", "aten::_unsafe_view", "aten::unsqueeze", "aten::squeeze", "aten::select", "aten::slice", "aten::transpose", "aten::t",
+                                                        "aten::permute", "aten::expand", "aten::result_type", "aten::item", "aten::_local_scalar_dense", "aten::is_nonzero", "aten::lift_fresh",
+                                                        "aten::resolve_conj", "aten::resolve_neg", "aten::unbind", "aten::stride", "aten::size", "aten::view_as", "aten::flatten", "aten::narrow", "aten::unflatten"):
         site, par = "?", ev.cpu_parent
         while par is not None:                       # backward ops run on the autograd thread: name the node being evaluated
             if "evaluate_function" in par.name or par.name.endswith("Backward"):
@@ -29,7 +32,7 @@ for ev in prof.events():
                 break
         shape = str(ev.input_shapes[0])[:28] if ev.input_shapes else ""
         cnt[(ev.name, site, shape)] += 1
-for k, v in cnt.most_common(45):
+for k, v in cnt.most_common(120):
     print(v, k)
 print("---- large operands (>= 1M elements at this batch)")
 big = collections.Counter()

@@ -26,4 +26,11 @@ for (Hh, Ci, Co, st) in [(256, 128, 128, 1), (128, 256, 256, 1), (64, 512, 512, 
     med = np.median(per.reshape(-1, 4), axis=0)
     early, late = np.median(per[:, :4].reshape(-1, 4), axis=0), np.median(per[:, 4:].reshape(-1, 4), axis=0)
     print(f"{Hh}^2 {Ci}->{Co}: steps {steps:.0f}; cycles/step  [DMA issue + first fragments landed] {med[0]:.0f}  [MFMA issue + interleaved reads] {med[1]:.0f}  [vmcnt wait] {med[2]:.0f}  [barrier wait] {med[3]:.0f}  total {med.sum():.0f}")
+    ck = (C.c_ulonglong * (2048 * 8 * 2))()
+    K.lib.lcgan_halo_clock.argtypes = [C.c_void_p]
+    if K.lib.lcgan_halo_clock(ck) == 0:
+        c = np.array(ck[:], dtype=np.float64).reshape(2048, 8, 2)[:min(ntiles, 2048)]
+        ghz = np.median(c[:, :, 0] / np.maximum(c[:, :, 1], 1.0)) * 0.1                     # s_memrealtime ticks at 100 MHz
+        print(f"      shader clock during the main loop (s_memtime / s_memrealtime): {ghz:.2f} GHz; MFMA work per step and SIMD 2048 cycles -> pipe occupancy {2048 / med.sum():.2f}; "
+              f"peak at this clock {ghz * 1.048576:.2f} PFLOP/s")
     print(f"      waves 0-3: {early.round()}   waves 4-7: {late.round()}")
