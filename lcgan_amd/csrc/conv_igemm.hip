@@ -47,7 +47,7 @@ int g_halo_dma_mod = 2;                   // lcgan_set_option(11, ...): the same
 int g_wgrad_dma = 3;                      // lcgan_set_option(12, ...): LDS-DMA staging in the row-segment weight-gradient kernel (3x3): 0 = off, 1 = stride 1 with the one-workgroup-per-CU split, 2 = stride 1, split for two workgroups per CU, 3 = also stride 2 (32-position chunks)
 int g_halo_s2dma = 4;                     // lcgan_set_option(13, ...): stride-2 forward 3x3 on the parity-plane LDS-DMA structure: 0 off, 1 = layers without per-sample input scales, 2 = all (two stages per workgroup, one workgroup per CU), 4 = as 2 but unscaled layers with ONE stage per workgroup and two workgroups per CU
 int g_halo_nb_group_kb = 8192;               // lcgan_set_option(14, ...): KB of weights (all taps x 128 rows x Cin) that concurrent channel blocks of one tile may hold in an XCD's L2; 0 = channel blocks slowest (one pass over the input per block)
-int g_wgrad_xcd = 0;                      // lcgan_set_option(15, ...): row-segment wgrad workgroups of one split share an XCD (1-D grid)
+int g_wgrad_xcd = 1;                      // lcgan_set_option(15, ...): row-segment wgrad workgroups of one split share an XCD (1-D grid; see WG3_INDEX)
 int g_wgrad_low_direct = 1;               // lcgan_set_option(20, ...): launch plan of the small-grid (8 x 8, 16 x 16) weight gradients without per-sample scales: splits chosen by the measured
                                           // cost model in conv_wgrad_impl, one split = the epilogue writes the finished gradient in weight layout, XCD order only from 8 splits
                                           // (0 = the round-2 plan: >= 1024 positions per split, XCD order always, atomics below 4 splits)
@@ -2389,16 +2389,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 //   * (sample, row, segment) decoding is scalar, and chunks whose input row is padding are skipped.
 // =========================================================================================================
 // Workgroup -> (a block, c block, kernel row ky, split).  Every workgroup of one split reads the same chunk range (G rows for its a
-// block, X rows for its c block and ky), so they should share an L2: the grid is 1-D, workgroups go round-robin over the 8 XCDs, and
-// XCD i takes splits i, i + 8, ... with all (a, c, ky) workgroups of a split consecutive on it.  (The 3-D grid put the workgroups of
-// a split on neighbouring XCDs: their common reads met in the Infinity Cache at best.)
+// block, X rows for its c block and ky), so they should share an L2.  With the 3-D grid (blockIdx.z = split x kernel row, dispatched
+// round-robin over the 8 XCDs) the three kernel-row siblings of a position range sat on three different XCDs and every operand byte
+// crossed the fabric 3-5 times (rocprofv3 FETCH_SIZE per dispatch, scripts/micro_wgrad_xcd.py: 3.2 GB for the 1.07 GB of operands of the
+// 256 x 256 layer).  XCD order (1-D grid): XCD i takes splits i, i + 8, ... with all (a, c, ky) workgroups of a split consecutive on it
+// -- 1.0-1.7x the operand bytes, -10 ... -15 % on the 256 x 256 launches.  Splits beyond the last whole group of 8 are dealt tile by
+// tile over all XCDs (their siblings do not share an L2, but no XCD is left with a longer queue than another: the first version put
+// whole splits only, and the plan had to pick split counts that are multiples of 8 x rounds -- 3x the partial-tile traffic on the
+// 512-channel layers, where it lost 10 %).
 #define WG3_INDEX(NKXV)                                                                                               \
   int a0, c0, split, ky;                                                                                              \
   if (a.xcd_order) {                                                                                                  \
     const int tiles = a.na * a.nc * (NKXV), xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;                             \
-    const int sl = slot / tiles, t = slot - sl * tiles;                                                               \
-    split = sl * 8 + xcd;                                                                                             \
-    if (split >= a.nsplit) return;                                                                                    \
+    const int nfull8 = a.nsplit >> 3, grouped = nfull8 * tiles;                                                       \
+    int t;                                                                                                            \
+    if (slot < grouped) {                                                                                             \
+      const int sl = slot / tiles;                                                                                    \
+      t = slot - sl * tiles;                                                                                          \
+      split = sl * 8 + xcd;                                                                                           \
+    } else {                                                                                                          \
+      const int r = (slot - grouped) * 8 + xcd, sr = r / tiles;                                                       \
+      t = r - sr * tiles;                                                                                             \
+      split = nfull8 * 8 + sr;                                                                                        \
+      if (split >= a.nsplit) return;                                                                                  \
+    }                                                                                                                 \
     a0 = (t % a.na) * 128; c0 = ((t / a.na) % a.nc) * 128; ky = t / (a.na * a.nc);                                    \
   } else {                                                                                                            \
     a0 = blockIdx.x * 128; c0 = blockIdx.y * 128;                                                                     \
@@ -3485,8 +3499,7 @@ static int conv_wgrad_impl(const void* x, const void* g, float* gwp,
       for (int pt = 1; pt <= max_parts; ++pt) {
         const int cpsplit = cdiv(cps, pt), real_parts = cdiv(cps, cpsplit);
         // (XCD order: XCD i runs splits i, i + 8, ...: the fullest XCD, 32 CUs, sets the number of rounds)
-        const long long rounds = g_wgrad_xcd ? ((long long)tiles3 * cdiv(groups * real_parts, 8) + 32 * occ - 1) / (32 * occ)
-                                             : ((long long)tiles3 * groups * real_parts + 256 * occ - 1) / (256 * occ);
+        const long long rounds = ((long long)tiles3 * groups * real_parts + 256 * occ - 1) / (256 * occ);   // (XCD order deals the splits beyond whole groups of 8 tile by tile: every XCD gets the same share)
         const double cost = (double)rounds * (1024.0 + (double)cpsplit * seg);   // (a packed chunk costs what a plain one does)
         if (cost < best) { best = cost; parts = real_parts; }
       }
@@ -3533,7 +3546,10 @@ static int conv_wgrad_impl(const void* x, const void* g, float* gwp,
     // (XCD order puts split i on XCD i % 8: with fewer than 8 splits it would leave whole XCDs idle)
     a.na = cdiv(A, 128); a.nc = cdiv(Bc, 128); a.xcd_order = g_wgrad_xcd && (a.nsplit >= 8 || g_wgrad_low_direct <= 0);
     dim3 grid3(a.na, a.nc, nkx * a.nsplit);
-    if (a.xcd_order) grid3 = dim3(8 * a.na * a.nc * nkx * cdiv(a.nsplit, 8), 1, 1);
+    if (a.xcd_order) {
+      const int tiles = a.na * a.nc * nkx, nfull8 = a.nsplit >> 3, rem = a.nsplit - 8 * nfull8;
+      grid3 = dim3(8 * (nfull8 * tiles + cdiv(rem * tiles, 8)), 1, 1);
+    }
 #define LAUNCH_WG3(ST, SG, SW, NK)                                                                                      \
     {                                                                                                                   \
       static bool set = false;                                                                                          \
