@@ -52,6 +52,7 @@ int g_wgrad_low_direct = 1;               // lcgan_set_option(20, ...): launch p
                                           // cost model in conv_wgrad_impl, one split = the epilogue writes the finished gradient in weight layout, XCD order only from 8 splits
                                           // (0 = the round-2 plan: >= 1024 positions per split, XCD order always, atomics below 4 splits)
 int g_wgrad_low_parts = 0;                // lcgan_set_option(21, ...): force the number of splits of the small-grid weight gradients (tuning experiments; 0 = automatic)
+int g_halo_phase_x = 0;                    // lcgan_set_option(24, ...): the 4 sub-pixel phases of a transposed convolution tile run side by side on one XCD (1-D grid) instead of as grid.z planes (measured: fabric reads -3.6x, time 0 ... +25 %: off)
 int g_flow_wgrad = 1;                     // lcgan_set_option(23, ...): one-pass weight gradient of the flow layer's 1x1 GEMM (flow_wgrad_kernel); 0 = the row-segment kernel
 int g_halo_split = 0;                     // lcgan_set_option(22, ...): halo launches below option 6's workgroup count split their input-channel range so that about this many workgroups run
                                           // (stride-1 LDS-DMA structure).  0 = off, the default: such launches go to the generic split-K kernel.  Measured with 256: the conv launches
@@ -647,6 +648,7 @@ struct HaloArgs {
   TapTable taps[4];
   int hy0[4], hx0[4], hh[4], hw[4];          // per phase: halo origin (min dy, min dx) and extent in input pixels
   int nblocks, nb_group;                     // channel blocks of 128; how many of them run together per tile (see the kernel's workgroup order)
+  int nph_x;                                 // 4: the sub-pixel phases of a transposed convolution are folded into grid.x (grid.z = 1); else 1
   int halo_elems;                            // LDS elements reserved for the halo (max over phases)
   int dbg;                                   // option 3, bit 8: linear instead of XCD-contiguous tile order
   // split of the input-channel range over blockIdx.y (stride-1 LDS-DMA structure only; launches that would leave most CUs idle): every
@@ -704,21 +706,32 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   // the 4 sub-pixel phases of a transposed conv have 1/2/2/4 taps: dispatch the long ones first (shorter tail)
-  const int phase = gridDim.z - 1 - blockIdx.z;
+  int phase = gridDim.z - 1 - blockIdx.z;
   // Workgroup order (grid.x = tiles x channel blocks).  Workgroups are dealt round-robin over the 8 XCDs, so every XCD gets a
   // contiguous run of tiles (neighbouring tiles share halo columns and rows in that XCD's L2: -1.3 % on the conv launches of an
   // iteration).  Inside an XCD the channel blocks of one tile run TOGETHER in groups of a.nb_group blocks (as many as keep their
   // weights resident in the XCD's 4 MB L2), so the tile's input is fetched from HBM once per group instead of once per block.
-  const int ntile = gridDim.x / a.nblocks;
+  // The 4 phases of a transposed convolution read the SAME 17 x 17 input halo.  As grid.z planes (all tiles of one phase, then the next)
+  // every phase fetches the input over the fabric again: 4.1-5.5x the input bytes per launch (rocprofv3 FETCH_SIZE per dispatch,
+  // scripts/micro_s2_pmc.py).  Option 24 folds the phases into the 1-D order (a.nph_x = 4: the phases of a tile neighbours in one XCD's
+  // queue, longest first).  MEASURED: the reads fall 3.6x (1 093 -> 299 MB at 128 x 128 -> 256 x 256) and the launch takes the same time
+  // there, 25 % LONGER on the 512-channel layers: these launches are not bound by what crosses the fabric but by the per-workgroup fixed
+  // cost paid four times per tile (a 1-tap phase is 8 steps of main loop); eight workgroups asking for the same lines at the same moment
+  // costs more than the Infinity Cache hits it saves.  Off by default.
+  const int nph = a.nph_x, ntile = gridDim.x / (a.nblocks * nph);
   int tile, nb;
   if (!(a.dbg & 8) && (ntile & 7) == 0) {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = (ntile >> 3) * a.nb_group;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, grp = a.nb_group * nph, per = (ntile >> 3) * grp;
     const int nbo = slot / per, rem = slot - nbo * per;
-    tile = xcd * (ntile >> 3) + rem / a.nb_group;
-    nb = nbo * a.nb_group + rem % a.nb_group;
+    tile = xcd * (ntile >> 3) + rem / grp;
+    const int r2 = rem % grp;
+    nb = nbo * a.nb_group + r2 / nph;
+    if (nph > 1) phase = nph - 1 - r2 % nph;
   } else {
     tile = blockIdx.x % ntile;
-    nb = blockIdx.x / ntile;
+    const int t2 = blockIdx.x / ntile;
+    nb = t2 % a.nblocks;
+    if (nph > 1) phase = nph - 1 - t2 / a.nblocks;
   }
   const int n0 = nb * BN;
   const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
@@ -2109,6 +2122,8 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
       if (a.nblocks % gsz == 0 && gsz * wbytes <= (size_t)g_halo_nb_group_kb * 1024) { a.nb_group = gsz; break; }
   }
   dim3 grid(c.B * a.tiles_x * a.tiles_y * a.nblocks, a.nsplit, nphase);
+  a.nph_x = 1;
+  if (nphase == 4 && g_halo_phase_x) { a.nph_x = 4; grid = dim3(grid.x * 4, a.nsplit, 1); }
 #define LAUNCH_HALO(IM, MM, EP)                                                                                         \
   {                                                                                                                     \
     static bool set = false;                                                                                            \
@@ -3244,6 +3259,7 @@ int lcgan_set_option(int option, int value) {
   if (option == 21) { const int old = g_wgrad_low_parts; g_wgrad_low_parts = value; return old; }
   if (option == 22) { const int old = g_halo_split; g_halo_split = value; return old; }
   if (option == 23) { const int old = g_flow_wgrad; g_flow_wgrad = value; return old; }
+  if (option == 24) { const int old = g_halo_phase_x; g_halo_phase_x = value; return old; }
   if (option == 17) { const int old = g_wgrad_prescale_mb; g_wgrad_prescale_mb = value; return old; }
   if (option == 18) { const int old = g_halo_wmod_mb; g_halo_wmod_mb = value; return old; }
   return LCGAN_EINVAL;
