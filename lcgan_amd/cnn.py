@@ -44,7 +44,9 @@ class Discriminator(torch.nn.Module):
         self.projection_header1 = ProjectionHead([out_features * 16, out_features * 4, out_features, self.geo_projection_dim])
         self.projection_header2 = ProjectionHead([out_features * 16, out_features * 4, out_features, self.app_projection_dim])
 
-    def forward(self, image, get_embedding_features=False):
+    def forward(self, image, get_embedding_features=False, n_sub=1):
+        """n_sub (not in the reference): `image` holds n_sub passes of the reference end to end (e.g. the three views of an even
+        iteration, worker.py:163-165); everything is per sample except the minibatch-stddev statistic, which is taken per pass"""
         mods = list(self.shared_model)
         blocks = mods[2:]
         # every block's input arrives with its 2 x 2 average (the skip branch's input, custom_layers.py:202) already made by the kernel
@@ -55,7 +57,7 @@ class Discriminator(torch.nn.Module):
                 h, pooled = blk(h, pooled, want_pool=True)
             else:
                 h = blk(h, pooled)
-        logit = self.logit_mapper(self.discriminator_epilogue(h))
+        logit = self.logit_mapper(self.discriminator_epilogue(h, n_sub))
         geometry_embedding = None
         appearance_embedding = None
         if get_embedding_features:
@@ -104,7 +106,9 @@ class Generator(torch.nn.Module):
         self.model = nn.Sequential(*blocks)
         self.rgb_layer = ToRGBBlock(out_features, 3, self.app_latent_dim, out_resolution, use_noise=False)
 
-    def forward(self, rand_noise1, rand_noise2, w_psi=-1.0):
+    def forward(self, rand_noise1, rand_noise2, w_psi=-1.0, n_sub=1):
+        """n_sub (not in the reference): the noise batches hold n_sub passes of the reference end to end (the three generator calls of an
+        even iteration, worker.py:194-196); the running latent means are then updated once per pass, in order, as n_sub calls would"""
         batch_size = rand_noise1.size(0)
         Lg, La = mapping_matrices((self.geometry_mapping, self.appearance_mapping))      # both QR factorisations in one launch
         # the two mapping chains side by side: their layers of equal shape (the fourth to the twelfth) share launches
@@ -112,8 +116,10 @@ class Generator(torch.nn.Module):
                                                          (rand_noise1.float(), rand_noise2.float()), (Lg, La))
 
         if w_psi <= 0:                                   # running latent means (cnn.py:95-97), one tiny kernel each
-            KM.K.avg_latent(geometry_code.detach(), self.avg_latent1, self.w_avg_beta)
-            KM.K.avg_latent(appearance_code.detach(), self.avg_latent2, self.w_avg_beta)
+            assert batch_size % n_sub == 0
+            for gc, ac in zip(geometry_code.detach().chunk(n_sub, dim=0), appearance_code.detach().chunk(n_sub, dim=0)):
+                KM.K.avg_latent(gc.contiguous(), self.avg_latent1, self.w_avg_beta)
+                KM.K.avg_latent(ac.contiguous(), self.avg_latent2, self.w_avg_beta)
         if w_psi > 0.0:                                  # truncation trick (cnn.py:99-101), inference only
             geometry_code = self.avg_latent1.lerp(geometry_code, w_psi)
             appearance_code = self.avg_latent2.lerp(appearance_code, w_psi)

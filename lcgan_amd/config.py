@@ -44,6 +44,18 @@ def set_synth_fork(on: bool) -> None:
     _synth_fork = bool(on)
 
 
+_batched_passes = _os.environ.get("LCGAN_BATCHED_PASSES", "1") != "0"   # A/B switch: the passes of an iteration that share weights as ONE batch (worker.py)
+
+
+def batched_passes() -> bool:
+    return _batched_passes
+
+
+def set_batched_passes(on: bool) -> None:
+    global _batched_passes
+    _batched_passes = bool(on)
+
+
 def set_feature_dtype(dtype: torch.dtype) -> None:
     global _feature_dtype
     if dtype not in (torch.bfloat16, torch.float32):

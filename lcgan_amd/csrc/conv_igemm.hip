@@ -660,6 +660,7 @@ struct HaloArgs {
 // diagnostic build (scripts/halo_stamps.py; never the shipped library): per wave of the first 2048 workgroups, cycle sums of the four
 // segments of a main-loop step -- [barrier exit -> fragments landed] [MFMA issue] [tile store -> barrier arrival] [barrier wait]
 __device__ unsigned long long g_halo_stamps[2048 * 8 * 5];
+__device__ unsigned long long g_halo_life[16384 * 5];        // per workgroup (wave 0): s_memrealtime at kernel entry, main-loop start, main-loop end, last store issued; HW_ID
 __device__ unsigned long long g_halo_clock[2048 * 8 * 2];     // per wave: (s_memtime, s_memrealtime [100 MHz]) deltas over the main loop -> the clock the chip held
 #define STAMP_RT(var)                                                                                               \
   __builtin_amdgcn_sched_barrier(0);                                                                                \
@@ -705,6 +706,10 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
+#ifdef HALO_STAMPS
+  unsigned long long life0 = 0, life1 = 0, life2 = 0, life3 = 0;
+  STAMP_RT(life0)
+#endif
   // the 4 sub-pixel phases of a transposed conv have 1/2/2/4 taps: dispatch the long ones first (shorter tail)
   int phase = gridDim.z - 1 - blockIdx.z;
   // Workgroup order (grid.x = tiles x channel blocks).  Workgroups are dealt round-robin over the 8 XCDs, so every XCD gets a
@@ -1239,6 +1244,7 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
 #ifdef HALO_STAMPS
     unsigned long long ck0 = 0, ck1 = 0, rt0 = 0, rt1 = 0;
     STAMP(ck0) STAMP_RT(rt0)
+    life1 = rt0;
 #endif
     for (int q = 0; q < total; q += 2) {
       step(q, std::integral_constant<int, 0>{});
@@ -1246,6 +1252,7 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
     }
 #ifdef HALO_STAMPS
     STAMP(ck1) STAMP_RT(rt1)
+    life2 = rt1;
     if (!M16 && lane == 0 && blockIdx.x < 2048 && blockIdx.z == 0 && blockIdx.y == 0) {
       unsigned long long* o = g_halo_stamps + ((size_t)blockIdx.x * 8 + wid) * 5;
       o[0] = dsA; o[1] = dsB; o[2] = dsC; o[3] = dsD; o[4] = total;
@@ -1652,6 +1659,19 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
     *(bf16x8*)(a.y + ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n) = *(const bf16x8*)(ot + row * OROW + vv * 8);
   }
   }
+#ifdef HALO_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the tile's stores have been acknowledged
+  STAMP_RT(life3)
+  if (tid == 0) {
+    const size_t wgid = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+    if (wgid < 16384) {
+      unsigned hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      unsigned long long* o = g_halo_life + wgid * 5;
+      o[0] = life0; o[1] = life1; o[2] = life2; o[3] = life3; o[4] = hwid;
+    }
+  }
+#endif
   if constexpr (EPI == 1) {
     // by-product of a DiscriminatorBlock's closing 1x1 convolution (custom_layers.py:203,209): avg_pool2d(out, 2), which the NEXT
     // block's skip branch reads (custom_layers.py:202), from the finished bf16 tile in LDS -- the same values, summation and
@@ -3266,6 +3286,9 @@ int lcgan_set_option(int option, int value) {
 }
 
 #ifdef HALO_STAMPS
+int lcgan_halo_life(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_life), sizeof(unsigned long long) * 16384 * 5) == hipSuccess ? LCGAN_OK : LCGAN_ELAUNCH;
+}
 int lcgan_halo_clock(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_clock), sizeof(unsigned long long) * 2048 * 8 * 2) == hipSuccess ? LCGAN_OK : LCGAN_ELAUNCH;
 }

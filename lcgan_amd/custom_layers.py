@@ -258,10 +258,15 @@ class MinibatchStdLayer(nn.Module):
         self.group_size = group_size
         self.num_channels = num_channels
 
-    def forward(self, x):
+    def forward(self, x, n_sub=1):
+        """n_sub > 1: the batch holds n_sub independent passes of the reference (worker.py:163-165, 198-200 evaluate the discriminator
+        once per view) laid end to end; the statistic is taken per pass, exactly as n_sub separate calls would (custom_layers.py:243-256)"""
+        if n_sub > 1:
+            assert x.shape[0] % n_sub == 0
+            return torch.cat([self.forward(c) for c in x.chunk(n_sub, dim=0)], dim=0)
         N = x.shape[0]
         G = min(self.group_size, N) if self.group_size is not None else N
-        return ops.MbstdFn.apply(x, G)
+        return ops.MbstdFn.apply(x.contiguous(), G)
 
 
 class DiscriminatorEpilogue(nn.Module):
@@ -274,8 +279,8 @@ class DiscriminatorEpilogue(nn.Module):
         self.conv = EqualizedConv2d(in_features + 1, in_features, kernel_size=3, lr_mul=1.0)
         self.linear = EqualizedLinear(in_features * (resolution ** 2), in_features, lr_mul=0.01)
 
-    def forward(self, x):
-        x = self.mb_std(x)                                                      # [B,4,4,C+1 -> padded to a multiple of 8]
+    def forward(self, x, n_sub=1):
+        x = self.mb_std(x, n_sub)                                               # [B,4,4,C+1 -> padded to a multiple of 8]
         x = self.conv(x, ACT_LRELU, 1.0)
         flat = ops.ToNCHWFn.apply(x, self.conv.weight.weight.shape[0]).flatten(1)   # NCHW order, as x.flatten(1) at :232
         return self.linear(flat, ACT_LRELU)

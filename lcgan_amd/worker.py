@@ -16,7 +16,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from . import cnn, loss
+from . import cnn, config, loss
 from .ema import Ema
 from .optim import Adam, DataParallel
 
@@ -188,6 +188,8 @@ class WORKER(object):
         rand2 = self._randn(self.args.app_noise_dim)
         odd = epoch % 2 == 1
 
+        if config.batched_passes() and epoch % 8 != 1:
+            return self._train_discriminator_batched(epoch, image, geometry_change, appearance_change, rand1, rand2)
         # (1) everything that only needs D's parameters: the real-image passes.  With N > 1 these overlap G's gradient all-reduce.
         if odd:
             image = image.detach().clone().requires_grad_(True)                       # worker.py:152
@@ -217,6 +219,35 @@ class WORKER(object):
         self._after_backward("d", self.discriminator, self.d_optimizer)
         return LazyLoss(d_loss)
 
+    def _train_discriminator_batched(self, epoch, image, geometry_change, appearance_change, rand1, rand2):
+        """The D step of an iteration WITHOUT the R1 penalty with all its discriminator evaluations as ONE batch: [real | fake] on odd
+        iterations (worker.py:152-157), [image | geometry view | appearance view | fake] on even ones (worker.py:163-169).  The reference
+        calls D once per tensor; the calls share the weights and are independent per sample except for the minibatch-stddev statistic,
+        which `n_sub` keeps per call (custom_layers.py:243-256) -- so this is the same function evaluated in fewer, fatter launches (the
+        low-resolution and latency-class kernels run once instead of 2-4 times; at local batch 4 that is most of the step).  The R1
+        iteration keeps separate passes: its double backward belongs to the real batch alone (loss.py:18-34)."""
+        B = image.shape[0]
+        self.flush(("g",))                         # the fake batch needs the UPDATED generator (worker.py:145-149)
+        with torch.no_grad():
+            fake_img = self.generator(rand1, rand2)
+        if epoch % 2 == 1:
+            image = image.detach().clone().requires_grad_(True)                       # worker.py:152 (every odd iteration)
+            logit, _, _ = self.discriminator(torch.cat([image, fake_img], dim=0), False, n_sub=2)
+            real_logit, fake_logit = logit[:B], logit[B:]
+            d_loss = loss.bce_with_logits(real_logit, True) + loss.bce_with_logits(fake_logit, False)
+        else:
+            logit, gf, af = self.discriminator(torch.cat([image, geometry_change, appearance_change, fake_img], dim=0), True, n_sub=4)
+            real_logit, fake_logit = logit[:B], logit[3 * B:]
+            geometry_feat, geometry_positive, geometry_negative = gf[:B], gf[B:2 * B], gf[2 * B:3 * B]
+            appearance_feat, appearance_negative, appearance_positive = af[:B], af[B:2 * B], af[2 * B:3 * B]
+            d_adv_loss = loss.bce_with_logits(real_logit, True) + loss.bce_with_logits(fake_logit, False)
+            d_aug_loss = (loss.contrastive_loss(geometry_feat, geometry_positive, geometry_negative, self.args.tau)
+                          + loss.contrastive_loss(appearance_feat, appearance_positive, appearance_negative, self.args.tau)) * self.args.l_aux
+            d_loss = d_adv_loss + d_aug_loss
+        d_loss.backward()
+        self._after_backward("d", self.discriminator, self.d_optimizer)
+        return LazyLoss(d_loss)
+
     # ---- G step (worker.py:179-214) -----------------------------------------------------------------------------------
     def train_generator(self, epoch):
         self.flush(("g",))
@@ -227,8 +258,14 @@ class WORKER(object):
         resample2 = self._randn(self.args.app_noise_dim)
 
         # G forwards need only G's parameters: with N > 1 they overlap the all-reduce of the previous D step's gradients
+        batched = config.batched_passes() and epoch % 2 == 0
         if epoch % 2 == 1:
             images = (self.generator(rand1, rand2),)
+        elif batched:
+            # the three generator calls of an even iteration (worker.py:194-196) as one batch of 3 B, and below the three discriminator
+            # calls on their results (worker.py:198-200) as one too; avg-latent updates and minibatch-stddev stay per call (n_sub)
+            B = rand1.shape[0]
+            images = self.generator(torch.cat([rand1, resample1, rand1], dim=0), torch.cat([rand2, rand2, resample2], dim=0), n_sub=3)
         else:
             images = (self.generator(rand1, rand2), self.generator(resample1, rand2), self.generator(rand1, resample2))   # worker.py:194-196
         self.flush(("d",))                         # D's postponed Adam must land before D is evaluated
@@ -237,9 +274,15 @@ class WORKER(object):
             logit, _, _ = self.discriminator(images[0], False)
             g_loss = loss.bce_with_logits(logit, True)
         else:
-            logit, geometry_feat, appearance_feat = self.discriminator(images[0], True)
-            _, geometry_positive, appearance_negative = self.discriminator(images[1], True)
-            _, geometry_negative, appearance_positive = self.discriminator(images[2], True)
+            if batched:
+                lg, gf, af = self.discriminator(images, True, n_sub=3)
+                logit, geometry_feat, appearance_feat = lg[:B], gf[:B], af[:B]
+                geometry_positive, appearance_negative = gf[B:2 * B], af[B:2 * B]
+                geometry_negative, appearance_positive = gf[2 * B:], af[2 * B:]
+            else:
+                logit, geometry_feat, appearance_feat = self.discriminator(images[0], True)
+                _, geometry_positive, appearance_negative = self.discriminator(images[1], True)
+                _, geometry_negative, appearance_positive = self.discriminator(images[2], True)
             g_adv_loss = loss.bce_with_logits(logit, True)
             g_aug_loss = (loss.contrastive_loss(geometry_feat, geometry_positive, geometry_negative, self.args.tau)
                           + loss.contrastive_loss(appearance_feat, appearance_positive, appearance_negative, self.args.tau)) * self.args.l_aux

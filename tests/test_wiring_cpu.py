@@ -88,6 +88,44 @@ def test_train_discriminator_matches_reference(S, epoch, frozen):
     assert none == sorted(k for k in S[f"{tag}/grad_none"] if k)
 
 
+@pytest.mark.parametrize("which,epoch", [("g", 0), ("d", 0), ("d", 3)])
+def test_batched_passes_equal_separate_passes(S, which, epoch):
+    """worker.py evaluates G three times and D three / four times on an even iteration and D twice on an odd one (worker.py:163-169,
+    194-200).  The product runs those calls as ONE batch (worker.WORKER: config.batched_passes) with the minibatch-stddev statistic
+    and the avg-latent updates kept per call (n_sub).  Both forms must give the reference's numbers (the golden tests above run the
+    batched form, this one runs the separate form against the same goldens) and agree with each other far below the golden tolerance."""
+    from lcgan_amd import config
+    res, B = int(S["res"]), int(S["B"])
+    out = {}
+    for batched in (True, False):
+        config.set_batched_passes(batched)
+        try:
+            w = seeded_worker(res, B, "cpu")
+            FixedFeed(w, B, res, "cpu")
+            w.g_optimizer.step = w.d_optimizer.step = lambda: None
+            if which == "g":
+                w.requires_grad(w.generator, True), w.requires_grad(w.discriminator, False)
+                lossv, net = w.train_generator(epoch), w.generator.module
+            else:
+                w.requires_grad(w.generator, False), w.requires_grad(w.discriminator, True)
+                lossv, net = w.train_discriminator(epoch), w.discriminator.module
+            out[batched] = (float(lossv), {k: (None if p.grad is None else p.grad.clone()) for k, p in net.named_parameters()},
+                            w.generator.module.avg_latent1.clone(), w.generator.module.avg_latent2.clone())
+            if not batched:                                 # the separate form against the reference's goldens too
+                assert rel(lossv, S[f"{which}{epoch}/loss"]) <= TOL
+                check_grads_vs_golden(S, f"{which}{epoch}", net.named_parameters(), TOL if epoch % 2 else TOL_EVEN_GRADS)
+        finally:
+            config.set_batched_passes(True)
+    (la, ga, a1, a2), (lb, gb, b1, b2) = out[True], out[False]
+    assert abs(la - lb) <= 1e-5 * abs(lb)
+    assert torch.allclose(a1, b1, rtol=1e-5, atol=1e-7) and torch.allclose(a2, b2, rtol=1e-5, atol=1e-7)      # avg-latent: one update per call, in order
+    for k in ga:
+        assert (ga[k] is None) == (gb[k] is None), k
+        if ga[k] is not None:
+            err = float((ga[k] - gb[k]).norm() / gb[k].norm().clamp_min(1e-30))
+            assert err <= (TOL if epoch % 2 else TOL_EVEN_GRADS), (k, err)   # (summation order of the batch reductions; the contrastive terms amplify fp32 rounding 20x, see TOL_EVEN_GRADS)
+
+
 def test_forward_truncation_and_deepcopy():
     """w_psi > 0 branch (cnn.py:99-101) and that the DataParallel-wrapped generator survives deepcopy (worker.py:40)."""
     w = seeded_worker(16, 2, "cpu")
