@@ -203,14 +203,16 @@ int lcgan_multi_tensor(const void* descs, const int* chunk_tensor, const int* ch
  * kernel (0 off, 1 / 2 = taps per barrier); 11 the same record layout for convolutions with per-sample input scales; 12 LDS-DMA
  * weight-gradient kernel (0 off, 1, 2 = split for two workgroups per CU, 3 = also stride 2); 13 parity-plane stride-2 forward;
  * 14 KB of weights concurrent channel blocks of one tile may keep in an XCD's L2 (0 = one input pass per channel block);
- * 15 XCD-grouped weight-gradient workgroup order; 16 LDS-DMA staging of the generic implicit-GEMM kernel (2 = modulated low-resolution layers too, through one prescale pass; 3 = its eight-wave form, 4 = with four stages);
+ * 15 XCD-grouped weight-gradient workgroup order (on: operand bytes cross the fabric 1.0-1.7x instead of 3-5x); 16 LDS-DMA staging of the generic implicit-GEMM kernel (2 = modulated low-resolution layers too, through one prescale pass; 3 = its eight-wave form, 4 = with four stages);
  * 17 MB of operands up to which a weight gradient with per-sample scales applies them by one elementwise pass and reduces the whole batch as one range (0 = never);
  * 18 MB of per-sample weight copies up to which a convolution with per-sample input scales folds them into the weights (0 = never);
  * 19 split-K launches of the eight-wave generic kernel with at most this many splits exchange partials through per-split slabs and the last split to arrive finishes the tile (more, or 0: atomics + a finalize launch);
  * 20 launch plan of the small-grid (8 x 8, 16 x 16) weight gradients: splits from a measured cost model, a single split writes the gradient in weight layout from its epilogue (0 = the round-2 plan);
  * 21 forced split count of the small-grid weight gradients (tuning; 0 = automatic);
  * 22 workgroup count up to which a halo-tile launch that option 6 would turn away splits its input-channel range instead (0 = never);
- * 23 one-pass weight gradient of the flow layer's 1x1 GEMM (0 = the row-segment kernel).  DESIGN.md section 2 ("Switches") has the measurements behind the defaults. */
+ * 23 one-pass weight gradient of the flow layer's 1x1 GEMM (0 = the row-segment kernel);
+ * 24 the four sub-pixel phases of a transposed-convolution tile as neighbours in one XCD's queue instead of grid.z planes (off: fabric reads -3.6x, time 0 ... +25 %).
+ * DESIGN.md section 2 ("Switches") has the measurements behind the defaults. */
 int lcgan_set_option(int option, int value);
 
 /* ---- per-launch HIP-event profiling (bench.py roofline) ---------------------------------------------------- */
