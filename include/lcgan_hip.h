@@ -65,6 +65,15 @@ int lcgan_conv_fwd(const void* x, const void* wp, void* y,
                    const float* pre, const float* post, const float* bias, float bias_scale,
                    int act, float gain, const void* residual, int residual_half, const void* xs, float* gs, void* pool_out,
                    int dtype, void* stream);
+/* lcgan_conv_fwd with one more optional by-product: mask_out [B*Hout*Wout][Cout/32] 32-bit words, bit c % 32 of word c / 32 =
+ * (pre-activation of channel c > 0) -- everything the backward of F.leaky_relu (custom_layers.py:205,208) needs of y, in 1/16 of its bytes
+ * (lcgan_act_bwd_reduce_m, lcgan_box3_actbwd_reduce_m).  *mask_written = 1 where the launch path wrote it (bf16 halo-tile kernels, leaky
+ * ReLU, no residual / xs, Cout % 32 == 0), else 0 and the caller keeps using y. */
+int lcgan_conv_fwd_m(const void* x, const void* wp, void* y,
+                     int B, int Hin, int Win, int Cin, int Cout, int N, int k, int stride,
+                     const float* pre, const float* post, const float* bias, float bias_scale,
+                     int act, float gain, const void* residual, int residual_half, const void* xs, float* gs, void* pool_out,
+                     void* mask_out, int* mask_written, int dtype, void* stream);
 /* adjoint of lcgan_conv_fwd w.r.t. x (weights from weight_prep(transpose=1)); stride 2 == the x2 transposed
  * convolution of ModulatedConv2d(up=2): output [B][Hg*stride][Wg*stride][Cout]. */
 int lcgan_conv_bwd_data(const void* g, const void* wpT, void* gx,
@@ -84,6 +93,9 @@ int lcgan_box3_act_bwd(const void* gy, const void* y, void* gx, int B, int H, in
    gz = box3(gy) * act'(y), gbias[c] += sum gz (gbias optional, accumulated) */
 int lcgan_box3_actbwd_reduce(const void* gy, const void* y, void* gz, float* gbias, int B, int H, int W, int C, int Clog,
                              int act, float gain, int dtype, void* stream);
+/* ... with the sign mask instead of y (see lcgan_act_bwd_reduce_m) */
+int lcgan_box3_actbwd_reduce_m(const void* gy, const void* y, const void* mask, void* gz, float* gbias, int B, int H, int W, int C, int Clog,
+                               int act, float gain, int dtype, void* stream);
 /* F.interpolate(x2, nearest) + box filter (+ residual), custom_layers.py:146-147,159 ; x [B,H,W,C] -> y [B,2H,2W,C] */
 int lcgan_up2box(const void* x, const void* residual, void* y, int B, int H, int W, int C, int dtype, void* stream);
 int lcgan_up2box_bwd(const void* gy, void* gx, int B, int H, int W, int C, int dtype, void* stream);
@@ -93,6 +105,11 @@ int lcgan_avgpool2_bwd(const void* gy, void* gx, int B, int H, int W, int C, int
 /* gz = gy*act'(y) (y = saved OUTPUT); gbias[c] += sum gz; gdq[b,c] += sum_p gz*(act^-1(y/gain) - bias[c]*bias_scale) */
 int lcgan_act_bwd_reduce(const void* gy, const void* y, void* gz, const float* bias, float bias_scale,
                          float* gbias, float* gdq, int B, int HW, int C, int Clog, int act, float gain, int dtype, void* stream);
+/* ... reading the activation's SIGN MASK (lcgan_conv_fwd_m: one bit per element, 1/16 of y's bytes) instead of y: the backward of
+ * F.leaky_relu (custom_layers.py:205,208; cnn.py:21) only needs the sign of the pre-activation.  mask: [B*HW][C/8] bytes, bit j of byte v =
+ * channel 8 v + j; needs act == leaky ReLU and gdq == NULL; y may then be NULL.  mask == NULL: lcgan_act_bwd_reduce. */
+int lcgan_act_bwd_reduce_m(const void* gy, const void* y, const void* mask, void* gz, const float* bias, float bias_scale,
+                           float* gbias, float* gdq, int B, int HW, int C, int Clog, int act, float gain, int dtype, void* stream);
 /* style gradient: gs[b,c] += sum_p x*u ; u <- s[b,c]*u in place   (autograd of custom_layers.py:62-64) */
 int lcgan_scale_reduce(void* u, const void* x, const float* s, float* gs, int B, int HW, int C, int dtype, void* stream);
 /* ... with u <- s*u + res (res may be NULL): the data gradient another consumer of the same tensor already produced joins here

@@ -19,17 +19,20 @@ SIGNATURES = {
     "lcgan_conv_wgrad_unprep": [P, I, I, I, F, I, P, P, P, P],
     "lcgan_conv_weight_prep_group": [P, P, P, I, P, P, D, P],
     "lcgan_conv_fwd": [P, P, P, I, I, I, I, I, I, I, I, P, P, P, F, I, F, P, I, P, P, P, I, P],
+    "lcgan_conv_fwd_m": [P, P, P, I, I, I, I, I, I, I, I, P, P, P, F, I, F, P, I, P, P, P, P, P, I, P],
     "lcgan_conv_bwd_data": [P, P, P, I, I, I, I, I, I, I, I, P, P, P, F, I, F, P, I, P, P, I, P],
     "lcgan_conv_wgrad": [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P, I, P],
     "lcgan_conv_wgrad_fused": [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P, I, F, I, P, P, P, P],
     "lcgan_box3_act": [P, P, I, I, I, I, I, F, I, P],
     "lcgan_box3_act_bwd": [P, P, P, I, I, I, I, I, F, I, P],
     "lcgan_box3_actbwd_reduce": [P, P, P, P, I, I, I, I, I, I, F, I, P],
+    "lcgan_box3_actbwd_reduce_m": [P, P, P, P, P, I, I, I, I, I, I, F, I, P],
     "lcgan_up2box": [P, P, P, I, I, I, I, I, P],
     "lcgan_up2box_bwd": [P, P, I, I, I, I, I, P],
     "lcgan_avgpool2": [P, P, I, I, I, I, I, P],
     "lcgan_avgpool2_bwd": [P, P, I, I, I, I, I, P],
     "lcgan_act_bwd_reduce": [P, P, P, P, F, P, P, I, I, I, I, I, F, I, P],
+    "lcgan_act_bwd_reduce_m": [P, P, P, P, P, F, P, P, I, I, I, I, I, F, I, P],
     "lcgan_scale_reduce": [P, P, P, P, I, I, I, I, P],
     "lcgan_scale_reduce_res": [P, P, P, P, P, I, I, I, I, P],
     "lcgan_warp_fwd": [P, P, P, I, I, I, I, F, I, P],

@@ -56,6 +56,18 @@ def set_batched_passes(on: bool) -> None:
     _batched_passes = bool(on)
 
 
+_act_masks = _os.environ.get("LCGAN_ACT_MASKS", "1") != "0"   # A/B switch: leaky-ReLU sign masks as a by-product of the discriminator's convolution epilogues (ops.Conv2dFn / ConvPoolFn)
+
+
+def act_masks() -> bool:
+    return _act_masks
+
+
+def set_act_masks(on: bool) -> None:
+    global _act_masks
+    _act_masks = bool(on)
+
+
 def set_feature_dtype(dtype: torch.dtype) -> None:
     global _feature_dtype
     if dtype not in (torch.bfloat16, torch.float32):

@@ -27,9 +27,13 @@
 extern "C" int lcgan_scale_reduce(void* u, const void* x, const float* sc, float* gs, int B, int HW, int C, int dtype, void* stream);
 extern "C" int lcgan_scale_reduce_res(void* u, const void* x, const float* sc, float* gs, const void* res, int B, int HW, int C, int dtype, void* stream);
 extern "C" int lcgan_avgpool2(const void* x, void* y, int B, int H, int W, int C, int dtype, void* stream);
+extern "C" int lcgan_conv_fwd_m(const void* x, const void* wp, void* y, int B, int Hin, int Win, int Cin, int Cout, int N, int k, int stride,
+                                const float* pre, const float* post, const float* bias, float bias_scale, int act, float gain, const void* residual,
+                                int residual_half, const void* xs, float* gs, void* pool_out, void* mask_out, int* mask_written, int dtype, void* stream);
 
 namespace {
 
+bool g_mask_written = false;              // set by the launch path that wrote ConvArgs::mask_out in its epilogue
 bool g_pool_written = false;              // set by the launch path that wrote ConvArgs::pool_out in its epilogue (else lcgan_conv_fwd runs the pooling kernel)
 int g_use_halo = 1;                       // lcgan_set_option(0, ...): bf16 halo-tile fast path on/off (A/B testing)
 int g_use_splitk = 1;                     // lcgan_set_option(1, ...): split-K for small-M convolutions
@@ -112,6 +116,7 @@ struct ConvArgs {
   const void* xs; float* gs;                 // fused style-gradient reduction: gs[b,n] += sum_pixels xs[b,p,n] * acc  (xs: [B,Hout,Wout,Cout]; y = post * acc)
   int res_half;                              // residual is [B,Hout/2,Wout/2,Cout]: add 0.25 * residual[oy/2][ox/2] (avg_pool2d adjoint)
   void* pool_out;                            // optional by-product [B,Hout/2,Wout/2,Cout] = avg_pool2d(y, 2) (the next DiscriminatorBlock's skip input)
+  unsigned* mask_out;                        // optional by-product [B*Hout*Wout][Cout/32] words: bit c%32 of word c/32 = (pre-activation > 0), what the activation backward needs of y
   int nsplit; float* ws;                     // split-K: blockIdx.z = phase * nsplit + split; raw fp32 partials are atomically added to ws [M_out pixels][Cout]
   float* slab; int* cnt;                     // split-K of conv_igemm8_kernel: per-(tile, split) partial tiles and per-tile arrival counters (the last split to arrive sums and finishes)
   TapTable taps[4];
@@ -640,6 +645,7 @@ struct HaloArgs {
   const __bf16* x; const __bf16* w; __bf16* y;
   const float* pre; const float* post; const float* bias; const __bf16* residual; int res_half;
   __bf16* pool_out;                          // see ConvArgs (written by the EPI == 1 epilogue)
+  unsigned* mask_out;                        // see ConvArgs (written by the transposed-accumulator epilogue)
   long long w_bstride;                       // elements between the weights of consecutive samples (0 = shared): per-sample modulated weight copies
   const __bf16* xs; float* gs;               // see ConvArgs
   int B, Hin, Win, Cin, Hout, Wout, Cout, Hm, Wm, N, Kpad, kc_per_tap;
@@ -1546,6 +1552,7 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
           }
       }
     }
+    unsigned mw[2][2] = {{0u, 0u}, {0u, 0u}};                                   // sign bits of this lane's pre-activations (a.mask_out)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -1560,6 +1567,7 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
           for (int j = 0; j < 4; ++j) {
             const float t = acc[mi][ni][4 * g + j] * pv[j] + bv[j];
             v[j] = (a.act == ACT_LRELU ? (t > 0.f ? t : t * LRELU_SLOPE) : t) * a.gain;
+            if (EPI == 0) mw[mi][ni] |= (t > 0.f ? 1u : 0u) << (8 * g + 4 * (lane >> 5) + j);
           }
           if (EPI != 0) {
             bf16x4 rr = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
@@ -1574,6 +1582,22 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
           *(bf16x4*)(ot + row * OROW + ch) = o;
         }
       }
+    if (EPI == 0 && a.mask_out) {
+      // activation sign mask: one 32-bit word per (pixel, 32 channels), bit c % 32 = (pre-activation of channel c > 0).  A lane holds the
+      // nibbles 8 g + 4 (lane >> 5) of its pixel's two words (ni); its partner 32 lanes away holds the other nibbles.
+      const int words = a.Cout >> 5;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const unsigned wv = mw[mi][ni] | (unsigned)__shfl_xor((int)mw[mi][ni], 32, 64);
+          const int row = wm * 64 + mi * 32 + (lane & 31);
+          const int py = ty * HT + (row >> 4), px = tx * HT + (row & 15);
+          const int wi = (n0 >> 5) + wn * 2 + ni;
+          if (lane < 32 && py < a.Hm && px < a.Wm && wi < words)
+            a.mask_out[((size_t)(b * a.Hout + py) * a.Wout + px) * words + wi] = wv;
+        }
+    }
   } else {
     auto colconst = [&](int nl, float& bv, float& pv) {              // per output column: bias and demodulation scale
       const int n = n0 + nl;
@@ -2076,6 +2100,8 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   // pooled by-product: the full-resolution-residual epilogue (EPI == 1) of this kernel writes it (every variant below shares that epilogue)
   a.pool_out = (c.pool_out && c.residual && !c.res_half && !c.xs && nphase == 1 && c.out_mul == 1 && !((c.Hout | c.Wout) & 1)) ? (__bf16*)c.pool_out : nullptr;
   a.bias_scale = c.bias_scale; a.gain = c.gain; a.act = c.act;
+  // activation sign mask: written by the transposed-accumulator epilogue of the plain (EPI == 0) variants
+  a.mask_out = (c.mask_out && c.act == ACT_LRELU && !c.xs && !c.residual && nphase == 1 && c.out_mul == 1 && (c.Cout & 31) == 0 && g_mfma16 == 0) ? c.mask_out : nullptr;
   int max_halo = 0, max_halo_elems = 0;
   for (int p = 0; p < nphase; ++p) {
     a.taps[p] = c.taps[p];
@@ -2113,6 +2139,7 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   }
   a.halo_elems = max_halo_elems;
   g_pool_written = a.pool_out != nullptr;                         // (no `return false` below this line)
+  g_mask_written = a.mask_out != nullptr;
   if (a.pre && g_halo_wmod_mb > 0 && c.Cin % 32 == 0 && c.Kpad == c.Cin && c.pre_stride >= c.Cin && g_mfma16 != 1) {
     // taps of the whole prepared weight (9 for a 3x3 kernel whatever the phase structure, 1 for 1x1)
     int wt_max = 0;
@@ -3204,7 +3231,7 @@ __global__ __launch_bounds__(256) void flow_wgrad_kernel(const __bf16* __restric
 int dispatch_igemm(const ConvArgs& a_in, int nphase, int dtype, hipStream_t s) {
   ConvArgs a = a_in;
   a.nsplit = 1; a.ws = nullptr; a.slab = nullptr; a.cnt = nullptr;
-  g_pool_written = false;
+  g_pool_written = false; g_mask_written = false;
   if (dtype == DT_BF16 && g_use_halo && try_launch_halo(a, nphase, a.in_mul, s)) return launch_status();
   if (g_igemm_dma >= 2 && dtype == DT_BF16 && a.pre && a.Cin % 32 == 0 && a.Kpad == a.Cin && a.M >= 256) {   // (with the eight-wave kernel and its slab split-K behind it the pass pays from M = 256: conv family 8.96 -> 8.83 ms at local batch 4, 13.39 -> 13.31 at 8; it was 2048 with the four-wave loop)
     const size_t elems = (size_t)a.B * a.Hin * a.Win * a.Cin;
@@ -3347,12 +3374,26 @@ int lcgan_conv_fwd(const void* x, const void* wp, void* y,
                    const float* pre, const float* post, const float* bias, float bias_scale,
                    int act, float gain, const void* residual, int residual_half, const void* xs, float* gs, void* pool_out,
                    int dtype, void* stream) {
+  return lcgan_conv_fwd_m(x, wp, y, B, Hin, Win, Cin, Cout, N, k, stride, pre, post, bias, bias_scale, act, gain, residual, residual_half, xs, gs,
+                          pool_out, nullptr, nullptr, dtype, stream);
+}
+
+// lcgan_conv_fwd + an optional second by-product: mask_out [B*Hout*Wout][Cout/32] 32-bit words, bit c % 32 of word c / 32 = (pre-activation of
+// channel c > 0) -- all the activation backward needs of y (lcgan_act_bwd_reduce_m / lcgan_box3_actbwd_reduce_m read 1/16 of the bytes).
+// *mask_written = 1 when the launch path wrote it (bf16 halo kernels, leaky ReLU, no residual, Cout % 32 == 0), else 0: use y.
+int lcgan_conv_fwd_m(const void* x, const void* wp, void* y,
+                     int B, int Hin, int Win, int Cin, int Cout, int N, int k, int stride,
+                     const float* pre, const float* post, const float* bias, float bias_scale,
+                     int act, float gain, const void* residual, int residual_half, const void* xs, float* gs, void* pool_out,
+                     void* mask_out, int* mask_written, int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (mask_written) *mask_written = 0;
   if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || (Cin & 7) || (Cout & 7) || N > Cout) return LCGAN_EINVAL;
   if (xs && (!gs || !post || (residual && residual_half) || bias || act != ACT_NONE || gain != 1.f)) return LCGAN_EINVAL;
   ConvArgs a = {};
   a.xs = xs; a.gs = xs ? gs : nullptr;
   a.pool_out = pool_out;
+  a.mask_out = (unsigned*)mask_out;
   a.x = x; a.w = (const __bf16*)wp; a.y = y;
   a.pre = pre; a.post = post; a.bias = bias; a.residual = residual; a.res_half = residual ? residual_half : 0;
   a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin;
@@ -3378,6 +3419,7 @@ int lcgan_conv_fwd(const void* x, const void* wp, void* y,
     ProfScope p(KID_CONV_IGEMM, 2.0 * M * N * Cin * k * k, 0, s, tag);
     rc = dispatch_igemm(a, 1, dtype, s);
   }
+  if (mask_written) *mask_written = (rc == LCGAN_OK && mask_out && g_mask_written) ? 1 : 0;
   // the by-product avg_pool2d(y, 2): written by the epilogue where the launch path has one for it, by the pooling kernel otherwise
   if (rc == LCGAN_OK && pool_out && !g_pool_written) rc = lcgan_avgpool2(y, pool_out, B, a.Hout, a.Wout, Cout, dtype, stream);
   return rc;

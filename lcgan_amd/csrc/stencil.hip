@@ -80,8 +80,12 @@ __global__ void box3_act_kernel(const T* __restrict__ x, T* __restrict__ y, int 
 // activation-backward pass.  Same sliding window as box3_act_kernel, over taller strips (BOXB_RH rows) so that the per-channel
 // bias reduction ends in few global atomics (LDS float atomics inside the block).
 // Strip height: see lcgan_box3_actbwd_reduce (taller strips = fewer same-address atomics, until too few threads are left).
+// mask (optional, instead of y): the activation's sign bits as a convolution epilogue leaves them (lcgan_conv_fwd_m): byte v of a pixel's
+// C / 8 mask bytes holds channels 8 v .. 8 v + 7 -- 1/16 of the bytes of y
+__device__ __forceinline__ float lrelu_grad_bit(unsigned bits, int j, float gain) { return ((bits >> j) & 1u) ? gain : gain * LRELU_SLOPE; }
+
 template <typename T>
-__global__ void box3_actbwd_reduce_kernel(const T* __restrict__ gy, const T* __restrict__ y, T* __restrict__ gz,
+__global__ void box3_actbwd_reduce_kernel(const T* __restrict__ gy, const T* __restrict__ y, const unsigned char* __restrict__ mask, T* __restrict__ gz,
                                           float* __restrict__ gbias, int B, int H, int W, int C, int Clog, int act, float gain,
                                           int BOXB_RH) {
   extern __shared__ float red[];                       // [C]
@@ -119,12 +123,21 @@ __global__ void box3_actbwd_reduce_kernel(const T* __restrict__ gy, const T* __r
     for (int hh = h0; hh < h1; ++hh) {
       const F8 r2 = rowsum(hh + 1);
       const size_t off = (((size_t)b * H + hh) * W + w) * C + v * 8;
-      const F8 yo = Feat<T>::load(y + off);
       F8 o;
+      if (mask) {
+        const unsigned bits = mask[off >> 3];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        o.v[j] = (r0.v[j] + r1.v[j] + r2.v[j]) * (1.f / 9.f) * act_grad_from_out(yo.v[j], act, gain);
-        sb[j] += o.v[j];
+        for (int j = 0; j < 8; ++j) {
+          o.v[j] = (r0.v[j] + r1.v[j] + r2.v[j]) * (1.f / 9.f) * lrelu_grad_bit(bits, j, gain);
+          sb[j] += o.v[j];
+        }
+      } else {
+        const F8 yo = Feat<T>::load(y + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          o.v[j] = (r0.v[j] + r1.v[j] + r2.v[j]) * (1.f / 9.f) * act_grad_from_out(yo.v[j], act, gain);
+          sb[j] += o.v[j];
+        }
       }
       Feat<T>::store(gz + off, o);
       r0 = r1; r1 = r2;
@@ -326,7 +339,7 @@ __global__ void avgpool2_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx
 // GDQ: the demodulation statistic is wanted as well (modulated convolutions only); the plain case carries neither its second
 // accumulator set nor its arithmetic (128 -> fewer registers, one more wave per SIMD).
 template <typename T, bool GDQ>
-__global__ void act_bwd_reduce_kernel(const T* __restrict__ gy, const T* __restrict__ y, T* __restrict__ gz,
+__global__ void act_bwd_reduce_kernel(const T* __restrict__ gy, const T* __restrict__ y, const unsigned char* __restrict__ mask, T* __restrict__ gz,
                                       const float* __restrict__ bias, float bias_scale,
                                       float* __restrict__ gbias, float* __restrict__ gdq,
                                       int HW, int C, int Clog, int act, float gain, int P) {
@@ -361,8 +374,32 @@ __global__ void act_bwd_reduce_kernel(const T* __restrict__ gy, const T* __restr
       }
       if (gz) Feat<T>::store(gz + off, z);
     };
+    // the same with the activation's sign bits instead of y (leaky ReLU, no demodulation statistic): 1 mask byte per 16 bytes of gy
+    auto one_m = [&](size_t off, const F8& g, unsigned bits) {
+      F8 z;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { z.v[j] = g.v[j] * lrelu_grad_bit(bits, j, gain); sb[j] += z.v[j]; }
+      if (gz) Feat<T>::store(gz + off, z);
+    };
     // four pixels per trip: all eight loads are issued before the first is used (a thread otherwise has one pixel in flight)
     int p = p0 + grp;
+    if (!GDQ && mask) {
+      for (; p + 3 * groups < p1; p += 4 * groups) {
+        size_t off[4]; F8 g[4]; unsigned bits[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          off[u] = ((size_t)b * HW + p + u * groups) * C + v * 8;
+          g[u] = Feat<T>::load(gy + off[u]);
+          bits[u] = mask[off[u] >> 3];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one_m(off[u], g[u], bits[u]);
+      }
+      for (; p < p1; p += groups) {
+        const size_t off = ((size_t)b * HW + p) * C + v * 8;
+        one_m(off, Feat<T>::load(gy + off), mask[off >> 3]);
+      }
+    } else {
     for (; p + 3 * groups < p1; p += 4 * groups) {
       size_t off[4]; F8 g[4], yo[4];
 #pragma unroll
@@ -379,6 +416,7 @@ __global__ void act_bwd_reduce_kernel(const T* __restrict__ gy, const T* __restr
       const F8 g = Feat<T>::load(gy + off);
       const F8 yo = need_y ? Feat<T>::load(y + off) : f8_zero();
       one(off, g, yo);
+    }
     }
   }
   if (!gbias && !GDQ) return;
@@ -1412,6 +1450,10 @@ int reduce_P(int HW, int B) {           // pixels per block for the reduction ke
   else return LCGAN_EINVAL;
 
 extern "C" {
+int lcgan_act_bwd_reduce_m(const void* gy, const void* y, const void* mask, void* gz, const float* bias, float bias_scale,
+                           float* gbias, float* gdq, int B, int HW, int C, int Clog, int act, float gain, int dtype, void* stream);
+int lcgan_box3_actbwd_reduce_m(const void* gy, const void* y, const void* mask, void* gz, float* gbias, int B, int H, int W, int C, int Clog,
+                               int act, float gain, int dtype, void* stream);
 
 int lcgan_box3_act(const void* x, void* y, int B, int H, int W, int C, int act, float gain, int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -1442,17 +1484,23 @@ int lcgan_box3_act_bwd(const void* gy, const void* y, void* gx, int B, int H, in
 // gz = box3(gy) * act'(y) ; gbias[c] += sum gz (gbias may be NULL; accumulated, must be zeroed by the caller)
 int lcgan_box3_actbwd_reduce(const void* gy, const void* y, void* gz, float* gbias, int B, int H, int W, int C, int Clog,
                              int act, float gain, int dtype, void* stream) {
+  return lcgan_box3_actbwd_reduce_m(gy, y, nullptr, gz, gbias, B, H, W, C, Clog, act, gain, dtype, stream);
+}
+int lcgan_box3_actbwd_reduce_m(const void* gy, const void* y, const void* mask, void* gz, float* gbias, int B, int H, int W, int C, int Clog,
+                               int act, float gain, int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if ((C & 7) || Clog > C) return LCGAN_EINVAL;
+  if (mask && act != ACT_LRELU) return LCGAN_EINVAL;
   const long long n = (long long)B * H * W * (C / 8);
-  Tag tg("box3_actbwd_reduce", B, H, W, C);
-  ProfScope p(KID_ACT_BWD, 0, (double)n * 8 * 3 * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
+  Tag tg(mask ? "box3_actbwd_reduce(mask)" : "box3_actbwd_reduce", B, H, W, C);
+  const double esz = dtype == DT_BF16 ? 2 : 4;
+  ProfScope p(KID_ACT_BWD, 0, (double)n * 8 * (2 * esz + (mask ? 0.125 : esz)), s, tg.s);
   // strip height: the tallest that still leaves ~128K (32 rows) / ~64K (16 rows) threads (scripts/ab_boxb.py: 77 -> 48 us at
   // 4 x 256 x 256 x 128, 43 -> 35 us at 32 x 32 x 32 x 512; below that 8 rows win)
   const int rh = n / 32 >= (1 << 17) ? 32 : (n / 16 >= (1 << 16) ? 16 : 8);
   const long long nthr = (long long)B * ((H + rh - 1) / rh) * W * (C / 8);
   DISPATCH_T(dtype, hipLaunchKernelGGL(box3_actbwd_reduce_kernel<T>, grid1d(nthr), dim3(TPB), C * sizeof(float), s, (const T*)gy,
-                                       (const T*)y, (T*)gz, gbias, B, H, W, C, Clog, act, gain, rh));
+                                       (const T*)y, (const unsigned char*)mask, (T*)gz, gbias, B, H, W, C, Clog, act, gain, rh));
   return launch_status();
 }
 
@@ -1499,15 +1547,23 @@ int lcgan_avgpool2_bwd(const void* gy, void* gx, int B, int H, int W, int C, int
 // gz may be NULL (reductions only); gbias / gdq may be NULL.  gbias: [Clog], gdq: [B][C] -- both accumulated (+=).
 int lcgan_act_bwd_reduce(const void* gy, const void* y, void* gz, const float* bias, float bias_scale,
                          float* gbias, float* gdq, int B, int HW, int C, int Clog, int act, float gain, int dtype, void* stream) {
+  return lcgan_act_bwd_reduce_m(gy, y, nullptr, gz, bias, bias_scale, gbias, gdq, B, HW, C, Clog, act, gain, dtype, stream);
+}
+// ... with the activation's sign mask (lcgan_conv_fwd_m) instead of y: mask != NULL needs act == leaky ReLU and no gdq; y may then be NULL
+int lcgan_act_bwd_reduce_m(const void* gy, const void* y, const void* mask, void* gz, const float* bias, float bias_scale,
+                           float* gbias, float* gdq, int B, int HW, int C, int Clog, int act, float gain, int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if ((C & 7) || C / 8 > TPB || Clog > C) return LCGAN_EINVAL;
+  if (mask && (act != ACT_LRELU || gdq)) return LCGAN_EINVAL;
   const int P = reduce_P(HW, B);
   dim3 grid(cdiv(HW, P), B);
-  Tag tg(gdq ? (gz ? "act_bwd_reduce+gdq" : "act_reduce+gdq") : (gz ? "act_bwd_reduce" : "act_reduce"), B, HW, 1, C);
-  ProfScope p(KID_ACT_BWD, 0, (double)B * HW * C * (gz ? 3 : 2) * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
-  if (gdq) { DISPATCH_T(dtype, hipLaunchKernelGGL((act_bwd_reduce_kernel<T, true>), grid, dim3(TPB), 0, s, (const T*)gy, (const T*)y, (T*)gz,
+  const unsigned char* mk = (const unsigned char*)mask;
+  Tag tg(gdq ? (gz ? "act_bwd_reduce+gdq" : "act_reduce+gdq") : (gz ? (mask ? "act_bwd_reduce(mask)" : "act_bwd_reduce") : "act_reduce"), B, HW, 1, C);
+  const double esz = dtype == DT_BF16 ? 2 : 4;
+  ProfScope p(KID_ACT_BWD, 0, (double)B * HW * C * ((gz ? 2 : 1) * esz + (mask ? 0.125 : esz)), s, tg.s);
+  if (gdq) { DISPATCH_T(dtype, hipLaunchKernelGGL((act_bwd_reduce_kernel<T, true>), grid, dim3(TPB), 0, s, (const T*)gy, (const T*)y, mk, (T*)gz,
                                                  bias, bias_scale, gbias, gdq, HW, C, Clog, act, gain, P)); }
-  else { DISPATCH_T(dtype, hipLaunchKernelGGL((act_bwd_reduce_kernel<T, false>), grid, dim3(TPB), 0, s, (const T*)gy, (const T*)y, (T*)gz,
+  else { DISPATCH_T(dtype, hipLaunchKernelGGL((act_bwd_reduce_kernel<T, false>), grid, dim3(TPB), 0, s, (const T*)gy, (const T*)y, mk, (T*)gz,
                                               bias, bias_scale, gbias, gdq, HW, C, Clog, act, gain, P)); }
   return launch_status();
 }

@@ -181,7 +181,7 @@ class HipKernels:
 
     def conv_fwd(self, x: Tensor, pw: PreparedWeight, N: int, k: int, stride: int, pre=None, post=None, bias=None,
                  bias_scale: float = 1.0, act: int = ACT_NONE, gain: float = 1.0, residual=None, residual_half: bool = False,
-                 xs: Optional[Tensor] = None, pool: bool = False):
+                 xs: Optional[Tensor] = None, pool: bool = False, want_mask: bool = False):
         """xs given (needs post, no bias/act): returns (y = post * u [+ residual], gs[b,n] = sum_pixels xs * u), u = the unscaled result;
         pool: returns (y, avg_pool2d(y, 2)) -- the by-product a DiscriminatorBlock's closing convolution leaves for the next block"""
         self._chk(x, pre, post, bias, residual, xs)
@@ -192,6 +192,18 @@ class HipKernels:
         gs = self._zeros.take((B, Cout), x.device) if xs is not None else None
         pooled = torch.empty((B, Ho // 2, Wo // 2, Cout), dtype=x.dtype, device=x.device) if pool else None
         assert pw.parts == (3 if x.dtype == torch.float32 else 1) and not (pool and xs is not None)
+        if want_mask:
+            # want_mask: returns (y, mask | None) -- the activation's sign bits as a by-product of the epilogue ([B*Ho*Wo, Cout/8] bytes), where
+            # the launch path can write them (lcgan_conv_fwd_m); None: the activation backward keeps reading y
+            assert not pool and xs is None
+            import ctypes as C
+            mask, wrote = None, C.c_int(0)
+            if act == ACT_LRELU and x.dtype == torch.bfloat16 and Cout % 32 == 0 and residual is None:
+                mask = torch.empty((B * Ho * Wo, Cout // 8), dtype=torch.uint8, device=x.device)
+            self._call("lcgan_conv_fwd_m", x.data_ptr(), pw.buf.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, N, k, stride,
+                       _p(pre), _p(post), _p(bias), float(bias_scale), act, float(gain), _p(residual), int(residual_half), None, None,
+                       None, _p(mask), C.addressof(wrote), dt_code(x.dtype), self._stream())
+            return y, (mask if wrote.value else None)
         self._call("lcgan_conv_fwd", x.data_ptr(), pw.buf.data_ptr(), y.data_ptr(), B, H, W, Cin, Cout, N, k, stride,
                    _p(pre), _p(post), _p(bias), float(bias_scale), act, float(gain), _p(residual), int(residual_half), _p(xs), _p(gs),
                    _p(pooled), dt_code(x.dtype), self._stream())
@@ -288,13 +300,13 @@ class HipKernels:
                    self._stream())
         return gx
 
-    def box3_actbwd(self, gy: Tensor, y: Tensor, act: int, gain: float, clog: int, want_gbias: bool):
-        """-> (gz = box3(gy) * act'(y), gbias [clog] | None)"""
-        self._chk(gy, y)
+    def box3_actbwd(self, gy: Tensor, y: Tensor, act: int, gain: float, clog: int, want_gbias: bool, mask: Optional[Tensor] = None):
+        """-> (gz = box3(gy) * act'(y), gbias [clog] | None); mask: the activation's sign bits (conv_fwd(want_mask=True)) read instead of y"""
+        self._chk(gy, y, mask)
         B, H, W, Cc = gy.shape
         gz = torch.empty_like(gy)
         gbias = self._zeros.take((clog,), gy.device) if want_gbias else None
-        self._call("lcgan_box3_actbwd_reduce", gy.data_ptr(), y.data_ptr(), gz.data_ptr(), _p(gbias), B, H, W, Cc, clog, act,
+        self._call("lcgan_box3_actbwd_reduce_m", gy.data_ptr(), y.data_ptr(), _p(mask), gz.data_ptr(), _p(gbias), B, H, W, Cc, clog, act,
                    float(gain), dt_code(gy.dtype), self._stream())
         return gz, gbias
 
@@ -327,14 +339,15 @@ class HipKernels:
         return gx
 
     def act_bwd_reduce(self, gy: Tensor, y: Optional[Tensor], act: int, gain: float, clog: int, want_gz: bool = True,
-                       bias: Optional[Tensor] = None, bias_scale: float = 1.0, want_gbias: bool = False, want_gdq: bool = False):
-        """-> (gz | None, gbias [clog] | None, gdq [B, C] | None)"""
-        self._chk(gy, y, bias)
+                       bias: Optional[Tensor] = None, bias_scale: float = 1.0, want_gbias: bool = False, want_gdq: bool = False,
+                       mask: Optional[Tensor] = None):
+        """-> (gz | None, gbias [clog] | None, gdq [B, C] | None); mask: the activation's sign bits read instead of y (no gdq)"""
+        self._chk(gy, y, bias, mask)
         B, H, W, Cc = gy.shape
         gz = torch.empty_like(gy) if want_gz else None
         gbias = self._zeros.take((clog,), gy.device) if want_gbias else None
         gdq = self._zeros.take((B, Cc), gy.device) if want_gdq else None
-        self._call("lcgan_act_bwd_reduce", gy.data_ptr(), _p(y), _p(gz), _p(bias), float(bias_scale), _p(gbias), _p(gdq),
+        self._call("lcgan_act_bwd_reduce_m", gy.data_ptr(), _p(y), _p(mask if not want_gdq else None), _p(gz), _p(bias), float(bias_scale), _p(gbias), _p(gdq),
                    B, H * W, Cc, clog, act, float(gain), dt_code(gy.dtype), self._stream())
         return gz, gbias, gdq
 

@@ -206,6 +206,11 @@ def _prep(w: Tensor, scale: float, transpose: bool, need_lo: bool, want_wsq: boo
     return hit
 
 
+def _act_masks() -> bool:
+    from . import config
+    return config.act_masks()
+
+
 def _use_fp8(x: Tensor, k: int, stride: int) -> bool:
     """MX-fp8 operands for this convolution launch?  (config.conv_operands() == "fp8": BASELINE configs[4]; the stride-1 3x3 / 1x1 forward
     and data-gradient launches on grids of at least 16 x 16 positions -- 60 % of the step's FLOPs; everything else stays bf16)"""
@@ -229,13 +234,18 @@ class Conv2dFn(Function):
         assert act != ACT_NONE or gain == 1.0, "fold the gain of an act-free conv into wscale"
         K = _K()
         A = w.shape[0]
+        mask = None
         if _use_fp8(x, k, stride):
             pw, _ = _prep(w, wscale, False, False, fp8=True)
             y = K.conv_fwd_fp8(x, pw, A, k, stride, bias=bias, bias_scale=bias_scale, act=act, gain=gain, residual=residual)
         else:
             pw, _ = _prep(w, wscale, False, _need_lo(x))
-            y = K.conv_fwd(x, pw, A, k, stride, bias=bias, bias_scale=bias_scale, act=act, gain=gain, residual=residual)
-        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+            if act == ACT_LRELU and residual is None and _act_masks():
+                # the sign mask of the pre-activation leaves the epilogue as a by-product: the activation backward reads it (1/16 of y's bytes)
+                y, mask = K.conv_fwd(x, pw, A, k, stride, bias=bias, bias_scale=bias_scale, act=act, gain=gain, want_mask=True)
+            else:
+                y = K.conv_fwd(x, pw, A, k, stride, bias=bias, bias_scale=bias_scale, act=act, gain=gain, residual=residual)
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None, mask)
         ctx.cfg = (k, stride, act, gain, wscale, bias_scale, bias is not None, residual is not None)
         return y
 
@@ -243,13 +253,13 @@ class Conv2dFn(Function):
     def backward(ctx, gy):
         if gy is None:                                     # (Conv2dPoolFn runs without materialised gradients)
             return (None,) * 10
-        x, w, y = ctx.saved_tensors
+        x, w, y, mask = ctx.saved_tensors
         k, stride, act, gain, wscale, bias_scale, has_bias, has_res = ctx.cfg
         gy = gy.contiguous()
         A = w.shape[0]
         want_gb = has_bias and _wants(ctx, 2)
         if act != ACT_NONE or want_gb:
-            gz, gb = _ap(ActBwdFn, gy, y, act, gain, A, want_gb, bias_scale)
+            gz, gb = _ap(ActBwdFn, gy, y, act, gain, A, want_gb, bias_scale, mask)
         else:
             gz, gb = gy, None
         gx = _ap(ConvTransposeFn, gz, w, k, stride, wscale, x.shape[-1], None) if ctx.needs_input_grad[0] else None
@@ -270,7 +280,7 @@ class Conv2dPoolFn(Function):
         K = _K()
         pw, _ = _prep(w, wscale, False, _need_lo(x))
         y, pooled = K.conv_fwd(x, pw, w.shape[0], k, stride, bias=bias, bias_scale=bias_scale, act=act, gain=gain, residual=residual, pool=True)
-        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None, None)
         ctx.cfg = (k, stride, act, gain, wscale, bias_scale, bias is not None, residual is not None)
         ctx.mark_non_differentiable(pooled)
         ctx.set_materialize_grads(False)        # (autograd would otherwise FILL a zero gradient of pooled's size for every backward pass)
@@ -321,20 +331,24 @@ class ConvPoolFn(Function):
     def forward(ctx, x, w, bias, k, act, gain, wscale, bias_scale, box, pooled_hint=None):
         """pooled_hint: avg_pool2d(x, 2) where the producer of x already left it (Conv2dPoolFn, RGBExpandFn(pool=True)): the pooling pass is skipped"""
         K = _K()
+        mask = None
         if _use_fp8(x, k, 1):
             pw, _ = _prep(w, wscale, False, False, fp8=True)
             y = K.conv_fwd_fp8(x, pw, w.shape[0], k, 1, bias=bias, bias_scale=bias_scale, act=act, gain=gain)
         else:
             pw, _ = _prep(w, wscale, False, _need_lo(x))
-            y = K.conv_fwd(x, pw, w.shape[0], k, 1, bias=bias, bias_scale=bias_scale, act=act, gain=gain)
-        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+            if act == ACT_LRELU and _act_masks():
+                y, mask = K.conv_fwd(x, pw, w.shape[0], k, 1, bias=bias, bias_scale=bias_scale, act=act, gain=gain, want_mask=True)
+            else:
+                y = K.conv_fwd(x, pw, w.shape[0], k, 1, bias=bias, bias_scale=bias_scale, act=act, gain=gain)
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None, mask)
         ctx.cfg = (k, act, gain, wscale, bias_scale, bias is not None, box)
         pooled = K.avgpool2(x) if pooled_hint is None else pooled_hint.detach().view_as(pooled_hint)
         return (K.box3_act(y, ACT_NONE, 1.0) if box else y), pooled
 
     @staticmethod
     def backward(ctx, gy, gpooled):
-        x, w, y = ctx.saved_tensors
+        x, w, y, mask = ctx.saved_tensors
         k, act, gain, wscale, bias_scale, has_bias, box = ctx.cfg
         A = w.shape[0]
         want_gb = has_bias and _wants(ctx, 2)
@@ -343,12 +357,12 @@ class ConvPoolFn(Function):
             return gx, None, None, None, None, None, None, None, None, None
         gy = gy.contiguous()
         if box and act != ACT_NONE:
-            gz, gb = _ap(BoxActBwdFn, gy, y, act, gain, A, want_gb, bias_scale)
+            gz, gb = _ap(BoxActBwdFn, gy, y, act, gain, A, want_gb, bias_scale, mask)
         else:
             if box:
                 gy = _ap(Box3Fn, gy)
             if act != ACT_NONE or want_gb:
-                gz, gb = _ap(ActBwdFn, gy, y, act, gain, A, want_gb, bias_scale)
+                gz, gb = _ap(ActBwdFn, gy, y, act, gain, A, want_gb, bias_scale, mask)
             else:
                 gz, gb = gy, None
         gx = None
@@ -362,8 +376,8 @@ class BoxActBwdFn(Function):
     """(gz, gbias) = (box3(gy) * act'(y), bias_scale * sum gz): backward of  act(.) -> box3  in one pass.  Linear in gy."""
 
     @staticmethod
-    def forward(ctx, gy, y, act, gain, clog, want_gbias, bias_scale):
-        gz, gb = _K().box3_actbwd(gy, y, act, gain, clog, want_gbias)
+    def forward(ctx, gy, y, act, gain, clog, want_gbias, bias_scale, mask=None):
+        gz, gb = _K().box3_actbwd(gy, y, act, gain, clog, want_gbias, mask=mask)
         if gb is None:
             gb = gy.new_empty((0,), dtype=torch.float32)
         else:
@@ -380,8 +394,8 @@ class BoxActBwdFn(Function):
         (y,) = ctx.saved_tensors
         act, gain = ctx.cfg
         if ggz is None:
-            return None, None, None, None, None, None, None
-        return _K().box3_act_bwd(ggz.contiguous(), y, act, gain), None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
+        return _K().box3_act_bwd(ggz.contiguous(), y, act, gain), None, None, None, None, None, None, None
 
 
 class ConvWeightGradFn(Function):
@@ -409,18 +423,19 @@ class ActBwdFn(Function):
     """(gz, gbias) = (gy * act'(y), bias_scale * sum_{b,h,w} gz).  Linear in gy; y is the saved activation OUTPUT."""
 
     @staticmethod
-    def forward(ctx, gy, y, act, gain, clog, want_gbias, bias_scale):
+    def forward(ctx, gy, y, act, gain, clog, want_gbias, bias_scale, mask=None):
+        """mask: the activation's sign bits where the producing convolution left them (Conv2dFn / ConvPoolFn): read instead of y"""
         K = _K()
         if act == ACT_NONE:
             _, gb, _ = K.act_bwd_reduce(gy, None, ACT_NONE, 1.0, clog, want_gz=False, want_gbias=want_gbias)
             gz = gy
         else:
-            gz, gb, _ = K.act_bwd_reduce(gy, y, act, gain, clog, want_gz=True, want_gbias=want_gbias)
+            gz, gb, _ = K.act_bwd_reduce(gy, y, act, gain, clog, want_gz=True, want_gbias=want_gbias, mask=mask)
         if gb is None:
             gb = gy.new_empty((0,), dtype=torch.float32)
         else:
             gb = gb * bias_scale if bias_scale != 1.0 else gb
-        ctx.save_for_backward(y)
+        ctx.save_for_backward(y, mask)
         ctx.cfg = (act, gain, clog)
         ctx.mark_non_differentiable(gb)
         ctx.set_materialize_grads(False)
@@ -428,12 +443,12 @@ class ActBwdFn(Function):
 
     @staticmethod
     def backward(ctx, ggz, _ggb):
-        (y,) = ctx.saved_tensors
+        y, mask = ctx.saved_tensors
         act, gain, clog = ctx.cfg
         if act == ACT_NONE or ggz is None:
-            return ggz, None, None, None, None, None, None
-        g, _ = _ap(ActBwdFn, ggz.contiguous(), y, act, gain, clog, False, 1.0)
-        return g, None, None, None, None, None, None
+            return ggz, None, None, None, None, None, None, None
+        g, _ = _ap(ActBwdFn, ggz.contiguous(), y, act, gain, clog, False, 1.0, mask)
+        return g, None, None, None, None, None, None, None
 
 
 class Box3Fn(Function):

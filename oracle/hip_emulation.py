@@ -141,7 +141,10 @@ class EmulatedKernels:
         return y, gs
 
     def conv_fwd(self, x, pw, N, k, stride, pre=None, post=None, bias=None, bias_scale=1.0, act=ACT_NONE, gain=1.0, residual=None,
-                 residual_half=False, xs=None, pool=False):
+                 residual_half=False, xs=None, pool=False, want_mask=False):
+        if want_mask:                                         # (y, sign mask of the pre-activation | None): see kernels.HipKernels.conv_fwd
+            y = self.conv_fwd(x, pw, N, k, stride, pre, post, bias, bias_scale, act, gain, residual, residual_half)
+            return y, ((y > 0) if (act == ACT_LRELU and residual is None) else None)
         if pool:                                              # by-product avg_pool2d(y, 2) of the values as stored
             y = self.conv_fwd(x, pw, N, k, stride, pre, post, bias, bias_scale, act, gain, residual, residual_half, xs)
             return y, self.avgpool2(y)
@@ -223,8 +226,9 @@ class EmulatedKernels:
     def box3_act(self, x, act, gain):
         return nhwc(act_fwd(F.avg_pool2d(nchw(x), 3, 1, 1), act) * gain, x.dtype)
 
-    def box3_actbwd(self, gy, y, act, gain, clog, want_gbias):
-        gz = F.avg_pool2d(nchw(gy), 3, 1, 1) * act_grad_from_out(nchw(y), act, gain)
+    def box3_actbwd(self, gy, y, act, gain, clog, want_gbias, mask=None):
+        ag = act_grad_from_out(nchw(y), act, gain) if mask is None else torch.where(nchw(mask) > 0, 1.0, SLOPE) * gain
+        gz = F.avg_pool2d(nchw(gy), 3, 1, 1) * ag
         gb = gz[:, :clog].sum(dim=(0, 2, 3)) if want_gbias else None
         return nhwc(gz, gy.dtype), gb
 
@@ -253,10 +257,14 @@ class EmulatedKernels:
     def avgpool2_bwd(self, gy):
         return nhwc(F.interpolate(nchw(gy), scale_factor=2, mode="nearest") * 0.25, gy.dtype)
 
-    def act_bwd_reduce(self, gy, y, act, gain, clog, want_gz=True, bias=None, bias_scale=1.0, want_gbias=False, want_gdq=False):
+    def act_bwd_reduce(self, gy, y, act, gain, clog, want_gz=True, bias=None, bias_scale=1.0, want_gbias=False, want_gdq=False, mask=None):
         g = gy.float()
         yo = y.float() if y is not None else None
-        z = g * act_grad_from_out(yo, act, gain) if act != ACT_NONE else g * gain
+        if mask is not None and not want_gdq:
+            assert act == ACT_LRELU
+            z = g * torch.where(mask, 1.0, SLOPE) * gain
+        else:
+            z = g * act_grad_from_out(yo, act, gain) if act != ACT_NONE else g * gain
         gz = z.to(gy.dtype) if want_gz else None
         gbias = z.sum(dim=(0, 1, 2))[:clog].contiguous() if want_gbias else None
         gdq = None

@@ -1094,3 +1094,36 @@ def test_conv_fp8(H, case):
         for kw in (dict(), dict(pre=post, post=pre), dict(residual=rh, residual_half=True)):
             got = H.conv_bwd_data_fp8(g.cuda(), pwT_h, Ci, k, stride, **{a: dev(b) if isinstance(b, torch.Tensor) else b for a, b in kw.items()})
             check(got, E.conv_bwd_data_fp8(g, pwT_e, Ci, k, stride, **kw), dtype, f"fp8 dgrad {sorted(kw)}")
+
+
+@pytest.mark.parametrize("case", [(4, 64, 64, 128, 128, 1), (2, 64, 64, 128, 256, 2), (2, 32, 32, 512, 512, 1), (3, 48, 40, 64, 96, 1)])
+def test_activation_sign_masks(H, case):
+    """lcgan_conv_fwd_m leaves the leaky-ReLU sign bits of its pre-activations as a by-product (bit j of byte v of a pixel = channel 8 v + j);
+    the activation-backward kernels reading the mask give bit for bit what they give reading y (custom_layers.py:205,208)."""
+    B, Hh, W, Ci, Co, stride = case
+    dtype, k = torch.bfloat16, 3
+    x = feat((B, Hh, W, ceil8(Ci)), dtype, 1, Ci)
+    w = torch.randn(Co, Ci, k, k, generator=torch.Generator().manual_seed(2))
+    bias = torch.randn(Co, generator=torch.Generator().manual_seed(3))
+    pw, _ = H.prep_weight(w.cuda(), 1 / math.sqrt(Ci * k * k), False, False)
+    old6 = H.lib.lcgan_set_option(6, 1)                           # (small grids may take the halo kernels)
+    try:
+        y, mask = H.conv_fwd(x.cuda(), pw, Co, k, stride, bias=bias.cuda(), bias_scale=0.5, act=1, gain=1.4, want_mask=True)
+        y0 = H.conv_fwd(x.cuda(), pw, Co, k, stride, bias=bias.cuda(), bias_scale=0.5, act=1, gain=1.4)
+    finally:
+        H.lib.lcgan_set_option(6, old6)
+    assert torch.equal(y, y0)
+    if Co % 32:
+        assert mask is None                                       # (96 channels: no whole mask words -> the caller keeps using y)
+        return
+    assert mask is not None and mask.shape == (y.shape[0] * y.shape[1] * y.shape[2], Co // 8)
+    bits = (y.reshape(-1, Co // 8, 8) > 0).to(torch.int32)
+    want = (bits << torch.arange(8, device="cuda", dtype=torch.int32)).sum(-1).to(torch.uint8)
+    assert torch.equal(mask, want)
+    gy = feat(tuple(y.shape), dtype, 9, Co).cuda()
+    a = H.act_bwd_reduce(gy, y, 1, 1.4, Co, want_gz=True, want_gbias=True)
+    b = H.act_bwd_reduce(gy, y, 1, 1.4, Co, want_gz=True, want_gbias=True, mask=mask)
+    assert torch.equal(a[0], b[0]) and torch.allclose(a[1], b[1], rtol=1e-5, atol=1e-5 * float(a[1].abs().max()))
+    a = H.box3_actbwd(gy, y, 1, 1.4, Co, True)
+    b = H.box3_actbwd(gy, y, 1, 1.4, Co, True, mask=mask)
+    assert torch.equal(a[0], b[0]) and torch.allclose(a[1], b[1], rtol=1e-5, atol=1e-5 * float(a[1].abs().max()))
