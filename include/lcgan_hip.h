@@ -144,6 +144,11 @@ int lcgan_rgb_wgrad(const float* img, const void* feat, float* gw, int B, int HW
  *   gbias += sum gz, gdq[b,c] += sum_p gz (ypre - bias) (the demodulation statistic of ModulatedConv2d), gwm += sum_p gimg y. */
 int lcgan_rgb_expand_bwd(const void* gy, const void* y, const float* img, const float* w, float* gimg, float* gw, float* gbias,
                          int B, int HW, int C, int Clog, int per_sample, int act, float gain, int dtype, void* stream);
+/* ... recompute = 1 (leaky ReLU, img != NULL): the sign the activation backward needs is recomputed from the image, the weights and the
+ * forward layer's bias (fbias * fbias_scale; may be NULL) -- cnn.py:20-21 is a 3-term dot product per channel -- and y is not read. */
+int lcgan_rgb_expand_bwd_r(const void* gy, const void* y, const float* img, const float* w, const float* fbias, float fbias_scale, int recompute,
+                           float* gimg, float* gw, float* gbias,
+                           int B, int HW, int C, int Clog, int per_sample, int act, float gain, int dtype, void* stream);
 int lcgan_rgb_reduce_bwd_act(const float* gimg, const void* y, const float* wm, const float* bias, float bias_scale, void* gz,
                              float* gbias, float* gdq, float* gwm, int B, int HW, int C, int Clog, int per_sample, int act, float gain,
                              int dtype, void* stream);

@@ -45,6 +45,7 @@ SIGNATURES = {
     "lcgan_rgb_reduce": [P, P, P, F, P, I, I, I, I, I, P],
     "lcgan_rgb_wgrad": [P, P, P, I, I, I, I, I, P],
     "lcgan_rgb_expand_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, F, I, P],
+    "lcgan_rgb_expand_bwd_r": [P, P, P, P, P, F, I, P, P, P, I, I, I, I, I, I, F, I, P],
     "lcgan_rgb_reduce_bwd_act": [P, P, P, P, F, P, P, P, P, I, I, I, I, I, I, F, I, P],
     "lcgan_flow_col2im": [P, P, P, P, I, I, I, I, I, P],
     "lcgan_flow_im2col": [P, P, P, I, I, I, I, I, P],

@@ -1246,9 +1246,12 @@ __global__ void flow_im2col_kernel(const T* __restrict__ gu, const float* __rest
 //   gw[bw,o,c]  += sum_p img[b,o,p] gz[b,p,c]           (optional)
 //   gbias[c]    += sum_{b,p} gz[b,p,c]                   (optional)
 // One block = P consecutive pixels of one sample; a pixel's channel vectors sit in adjacent lanes of one wave.
-template <typename T, int ACT>
+// RECOMP (leaky ReLU, img given): the sign of the pre-activation is RECOMPUTED from the image -- t = i0 w0 + i1 w1 + i2 w2 + bias, the
+// forward kernel's own expression on operands this kernel holds anyway -- instead of read back from y: half of the kernel's bytes.
+template <typename T, int ACT, bool RECOMP = false>
 __global__ void rgb_expand_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ y, const float* __restrict__ img,
-                                      const float* __restrict__ w, float* __restrict__ gimg, float* __restrict__ gw,
+                                      const float* __restrict__ w, const float* __restrict__ fbias, float fbias_scale,
+                                      float* __restrict__ gimg, float* __restrict__ gw,
                                       float* __restrict__ gbias, int HW, int C, int Clog, int per_sample, int act_rt, float gain, int P) {
   const int act = ACT >= 0 ? ACT : act_rt;
   __shared__ float red[4][TPB * 8];
@@ -1257,18 +1260,19 @@ __global__ void rgb_expand_bwd_kernel(const T* __restrict__ gy, const T* __restr
   const int grp = threadIdx.x / nvec, v = threadIdx.x - grp * nvec;
   const int b = blockIdx.y;
   const float* wb = w + (per_sample ? (size_t)b * 3 * C : 0);
-  float w0[8], w1[8], w2[8], a0[8], a1[8], a2[8], sb[8], cm[8];
+  float w0[8], w1[8], w2[8], a0[8], a1[8], a2[8], sb[8], cm[8], fb[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = v * 8 + j;
     w0[j] = wb[c]; w1[j] = wb[C + c]; w2[j] = wb[2 * C + c];
     a0[j] = 0.f; a1[j] = 0.f; a2[j] = 0.f; sb[j] = 0.f;
     cm[j] = c < Clog ? 1.f : 0.f;                            // padding channels carry no gradient
+    fb[j] = (RECOMP && fbias && c < Clog) ? fbias[c] * fbias_scale : 0.f;
   }
   const int p0 = blockIdx.x * P, p1 = min(p0 + P, HW);
   const float* ib = img + (size_t)b * 3 * HW;
   float* gib = gimg ? gimg + (size_t)b * 3 * HW : nullptr;
-  const bool need_img = gw != nullptr;
+  const bool need_img = RECOMP || gw != nullptr;
   for (int pb = p0; pb < p1; pb += 2 * groups) {             // two pixels per trip: their loads are issued together
     F8 g[2], yo[2];
     float im[2][3];
@@ -1279,7 +1283,7 @@ __global__ void rgb_expand_bwd_kernel(const T* __restrict__ gy, const T* __restr
       live[u] = p < p1;
       const size_t off = ((size_t)b * HW + (live[u] ? p : p0)) * C + v * 8;
       g[u] = Feat<T>::load(gy + off);
-      yo[u] = act != ACT_NONE ? Feat<T>::load(y + off) : f8_zero();
+      yo[u] = (act != ACT_NONE && !RECOMP) ? Feat<T>::load(y + off) : f8_zero();
       const int pc = live[u] ? p : p0;
       im[u][0] = need_img ? ib[pc] : 0.f; im[u][1] = need_img ? ib[HW + pc] : 0.f; im[u][2] = need_img ? ib[2 * HW + pc] : 0.f;
     }
@@ -1289,7 +1293,14 @@ __global__ void rgb_expand_bwd_kernel(const T* __restrict__ gy, const T* __restr
       float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float z = g[u].v[j] * act_grad_from_out(yo[u].v[j], act, gain) * cm[j] * lv;
+        float ag;
+        if (RECOMP) {
+          const float t = im[u][0] * w0[j] + im[u][1] * w1[j] + im[u][2] * w2[j] + fb[j];      // (rgb_expand_kernel's expression)
+          ag = t > 0.f ? gain : gain * LRELU_SLOPE;
+        } else {
+          ag = act_grad_from_out(yo[u].v[j], act, gain);
+        }
+        const float z = g[u].v[j] * ag * cm[j] * lv;
         o0 += z * w0[j]; o1 += z * w1[j]; o2 += z * w2[j];
         a0[j] += im[u][0] * z; a1[j] += im[u][1] * z; a2[j] += im[u][2] * z;
         sb[j] += z;
@@ -1450,6 +1461,8 @@ int reduce_P(int HW, int B) {           // pixels per block for the reduction ke
   else return LCGAN_EINVAL;
 
 extern "C" {
+int lcgan_rgb_expand_bwd_r(const void* gy, const void* y, const float* img, const float* w, const float* fbias, float fbias_scale, int recompute,
+                           float* gimg, float* gw, float* gbias, int B, int HW, int C, int Clog, int per_sample, int act, float gain, int dtype, void* stream);
 int lcgan_act_bwd_reduce_m(const void* gy, const void* y, const void* mask, void* gz, const float* bias, float bias_scale,
                            float* gbias, float* gdq, int B, int HW, int C, int Clog, int act, float gain, int dtype, void* stream);
 int lcgan_box3_actbwd_reduce_m(const void* gy, const void* y, const void* mask, void* gz, float* gbias, int B, int H, int W, int C, int Clog,
@@ -1732,15 +1745,24 @@ int lcgan_flow_im2col(const void* gu, const float* d, void* gt, int B, int H, in
 // gbias [Clog] (accumulated: zeroed by the caller); each may be NULL.  y: the saved OUTPUT of lcgan_rgb_expand (ignored for act 0).
 int lcgan_rgb_expand_bwd(const void* gy, const void* y, const float* img, const float* w, float* gimg, float* gw, float* gbias,
                          int B, int HW, int C, int Clog, int per_sample, int act, float gain, int dtype, void* stream) {
+  return lcgan_rgb_expand_bwd_r(gy, y, img, w, nullptr, 0.f, 0, gimg, gw, gbias, B, HW, C, Clog, per_sample, act, gain, dtype, stream);
+}
+// ... recompute = 1 (leaky ReLU, img != NULL): the activation's sign comes from the image and the forward layer's bias (fbias, may be
+// NULL) instead of y, which is then not read (may be NULL): act'(y) needs only sign(w . img + fbias * fbias_scale)
+int lcgan_rgb_expand_bwd_r(const void* gy, const void* y, const float* img, const float* w, const float* fbias, float fbias_scale, int recompute,
+                           float* gimg, float* gw, float* gbias,
+                           int B, int HW, int C, int Clog, int per_sample, int act, float gain, int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if ((C & 7) || !pow2_le64(C / 8) || Clog > C || (gw && !img)) return LCGAN_EINVAL;
+  if (recompute && (act != ACT_LRELU || !img)) return LCGAN_EINVAL;
+  if (!recompute && act != ACT_NONE && !y) return LCGAN_EINVAL;
   const int P = reduce_P(HW, B);
   dim3 grid(cdiv(HW, P), B);
-  Tag tg("rgb_expand_bwd", B, HW, 1, C);
-  ProfScope p(KID_RGB, 0, (double)B * HW * C * (act != ACT_NONE ? 2 : 1) * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
-#define RGBB(A) DISPATCH_T(dtype, hipLaunchKernelGGL((rgb_expand_bwd_kernel<T, A>), grid, dim3(TPB), 0, s, (const T*)gy, (const T*)y, img, w, gimg, gw, gbias, \
+  Tag tg(recompute ? "rgb_expand_bwd(recompute)" : "rgb_expand_bwd", B, HW, 1, C);
+  ProfScope p(KID_RGB, 0, (double)B * HW * C * ((act != ACT_NONE && !recompute) ? 2 : 1) * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
+#define RGBB(A, R) DISPATCH_T(dtype, hipLaunchKernelGGL((rgb_expand_bwd_kernel<T, A, R>), grid, dim3(TPB), 0, s, (const T*)gy, (const T*)y, img, w, fbias, fbias_scale, gimg, gw, gbias, \
                                                 HW, C, Clog, per_sample, act, gain, P))
-  if (act == ACT_LRELU) { RGBB(ACT_LRELU); } else if (act == ACT_NONE) { RGBB(ACT_NONE); } else { RGBB(-1); }
+  if (recompute) { RGBB(ACT_LRELU, true); } else if (act == ACT_LRELU) { RGBB(ACT_LRELU, false); } else if (act == ACT_NONE) { RGBB(ACT_NONE, false); } else { RGBB(-1, false); }
 #undef RGBB
   return launch_status();
 }

@@ -435,16 +435,19 @@ class HipKernels:
         return gw
 
     def rgb_expand_bwd(self, gy: Tensor, y: Optional[Tensor], img: Optional[Tensor], w: Tensor, act: int, gain: float, clog: int,
-                       want_gimg: bool, want_gw: bool, want_gbias: bool):
-        """fused backward of rgb_expand -> (gimg [B,3,H,W] | None, gw [Bw,3,C] | None, gbias [clog] | None); gz = gy * act'(y) is never stored"""
-        self._chk(gy, y, img, w)
+                       want_gimg: bool, want_gw: bool, want_gbias: bool, fbias: Optional[Tensor] = None, fbias_scale: float = 1.0,
+                       recompute: bool = False):
+        """fused backward of rgb_expand -> (gimg [B,3,H,W] | None, gw [Bw,3,C] | None, gbias [clog] | None); gz = gy * act'(y) is never stored.
+        recompute (leaky ReLU; img, fbias = the forward layer's bias given): the activation's sign from w . img + fbias instead of y"""
+        self._chk(gy, y, img, w, fbias)
+        recompute = bool(recompute and act == ACT_LRELU and img is not None)
         B, H, W, Cc = gy.shape
         per_sample = w.shape[0] > 1
         gimg = torch.empty((B, 3, H, W), dtype=torch.float32, device=gy.device) if want_gimg else None
         gw = self._zeros.take((B if per_sample else 1, 3, Cc), gy.device) if want_gw else None
         gbias = self._zeros.take((clog,), gy.device) if want_gbias else None
-        self._call("lcgan_rgb_expand_bwd", gy.data_ptr(), _p(y), _p(img), w.data_ptr(), _p(gimg), _p(gw), _p(gbias), B, H * W, Cc, clog,
-                   int(per_sample), act, float(gain), dt_code(gy.dtype), self._stream())
+        self._call("lcgan_rgb_expand_bwd_r", gy.data_ptr(), _p(y), _p(img), w.data_ptr(), _p(fbias), float(fbias_scale), int(recompute),
+                   _p(gimg), _p(gw), _p(gbias), B, H * W, Cc, clog, int(per_sample), act, float(gain), dt_code(gy.dtype), self._stream())
         return gimg, gw, gbias
 
     def rgb_reduce_bwd_act(self, gimg: Tensor, y: Tensor, wm: Tensor, bias: Optional[Tensor], bias_scale: float, act: int, gain: float,

@@ -494,7 +494,7 @@ class RGBExpandFn(Function):
         """pool: also returns avg_pool2d(feat, 2) as a non-differentiable by-product (see Conv2dPoolFn)"""
         out = _K().rgb_expand(img, wt, bias, bias_scale, clog, act, gain, dtype, pool=pool)
         y = out[0] if pool else out
-        ctx.save_for_backward(img, wt, y if act != ACT_NONE else None)
+        ctx.save_for_backward(img, wt, y if act != ACT_NONE else None, bias)
         ctx.cfg = (bias_scale, clog, act, gain, bias is not None)
         if pool:
             ctx.mark_non_differentiable(out[1])
@@ -506,7 +506,7 @@ class RGBExpandFn(Function):
     def backward(ctx, gy, _gpooled=None):
         if gy is None:
             return (None,) * 9
-        img, wt, y = ctx.saved_tensors
+        img, wt, y, fbias = ctx.saved_tensors
         bias_scale, clog, act, gain, has_bias = ctx.cfg
         gy = gy.contiguous()
         want_gb = has_bias and _wants(ctx, 2)
@@ -515,7 +515,11 @@ class RGBExpandFn(Function):
             # gradient and the bias gradient (1.1 GB instead of 2.7 GB of traffic at 256 x 256, batch 32).  Under create_graph (R1,
             # loss.py:28-33) the composition below records the graph the second backward walks.
             want_gw = _wants(ctx, 1)
-            gimg, gwt, gb = _K().rgb_expand_bwd(gy, y, img if want_gw else None, wt, act, gain, clog, ctx.needs_input_grad[0], want_gw, want_gb)
+            # (leaky ReLU: the sign act' needs is recomputed from the image -- a 3-term dot product on operands the kernel holds -- instead of
+            #  reading y back: half of the pass's bytes)
+            recomp = act == ACT_LRELU and _act_masks()
+            gimg, gwt, gb = _K().rgb_expand_bwd(gy, y, img if (want_gw or recomp) else None, wt, act, gain, clog, ctx.needs_input_grad[0], want_gw, want_gb,
+                                                fbias=fbias.detach() if fbias is not None else None, fbias_scale=bias_scale, recompute=recomp)
             if gb is not None and bias_scale != 1.0:
                 gb = gb * bias_scale
             return gimg, gwt, gb, None, None, None, None, None, None

@@ -361,7 +361,7 @@ class EmulatedKernels:
         gw = torch.einsum("bohw,bhwc->boc", img.float(), feat.float())
         return gw.contiguous() if per_sample else gw.sum(0, keepdim=True).contiguous()
 
-    def rgb_expand_bwd(self, gy, y, img, w, act, gain, clog, want_gimg, want_gw, want_gbias):
+    def rgb_expand_bwd(self, gy, y, img, w, act, gain, clog, want_gimg, want_gw, want_gbias, fbias=None, fbias_scale=1.0, recompute=False):
         """lcgan_rgb_expand_bwd: gz = gy * act'(y) stays fp32 (never rounded to the feature dtype)"""
         B = gy.shape[0]
         z = gy.float() * (act_grad_from_out(y.float(), act, gain) if act != ACT_NONE else gain)

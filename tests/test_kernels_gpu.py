@@ -808,6 +808,16 @@ def test_rgb_fused_backward(H, dtype, per_sample, shape):
     check(gw, H.rgb_wgrad(img.cuda(), gz, per_sample).cpu(), f32ish, "expand_bwd vs composition: gw", l2_scale=2.0)
     check(gbias, gb.cpu(), f32ish, "expand_bwd vs composition: gbias", l2_scale=2.0)
 
+    # recompute form: the activation's sign from the image (w . img + bias) instead of the saved output -- with y the layer's own output both
+    # forms see the same signs, so everything agrees to reduction order
+    fb = torch.randn(C, generator=torch.Generator().manual_seed(80)) * 0.2
+    y_own = H.rgb_expand(img.cuda(), w.cuda(), fb.cuda(), 0.7, clog, 1, 1.2, dtype)
+    a = H.rgb_expand_bwd(gy.cuda(), y_own, img.cuda(), w.cuda(), 1, 1.2, clog, True, True, True)
+    r = H.rgb_expand_bwd(gy.cuda(), None, img.cuda(), w.cuda(), 1, 1.2, clog, True, True, True, fbias=fb.cuda(), fbias_scale=0.7, recompute=True)
+    assert torch.equal(a[0], r[0]), "recomputed sign: gimg differs"
+    for name, u, v in zip(("gw", "gbias"), a[1:], r[1:]):
+        assert torch.allclose(u, v, rtol=1e-4, atol=1e-5 * float(u.abs().max())), name           # (float atomics: order)
+
     gimg_in = torch.randn(B, 3, Hh, W, generator=torch.Generator().manual_seed(78))
     bias = torch.randn(C, generator=torch.Generator().manual_seed(79)) * 0.2
     got = H.rgb_reduce_bwd_act(gimg_in.cuda(), y.cuda(), w.cuda(), bias.cuda(), 1.0, 1, 1.3, clog)
