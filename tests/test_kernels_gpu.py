@@ -252,7 +252,7 @@ def _same_as_add_pass(y_r, y_plain, r, dtype, what):
     want = (y_plain.float() + r.float()).to(dtype)
     if torch.equal(y_r, want):
         return
-    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -22
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -20       # (f32 parity mode: atomics over up to 36 splits move u by a few units in the last place)
     err = float((y_r.float() - want.float()).abs().max()) / float(want.float().abs().max())
     assert err <= ulp, f"{what}: differs from the add pass by {err:.2e} (> one rounding step {ulp:.1e})"
 
