@@ -693,8 +693,13 @@ constexpr int DMA_HBUF = (DMA_HROWS * DMA_HP * 64 + 1023) & ~1023; // bytes per 
 constexpr int DMA_BBUF = 128 * 64;                               // bytes per weight tile (two)
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int IN_MUL, bool M16, int EPI, int DMA = 0, bool MOD = false>
+template <int IN_MUL, bool M16, int EPI_, int DMA = 0, bool MOD = false>
 __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) void conv_halo_kernel(HaloArgs a) {
+  // EPI_ == 4: the plain epilogue (0) that also leaves the activation's sign mask (a.mask_out).  Its own instantiation: as a run-time
+  // branch of the plain epilogue the four mask words cost EVERY plain launch 6 VGPRs and ~40 spilled SGPRs, and the modulated
+  // instantiations (123 -> 129 VGPRs) their second workgroup per CU (+30 % on the 512-channel generator layers, measured).
+  constexpr int EPI = EPI_ == 4 ? 0 : EPI_;
+  constexpr bool MK = EPI_ == 4;
   static_assert(DMA == 0 || (IN_MUL == 1 && DMA <= 2 && (!M16 || DMA == 2)) || (IN_MUL == 2 && (DMA == 3 || DMA == 4) && !M16),
                 "LDS-DMA staging: stride-1 geometries (1 / 2 taps per barrier) or the stride-2 forward structure (DMA == 3)");
   static_assert(!MOD || DMA != 0, "MOD: the swizzled-record structure with the halo staged through registers (per-sample input scales)");
@@ -1552,7 +1557,7 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
           }
       }
     }
-    unsigned mw[2][2] = {{0u, 0u}, {0u, 0u}};                                   // sign bits of this lane's pre-activations (a.mask_out)
+    unsigned mw[2][2] = {{0u, 0u}, {0u, 0u}};                                   // sign bits of this lane's pre-activations (MK: a.mask_out)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -1567,7 +1572,7 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
           for (int j = 0; j < 4; ++j) {
             const float t = acc[mi][ni][4 * g + j] * pv[j] + bv[j];
             v[j] = (a.act == ACT_LRELU ? (t > 0.f ? t : t * LRELU_SLOPE) : t) * a.gain;
-            if (EPI == 0) mw[mi][ni] |= (t > 0.f ? 1u : 0u) << (8 * g + 4 * (lane >> 5) + j);
+            if (MK) mw[mi][ni] |= (t > 0.f ? 1u : 0u) << (8 * g + 4 * (lane >> 5) + j);
           }
           if (EPI != 0) {
             bf16x4 rr = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
@@ -1582,7 +1587,7 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
           *(bf16x4*)(ot + row * OROW + ch) = o;
         }
       }
-    if (EPI == 0 && a.mask_out) {
+    if (MK) {
       // activation sign mask: one 32-bit word per (pixel, 32 channels), bit c % 32 = (pre-activation of channel c > 0).  A lane holds the
       // nibbles 8 g + 4 (lane >> 5) of its pixel's two words (ni); its partner 32 lanes away holds the other nibbles.
       const int words = a.Cout >> 5;
@@ -2101,7 +2106,8 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   a.pool_out = (c.pool_out && c.residual && !c.res_half && !c.xs && nphase == 1 && c.out_mul == 1 && !((c.Hout | c.Wout) & 1)) ? (__bf16*)c.pool_out : nullptr;
   a.bias_scale = c.bias_scale; a.gain = c.gain; a.act = c.act;
   // activation sign mask: written by the transposed-accumulator epilogue of the plain (EPI == 0) variants
-  a.mask_out = (c.mask_out && c.act == ACT_LRELU && !c.xs && !c.residual && nphase == 1 && c.out_mul == 1 && (c.Cout & 31) == 0 && g_mfma16 == 0) ? c.mask_out : nullptr;
+  // (the unmodulated LDS-DMA structures below carry the EPI 4 instantiation; every other path clears a.mask_out again)
+  a.mask_out = (c.mask_out && c.act == ACT_LRELU && !c.xs && !c.residual && !c.pre && nphase == 1 && c.out_mul == 1 && (c.Cout & 31) == 0 && g_mfma16 == 0) ? c.mask_out : nullptr;
   int max_halo = 0, max_halo_elems = 0;
   for (int p = 0; p < nphase; ++p) {
     a.taps[p] = c.taps[p];
@@ -2139,7 +2145,7 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   }
   a.halo_elems = max_halo_elems;
   g_pool_written = a.pool_out != nullptr;                         // (no `return false` below this line)
-  g_mask_written = a.mask_out != nullptr;
+  g_mask_written = false;                                         // (set where an EPI 4 instantiation is launched)
   if (a.pre && g_halo_wmod_mb > 0 && c.Cin % 32 == 0 && c.Kpad == c.Cin && c.pre_stride >= c.Cin && g_mfma16 != 1) {
     // taps of the whole prepared weight (9 for a 3x3 kernel whatever the phase structure, 1 for 1x1)
     int wt_max = 0;
@@ -2207,7 +2213,8 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
     if (!set) { hipFuncSetAttribute((const void*)conv_halo_kernel<2, false, EP, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
     hipLaunchKernelGGL((conv_halo_kernel<2, false, EP, 4>), grid, dim3(512), dsm1, s, a);                               \
   }
-      if (a.xs) LAUNCH_S2S(3) else if (a.residual && a.res_half) LAUNCH_S2S(2) else if (a.residual) LAUNCH_S2S(1) else LAUNCH_S2S(0)
+      if (a.xs) LAUNCH_S2S(3) else if (a.residual && a.res_half) LAUNCH_S2S(2) else if (a.residual) LAUNCH_S2S(1)
+      else if (a.mask_out) { g_mask_written = true; LAUNCH_S2S(4) } else LAUNCH_S2S(0)
 #undef LAUNCH_S2S
       return true;
     }
@@ -2229,7 +2236,8 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
     if (!set) { hipFuncSetAttribute((const void*)conv_halo_kernel<2, false, EP, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
     hipLaunchKernelGGL((conv_halo_kernel<2, false, EP, 3>), grid, dim3(512), dsmem, s, a);                              \
   }
-    if (a.xs) LAUNCH_S2(3) else if (a.residual && a.res_half) LAUNCH_S2(2) else if (a.residual) LAUNCH_S2(1) else LAUNCH_S2(0)
+    if (a.xs) LAUNCH_S2(3) else if (a.residual && a.res_half) LAUNCH_S2(2) else if (a.residual) LAUNCH_S2(1)
+    else if (a.mask_out) { g_mask_written = true; LAUNCH_S2(4) } else LAUNCH_S2(0)
 #undef LAUNCH_S2
     return true;
   }
@@ -2246,7 +2254,8 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
     hipLaunchKernelGGL((conv_halo_kernel<1, false, EP, TPV, MD>), grid, dim3(512), dsmem, s, a);                        \
   }
 #define LAUNCH_DMA_EPI(TPV)                                                                                             \
-  { if (a.xs) LAUNCH_DMA(3, TPV, false) else if (a.residual && a.res_half) LAUNCH_DMA(2, TPV, false) else if (a.residual) LAUNCH_DMA(1, TPV, false) else LAUNCH_DMA(0, TPV, false) }
+  { if (a.xs) LAUNCH_DMA(3, TPV, false) else if (a.residual && a.res_half) LAUNCH_DMA(2, TPV, false) else if (a.residual) LAUNCH_DMA(1, TPV, false) \
+    else if (a.mask_out) { g_mask_written = true; LAUNCH_DMA(4, TPV, false) } else LAUNCH_DMA(0, TPV, false) }
 #define LAUNCH_DMA_MOD(TPV)                                                                                             \
   { if (a.xs) LAUNCH_DMA(3, TPV, true) else if (a.residual && a.res_half) LAUNCH_DMA(2, TPV, true)                      \
     else if (a.residual) LAUNCH_DMA(1, TPV, true) else LAUNCH_DMA(0, TPV, true) }
@@ -2256,7 +2265,7 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
     if (!set) { hipFuncSetAttribute((const void*)conv_halo_kernel<1, true, EP, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
     hipLaunchKernelGGL((conv_halo_kernel<1, true, EP, 2, false>), grid, dim3(512), dsmem, s, a);                        \
   }
-    if (g_mfma16 == 2 && !mod && !a.xs && tp == 2) { if (a.residual && a.res_half) LAUNCH_DMA16(2) else if (a.residual) LAUNCH_DMA16(1) else LAUNCH_DMA16(0) }
+    if (g_mfma16 == 2 && !mod && !a.xs && tp == 2) { a.mask_out = nullptr; if (a.residual && a.res_half) LAUNCH_DMA16(2) else if (a.residual) LAUNCH_DMA16(1) else LAUNCH_DMA16(0) }
     else if (mod) { if (tp == 2) LAUNCH_DMA_MOD(2) else LAUNCH_DMA_MOD(1) }
     else if (tp == 2) LAUNCH_DMA_EPI(2) else LAUNCH_DMA_EPI(1)
 #undef LAUNCH_DMA16
@@ -2265,6 +2274,7 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
 #undef LAUNCH_DMA
     return true;
   }
+  a.mask_out = nullptr;                                          // (register-staged structures: no mask instantiation)
   if (in_mul == 1 && g_mfma16 == 1 && !a.xs && !a.residual) LAUNCH_HALO(1, true, 0)
   else if (in_mul == 1) LAUNCH_HALO_EPI(1, false)
   else if (g_mfma16 == 1 && !a.xs && !a.residual) LAUNCH_HALO(2, true, 0)
