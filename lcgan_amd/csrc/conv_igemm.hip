@@ -1572,7 +1572,9 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
           for (int j = 0; j < 4; ++j) {
             const float t = acc[mi][ni][4 * g + j] * pv[j] + bv[j];
             v[j] = (a.act == ACT_LRELU ? (t > 0.f ? t : t * LRELU_SLOPE) : t) * a.gain;
-            if (MK) mw[mi][ni] |= (t > 0.f ? 1u : 0u) << (8 * g + 4 * (lane >> 5) + j);
+            // (MK) "not positive" bits by integer arithmetic on the float's bits -- bits(t) - 1 has its top bit set exactly for t <= +0 and
+            //  for negative t other than -0, which fp32 accumulation from +0 never produces -- instead of 64 compares, each holding an SGPR pair
+            if (MK) mw[mi][ni] |= ((__builtin_bit_cast(unsigned, t) - 1u) >> 31) << (8 * g + 4 * (lane >> 5) + j);
           }
           if (EPI != 0) {
             bf16x4 rr = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
@@ -1595,7 +1597,7 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-          const unsigned wv = mw[mi][ni] | (unsigned)__shfl_xor((int)mw[mi][ni], 32, 64);
+          const unsigned wv = ~(mw[mi][ni] | (unsigned)__shfl_xor((int)mw[mi][ni], 32, 64));      // (the lanes collected the COMPLEMENT)
           const int row = wm * 64 + mi * 32 + (lane & 31);
           const int py = ty * HT + (row >> 4), px = tx * HT + (row & 15);
           const int wi = (n0 >> 5) + wn * 2 + ni;
