@@ -93,16 +93,22 @@ def cpu_baseline(res: int, batch: int = 4, full_cycle: bool = False):
 
 
 def committed_traffic():
-    """HBM bytes per launch of the dominant kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    separate runs, FETCH_SIZE x 2 on gfx950: scripts/pmc_traffic.py -> profiles/r03_pmc_traffic.json).  PMC counters cannot be read
-    inside a timed run, so the bench line quotes the profiled figure with the commit it was taken at; None when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    """Memory-side bytes per launch of the dominant kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate runs, FETCH_SIZE x 2 on gfx950: scripts/pmc_traffic.py -> profiles/r04_pmc_traffic.json).  PMC counters cannot be read
+    inside a timed run, so the bench line quotes the profiled figure -- but only while the kernel sources of the running build hash to
+    what the profiled build hashed to (`_srchash`); otherwise `traffic` is null and the file is named under `traffic_source` alone."""
+    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        fam = d.get("conv_halo")
-        return {"bytes_per_launch": fam["bytes_per_launch"], "kernel": "conv_halo_kernel", "launches": fam["launches"],
-                "source": "profiles/r03_pmc_traffic.json", "commit": d.get("_commit")}
+        fam = d["families"]["conv_halo"]
+        from lcgan_amd.build import source_hash
+        same = d.get("_srchash") is not None and d.get("_srchash") == source_hash()
+        amp = (d.get("amplification") or {}).get("conv fwd/dgrad")
+        return {"bytes_per_launch": fam["bytes_per_launch"] if same else None, "kernel": "conv_halo_kernel", "launches": fam["launches"],
+                "source": "profiles/r04_pmc_traffic.json", "commit": d.get("_commit"), "same_kernel_sources_as_this_build": same,
+                "total_over_algorithmic_bytes": amp["total_over_algorithmic"] if amp else None,
+                "stale_bytes_per_launch": None if same else fam["bytes_per_launch"]}
     except Exception:  # noqa: BLE001
         return None
 
@@ -233,9 +239,9 @@ def main():
         none = {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "count": 0}
         ig, wg = prof.get("conv_igemm", none), prof.get("conv_wgrad", none)
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
-        # `traffic` (HBM bytes per launch) needs PMC passes under rocprofv3 and cannot be measured inside this run: the separately
-        # profiled figure of the same command (scripts/pmc_traffic.py -> profiles/r03_pmc_traffic.json, FETCH_SIZE x2 on gfx950) is quoted
-        # with its commit; only for the configuration it was profiled on (256 x 256, batch 32, bf16)
+        # `traffic` (memory-side bytes per launch) needs PMC passes under rocprofv3 and cannot be measured inside this run: the separately
+        # profiled figure of the same command (scripts/pmc_traffic.py -> profiles/r04_pmc_traffic.json, FETCH_SIZE x2 on gfx950) is quoted
+        # while the running build's kernel sources match the profiled build's; only for the configuration it was profiled on (256 x 256, batch 32, bf16)
         tr = committed_traffic() if (a.res == 256 and a.batch == 32 and a.dtype == "bf16" and world == 1) else None
         out["roofline"] = {"bound": "mfma", "kernel": "conv_halo_kernel + conv_igemm_kernel (forward / data-gradient convolutions)",
                            "achieved": ach, "peak": PEAK_BF16_DENSE / 1e12,

@@ -134,4 +134,10 @@ if __name__ == "__main__":
                 res["amplification"][g] = {"algorithmic_bytes": a, "read_bytes": rd, "write_bytes": w, "total_over_algorithmic": (rd + w) / a}
                 print(f"  {g:16s} algorithmic {a / 1e9:7.2f} GB   measured read {rd / 1e9:7.2f} + write {w / 1e9:7.2f} GB   total / algorithmic = {(rd + w) / a:4.2f}")
     res["_commit"] = os.environ.get("LCGAN_COMMIT")          # the build the passes ran on (set by the submitting shell: the GPU box has no .git)
+    try:                                                     # ... and the hash of the kernel sources the profiled library was built from:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from lcgan_amd.build import source_hash              # bench.py quotes `traffic` only while the running build still matches it
+        res["_srchash"] = source_hash()
+    except Exception:  # noqa: BLE001
+        res["_srchash"] = None
     json.dump(res, open(sys.argv[3], "w"), indent=1)
