@@ -56,6 +56,7 @@ int g_wgrad_low_direct = 1;               // lcgan_set_option(20, ...): launch p
                                           // cost model in conv_wgrad_impl, one split = the epilogue writes the finished gradient in weight layout, XCD order only from 8 splits
                                           // (0 = the round-2 plan: >= 1024 positions per split, XCD order always, atomics below 4 splits)
 int g_wgrad_low_parts = 0;                // lcgan_set_option(21, ...): force the number of splits of the small-grid weight gradients (tuning experiments; 0 = automatic)
+int g_wgrad_slab_bf16 = 1;                 // lcgan_set_option(25, ...): bf16 launches store their split partial tiles in bf16 (fp32 accumulation inside a split and across the splits)
 int g_halo_phase_x = 0;                    // lcgan_set_option(24, ...): the 4 sub-pixel phases of a transposed convolution tile run side by side on one XCD (1-D grid) instead of as grid.z planes (measured: fabric reads -3.6x, time 0 ... +25 %: off)
 int g_flow_wgrad = 1;                     // lcgan_set_option(23, ...): one-pass weight gradient of the flow layer's 1x1 GEMM (flow_wgrad_kernel); 0 = the row-segment kernel
 int g_halo_split = 0;                     // lcgan_set_option(22, ...): halo launches below option 6's workgroup count split their input-channel range so that about this many workgroups run
@@ -2301,6 +2302,7 @@ struct WgradArgs {
   int parts;                                 // wgrad3: split = group * parts + part
   int cps_group;                             // wgrad3: chunks per group (group = one sample when per-sample scales exist, else the whole batch)
   float* slab;                               // wgrad3: non-null = every split stores its partial tile to slab[split][tap][A][Bc] (plain stores) instead of atomics
+  int slab_bf16;                             // ... as bf16 elements (the slab pointer is then a __bf16*): half the partial-tile traffic of a bf16 launch
   int xcd_order, na, nc;                     // wgrad3: 1-D XCD-aware workgroup order (see WG3_INDEX); a / c blocks of 128  // wgrad3, single split, fused un-prep: the epilogue writes the gradient in WEIGHT layout itself (no gwp clear, no atomics, no second launch):
   // dgw[a][b][t] = dscale * acc + 2 dscale^2 dw[a][b][t] dgwsq[a][b]  (see unprep_wgrad_kernel; dtransposed: the weight is [Bc][A])
   float* dgw; const float* dw; const float* dgwsq; float dscale; int dtransposed;
@@ -2681,7 +2683,10 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
         if (aa < a.A && cc < a.Bc) {
           const float sgv = a.pre_g ? a.pre_g[(size_t)bsmp * a.Cg + aa] : 1.f;
           const size_t off = ((size_t)(ky * NKX + kx) * a.A + aa) * a.Bc + cc;
-          if (a.slab) a.slab[(size_t)split * (NKX * NKX) * a.A * a.Bc + off] = acc[kx][mi][r] * sxv * sgv;
+          if (a.slab) {
+            const size_t si = (size_t)split * (NKX * NKX) * a.A * a.Bc + off;
+            if (a.slab_bf16) ((__bf16*)a.slab)[si] = (__bf16)(acc[kx][mi][r] * sxv * sgv); else a.slab[si] = acc[kx][mi][r] * sxv * sgv;
+          }
           else atomicAdd(a.gwp + off, acc[kx][mi][r] * sxv * sgv);
         }
       }
@@ -2855,7 +2860,10 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad3_dma_kernel(WgradArgs a) {
         if (aa < a.A && cc < a.Bc) {
           const float sgv = a.pre_g ? a.pre_g[(size_t)bsmp * a.Cg + aa] : 1.f;
           const size_t off = ((size_t)(ky * NKX + kx) * a.A + aa) * a.Bc + cc;
-          if (a.slab) a.slab[(size_t)split * (NKX * NKX) * a.A * a.Bc + off] = acc[kx][mi][r] * sxv * sgv;
+          if (a.slab) {
+            const size_t si = (size_t)split * (NKX * NKX) * a.A * a.Bc + off;
+            if (a.slab_bf16) ((__bf16*)a.slab)[si] = (__bf16)(acc[kx][mi][r] * sxv * sgv); else a.slab[si] = acc[kx][mi][r] * sxv * sgv;
+          }
           else atomicAdd(a.gwp + off, acc[kx][mi][r] * sxv * sgv);
         }
       }
@@ -2864,25 +2872,27 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad3_dma_kernel(WgradArgs a) {
 
 // gwp[i] = sum_s slab[s][i]: the partial weight-gradient tiles of the row-segment kernel meet here instead of through fp32
 // atomics (12.5 M atomic adds onto 147 K addresses for the 128x128 top layer: ~20 % of that kernel)
-__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ gwp, int total, int nsplit) {
+template <typename ST>                                       // ST: element type of the partial tiles (float, or __bf16: WgradArgs::slab_bf16)
+__global__ void slab_reduce_kernel(const ST* __restrict__ slab, float* __restrict__ gwp, int total, int nsplit) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   float acc = 0.f;
 #pragma unroll 4
-  for (int sI = 0; sI < nsplit; ++sI) acc += slab[(size_t)sI * total + i];
+  for (int sI = 0; sI < nsplit; ++sI) acc += (float)slab[(size_t)sI * total + i];
   gwp[i] = acc;
 }
 
 // slab reduction fused with the un-prep of the weight gradient (lcgan_conv_wgrad_unprep): gw[a][b][t] = scale * sum_s slab[s][src] (+ demod
 // term), src = the element's place in the prepared layout.  One launch instead of slab_reduce + unprep and no gwp round trip.
-__global__ void slab_reduce_unprep_kernel(const float* __restrict__ slab, int nsplit, int A, int Bc, int kk, float scale, int transposed,
+template <typename ST>
+__global__ void slab_reduce_unprep_kernel(const ST* __restrict__ slab, int nsplit, int A, int Bc, int kk, float scale, int transposed,
                                           const float* __restrict__ w, const float* __restrict__ gwsq, float* __restrict__ gw) {
   const int total = A * Bc * kk;
   const int i = blockIdx.x * 256 + threadIdx.x;              // index in the prepared layout ([t][A][Bc] or [t][Bc][A]): coalesced slab reads
   if (i >= total) return;
   float acc = 0.f;
 #pragma unroll 4
-  for (int sI = 0; sI < nsplit; ++sI) acc += slab[(size_t)sI * total + i];
+  for (int sI = 0; sI < nsplit; ++sI) acc += (float)slab[(size_t)sI * total + i];
   const int t = i / (A * Bc), r = i - t * (A * Bc);
   const int aa = transposed ? r % A : r / Bc, b = transposed ? r / A : r % Bc;
   const size_t ab = (size_t)aa * Bc + b, idx = ab * kk + t;
@@ -3319,6 +3329,7 @@ int lcgan_set_option(int option, int value) {
   if (option == 22) { const int old = g_halo_split; g_halo_split = value; return old; }
   if (option == 23) { const int old = g_flow_wgrad; g_flow_wgrad = value; return old; }
   if (option == 24) { const int old = g_halo_phase_x; g_halo_phase_x = value; return old; }
+  if (option == 25) { const int old = g_wgrad_slab_bf16; g_wgrad_slab_bf16 = value; return old; }
   if (option == 17) { const int old = g_wgrad_prescale_mb; g_wgrad_prescale_mb = value; return old; }
   if (option == 18) { const int old = g_halo_wmod_mb; g_halo_wmod_mb = value; return old; }
   return LCGAN_EINVAL;
@@ -3635,6 +3646,10 @@ static int conv_wgrad_impl(const void* x, const void* g, float* gwp,
     // launch with enough splits takes the slab.
     if (pk == 1 && g_wgrad_slab_min > 0 && (a.nsplit >= g_wgrad_slab_min || (lowres && a.nsplit > 1)) && slab_bytes <= ((size_t)1 << 30))
       a.slab = wgrad_slab_scratch(slab_bytes, s);                    // (packed groups: several waves add into one element -> atomics only)
+    // Partial tiles of a bf16 launch cross memory as bf16: a split accumulates its ~10^4 positions in fp32, rounds the tile once (2^-9
+    // relative), and the reduction pass sums the splits in fp32 again -- the rounding errors of S splits add up to ~2^-9 of the total,
+    // against the 3-5 % the bf16 operands already cost a weight gradient; the slabs were 12 GB of the 38 GB the family moved.
+    a.slab_bf16 = (a.slab && g_wgrad_slab_bf16 && a.nsplit >= 8) ? 1 : 0;
     if (up && !a.slab && !direct) hipMemsetAsync(gwp, 0, (size_t)k * k * A * Bc * sizeof(float), s);   // fused entry: gwp arrives uncleared
     // (XCD order puts split i on XCD i % 8: with fewer than 8 splits it would leave whole XCDs idle)
     a.na = cdiv(A, 128); a.nc = cdiv(Bc, 128); a.xcd_order = g_wgrad_xcd && (a.nsplit >= 8 || g_wgrad_low_direct <= 0);
@@ -3692,11 +3707,16 @@ static int conv_wgrad_impl(const void* x, const void* g, float* gwp,
       const int total = k * k * A * Bc;
       if (up && up->gw) {
         // (the un-prep's A / Bc are the WEIGHT's [A][Bc] = this call's [A][Bc] or its transpose; prepared layout [t][A][Bc] of this call)
-        hipLaunchKernelGGL(slab_reduce_unprep_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, a.slab, a.nsplit,
-                           up->transposed ? Bc : A, up->transposed ? A : Bc, k * k, up->scale, up->transposed, up->w, up->gwsq, up->gw);
+        if (a.slab_bf16)
+          hipLaunchKernelGGL(slab_reduce_unprep_kernel<__bf16>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const __bf16*)a.slab, a.nsplit,
+                             up->transposed ? Bc : A, up->transposed ? A : Bc, k * k, up->scale, up->transposed, up->w, up->gwsq, up->gw);
+        else
+          hipLaunchKernelGGL(slab_reduce_unprep_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const float*)a.slab, a.nsplit,
+                             up->transposed ? Bc : A, up->transposed ? A : Bc, k * k, up->scale, up->transposed, up->w, up->gwsq, up->gw);
         return launch_status() ? launch_status() : 1;          // 1 = un-prep done
       }
-      hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, a.slab, gwp, total, a.nsplit);
+      if (a.slab_bf16) hipLaunchKernelGGL(slab_reduce_kernel<__bf16>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const __bf16*)a.slab, gwp, total, a.nsplit);
+      else hipLaunchKernelGGL(slab_reduce_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const float*)a.slab, gwp, total, a.nsplit);
     }
   } else if (dtype == DT_BF16) {
     const size_t smem = 2 * 2 * WG_TILE * sizeof(__bf16);
