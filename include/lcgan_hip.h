@@ -234,7 +234,8 @@ int lcgan_multi_tensor(const void* descs, const int* chunk_tensor, const int* ch
  * 22 workgroup count up to which a halo-tile launch that option 6 would turn away splits its input-channel range instead (0 = never);
  * 23 one-pass weight gradient of the flow layer's 1x1 GEMM (0 = the row-segment kernel);
  * 24 the four sub-pixel phases of a transposed-convolution tile as neighbours in one XCD's queue instead of grid.z planes (off: fabric reads -3.6x, time 0 ... +25 %);
- * 25 partial weight-gradient tiles of a bf16 launch with at least 8 splits cross memory as bf16 (fp32 accumulation within a split and across them).
+ * 25 partial weight-gradient tiles of a bf16 launch with at least 8 splits cross memory as bf16 (fp32 accumulation within a split and across them);
+ * 26 plain stride-2 forward convolutions on the kernel with two anti-phased teams per 1024-thread workgroup (conv_s2duo_kernel).
  * DESIGN.md section 2 ("Switches") has the measurements behind the defaults. */
 int lcgan_set_option(int option, int value);
 

@@ -56,6 +56,7 @@ int g_wgrad_low_direct = 1;               // lcgan_set_option(20, ...): launch p
                                           // cost model in conv_wgrad_impl, one split = the epilogue writes the finished gradient in weight layout, XCD order only from 8 splits
                                           // (0 = the round-2 plan: >= 1024 positions per split, XCD order always, atomics below 4 splits)
 int g_wgrad_low_parts = 0;                // lcgan_set_option(21, ...): force the number of splits of the small-grid weight gradients (tuning experiments; 0 = automatic)
+int g_s2duo = 1;                           // lcgan_set_option(26, ...): stride-2 forward convolutions without per-sample scales / residual / fused reductions on the two-team kernel (conv_s2duo_kernel)
 int g_wgrad_slab_bf16 = 1;                 // lcgan_set_option(25, ...): bf16 launches store their split partial tiles in bf16 (fp32 accumulation inside a split and across the splits)
 int g_halo_phase_x = 0;                    // lcgan_set_option(24, ...): the 4 sub-pixel phases of a transposed convolution tile run side by side on one XCD (1-D grid) instead of as grid.z planes (measured: fabric reads -3.6x, time 0 ... +25 %: off)
 int g_flow_wgrad = 1;                     // lcgan_set_option(23, ...): one-pass weight gradient of the flow layer's 1x1 GEMM (flow_wgrad_kernel); 0 = the row-segment kernel
@@ -1727,6 +1728,212 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
   }
 }
 
+
+// =========================================================================================================
+// conv_s2duo_kernel -- stride-2 3 x 3 forward convolution, two ANTI-PHASED teams in one 1024-thread workgroup.
+//
+// Why (round 4, measured): conv_halo_kernel<2, ., ., 4> runs ONE stage per workgroup (the planes of a 16-channel half-chunk + the weight
+// tiles of all nine taps: 78 KB; load, barrier, 36 MFMAs per wave, barrier) and relies on the second workgroup of the CU to compute while
+// this one loads.  It does not happen: with one workgroup per CU (option 3, bit 32) a 256 x 256 launch takes 537 us against 501 with two --
+// the two co-resident workgroups start together, stay in lock step, load together (sharing the CU's fill path: each load twice as long) and
+// compute together (sharing the matrix pipe): 2 L + 2 C per pair of stages where max(L, C) ~ (L + C) / 2 would do (L = 1.56 us, C = 1.44 us).
+// Nothing synchronises two workgroups, so here the pair IS one workgroup: team A (waves 0-7) and team B (waves 8-15) own one output
+// tile each (neighbours in x, the SAME 128-channel block, hence the same weights) and one barrier per phase keeps them half a period apart:
+//     phase 2 h     : A computes half-chunk h            | B's planes of half-chunk h and 20 KB of the weight tiles of h + 1 land
+//     phase 2 h + 1 : B computes half-chunk h            | A's planes of h + 1 and the other 16 KB of the weight tiles of h + 1 land
+// LDS: planes A, planes B (42 KB each), two weight stages (36 KB each) = 156 KB; the weight bytes per MFMA halve on the way.
+// Same operand images, fragment addresses, tap order and accumulation order as the one-stage kernel: results are bit-identical to it.
+// Epilogue: the plain transposed-accumulator form (bias, leaky ReLU, gain; EPI_ == 4: + the activation sign mask), per team.
+// =========================================================================================================
+template <int EPI_>
+__global__ __launch_bounds__(1024) void conv_s2duo_kernel(HaloArgs a) {
+  constexpr bool MK = EPI_ == 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int PP = 20;                                       // plane row pitch in 32-byte records (see conv_halo_kernel, DMA == 3 / 4)
+  constexpr int P_OFF[4] = {0, 17 * PP, 2 * 17 * PP, 2 * 17 * PP + 16 * PP};
+  constexpr int NREC = 2 * 17 * PP + 2 * 16 * PP;
+  constexpr int HPIECES = (NREC + 31) / 32;                    // 42 one-KB pieces
+  constexpr int S2_H = HPIECES * 1024, S2_B = 9 * 4096;
+  const int tid = threadIdx.x, team = tid >> 9, ltid = tid & 511, lane = tid & 63, lwid = ltid >> 6;
+  const int wm = lwid >> 1, wn = lwid & 1;
+  const int widu = __builtin_amdgcn_readfirstlane(lwid), teamu = __builtin_amdgcn_readfirstlane(team);
+  char* planes = smem + teamu * S2_H;                           // this team's planes
+  char* wst = smem + 2 * S2_H;                                  // two weight stages
+
+  // workgroup -> (pair of tiles, channel block), XCD-contiguous like conv_halo_kernel; team t owns tile 2 pair + t
+  const int npair = gridDim.x / a.nblocks;
+  int pair, nb;
+  if ((npair & 7) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = (npair >> 3) * a.nb_group;
+    const int nbo = slot / per, rem = slot - nbo * per;
+    pair = xcd * (npair >> 3) + rem / a.nb_group;
+    nb = nbo * a.nb_group + rem % a.nb_group;
+  } else {
+    pair = blockIdx.x % npair;
+    nb = blockIdx.x / npair;
+  }
+  const int tile = 2 * pair + team;
+  const int n0 = nb * BN;
+  const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
+  const int gy0 = ty * HT * 2 - 1, gx0 = tx * HT * 2 - 1;       // input pixel of plane record (0, 0): halo origin (-1, -1)
+  const TapTable& tt = a.taps[0];
+  float ep_bias = 0.f, ep_post = 1.f;
+  if (ltid < BN) {
+    const int n = n0 + ltid;
+    if (a.bias && n < a.N) ep_bias = a.bias[n] * a.bias_scale;
+    if (a.post && n < a.Cout) ep_post = a.post[(size_t)b * a.Cout + n];
+  }
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(2u * (unsigned)(a.B * a.Hin * a.Win * a.Cin)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
+  unsigned hvo[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int L = 32 * (widu + 8 * k) + (lane >> 1);           // record of this lane in piece widu + 8 k
+    const int pl = L < P_OFF[1] ? 0 : L < P_OFF[2] ? 1 : L < P_OFF[3] ? 2 : 3;
+    const int rc = L - (pl == 0 ? P_OFF[0] : pl == 1 ? P_OFF[1] : pl == 2 ? P_OFF[2] : P_OFF[3]);
+    const int r = rc / PP, cc = rc - r * PP, pr = pl >> 1, pc = pl & 1;
+    const int ch = (lane & 1) ^ ((cc >> 2) & 1);
+    const int gy = gy0 + 2 * r + pr, gx = gx0 + 2 * cc + pc;
+    const bool ok = L < NREC && r < 17 - pr && cc < 17 - pc && (unsigned)gy < (unsigned)a.Hin && (unsigned)gx < (unsigned)a.Win;
+    hvo[k] = ok ? 2u * (unsigned)(((b * a.Hin + gy) * a.Win + gx) * a.Cin + ch * 8) : 0xffffffffu;
+  }
+  const int wrow = 32 * (widu & 3) + (lane >> 1);              // weight row of this lane: piece i = widu + 8 k is (tap i / 4, rows 32 (i % 4) ..)
+  const unsigned wvo = n0 + wrow < a.N ? 2u * (unsigned)((n0 + wrow) * a.Kpad + (((lane & 1) ^ ((wrow >> 3) & 1)) * 8)) : 0xffffffffu;
+  auto dma_planes = [&](int h) {
+    const int cofs = __builtin_amdgcn_readfirstlane(h * 32);
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      if (widu + 8 * k < HPIECES)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xres, (lds_void*)(planes + (widu + 8 * k) * 1024), 16, hvo[k], cofs, 0, 0);
+  };
+  // weight stage of half-chunk h: pieces [8 k0, 8 k1) + this wave (the nine taps are 36 one-KB pieces; the two load phases of a period
+  // take 20 and 16 of them so that both move ~60 KB)
+  auto dma_weights = [&](int h, int k0, int k1) {
+    char* W = wst + (h & 1) * S2_B;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int i = widu + 8 * k;
+      if (k >= k0 && k < k1 && i < 36)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_void*)(W + i * 1024), 16, wvo,
+                                                 __builtin_amdgcn_readfirstlane(2 * (tt.wt[i >> 2] * a.N * a.Kpad) + h * 32), 0, 0);
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int half = lane >> 5, xl = lane & 15, yl = wm * 4 + ((lane & 31) >> 4);
+  int acol[2];
+#pragma unroll
+  for (int sft = 0; sft < 2; ++sft) acol[sft] = yl * (PP * 32) + (xl + sft) * 32 + ((half ^ (((xl + sft) >> 2) & 1)) << 4);
+  const int brl = wn * 64 + (lane & 31);
+  const int baddr = brl * 32 + ((half ^ ((brl >> 3) & 1)) << 4);
+  // a computing team has two waves per SIMD: the fragments of tap t + 1 are requested BEFORE the MFMAs of tap t are issued (two named
+  // register sets, the loop fully unrolled), so that a wave's LDS round trip runs under its own matrix work, not only under the other wave's
+  auto half_chunk = [&](int h) {
+    const char* S = planes;
+    const char* W = wst + (h & 1) * S2_B;
+    bf16x8 af[2][2], bf[2][2];
+    auto frags = [&](int t, int set) {                           // stride-2 forward tap table is row-major over (ky, kx): tap t = 3 ky + kx
+      const int ky = t / 3, kx = t - 3 * (t / 3);
+      const int pbase = P_OFF[(ky & 1) * 2 + (kx & 1)] * 32 + (ky >> 1) * (PP * 32);
+      const int aa = acol[kx >> 1] + pbase;
+      af[set][0] = *(const bf16x8*)(S + aa);
+      af[set][1] = *(const bf16x8*)(S + aa + 2 * PP * 32);
+      bf[set][0] = *(const bf16x8*)(W + baddr + t * 4096);
+      bf[set][1] = *(const bf16x8*)(W + baddr + t * 4096 + 32 * 32);
+    };
+    frags(0, 0);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if (t + 1 < 9) frags(t + 1, (t + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[t & 1][ni], af[t & 1][mi], acc[mi][ni], 0, 0, 0);     // (operands swapped: see TR in conv_halo_kernel)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  const int nh = 2 * a.kc_per_tap;                              // 16-channel half-chunks
+  // prologue: A's first planes + the first weight stage
+  if (teamu == 0) { dma_planes(0); dma_weights(0, 0, 5); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int h = 0; h < nh; ++h) {
+    // phase 2 h: A computes h | B's planes of h and the first 20 pieces of the weights of h + 1 land (that stage was last read in phase 2 h - 1)
+    if (teamu == 0) half_chunk(h);
+    else { dma_planes(h); if (h + 1 < nh) dma_weights(h + 1, 0, 3); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // phase 2 h + 1: B computes h | A's planes of h + 1 and the other 16 weight pieces of h + 1 land
+    if (teamu == 1) half_chunk(h);
+    else if (h + 1 < nh) { dma_planes(h + 1); dma_weights(h + 1, 3, 5); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue (per team): bias / activation / gain in registers -> bf16 tile in LDS -> 16-byte coalesced stores ---------------------
+  constexpr int OROW = BN + 8;
+  constexpr int TEAM_EPI = 256 * OROW * (int)sizeof(__bf16) + 2 * BN * (int)sizeof(float);
+  __bf16* ot = (__bf16*)(smem + teamu * TEAM_EPI);
+  float* cbias = (float*)((char*)ot + 256 * OROW * sizeof(__bf16));
+  float* cpost = cbias + BN;
+  if (ltid < BN) { cbias[ltid] = ep_bias; cpost[ltid] = ep_post; }
+  __syncthreads();
+  {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    unsigned mw[2][2] = {{0u, 0u}, {0u, 0u}};
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ch = wn * 64 + ni * 32 + 8 * g + 4 * (lane >> 5);
+        const f32x4 bv = *(const f32x4*)(cbias + ch), pv = *(const f32x4*)(cpost + ch);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int row = wm * 64 + mi * 32 + (lane & 31);
+          bf16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float t = acc[mi][ni][4 * g + j] * pv[j] + bv[j];
+            o[j] = (__bf16)((a.act == ACT_LRELU ? (t > 0.f ? t : t * LRELU_SLOPE) : t) * a.gain);
+            if (MK) mw[mi][ni] |= ((__builtin_bit_cast(unsigned, t) - 1u) >> 31) << (8 * g + 4 * (lane >> 5) + j);
+          }
+          *(bf16x4*)(ot + row * OROW + ch) = o;
+        }
+      }
+    if (MK) {
+      const int words = a.Cout >> 5;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const unsigned wv = ~(mw[mi][ni] | (unsigned)__shfl_xor((int)mw[mi][ni], 32, 64));
+          const int row = wm * 64 + mi * 32 + (lane & 31);
+          const int py = ty * HT + (row >> 4), px = tx * HT + (row & 15);
+          const int wi = (n0 >> 5) + wn * 2 + ni;
+          if (lane < 32 && py < a.Hm && px < a.Wm && wi < words)
+            a.mask_out[((size_t)(b * a.Hout + py) * a.Wout + px) * words + wi] = wv;
+        }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int idx = ltid + k * 512;                              // 256 rows x 16 vectors
+    const int row = idx >> 4, vv = idx & 15;
+    const int py = ty * HT + (row >> 4), px = tx * HT + (row & 15);
+    const int n = n0 + vv * 8;
+    if (py >= a.Hm || px >= a.Wm || n >= a.Cout) continue;
+    *(bf16x8*)(a.y + ((size_t)(b * a.Hout + py) * a.Wout + px) * a.Cout + n) = *(const bf16x8*)(ot + row * OROW + vv * 8);
+  }
+}
+
 // =========================================================================================================
 // halo-tile kernel for NARROW layers (Cout <= 64: the C = 32 / 64 octaves of the 512 x 512 and 1024 x 1024 networks), stride-1
 // geometries.  conv_halo_kernel's 128-channel N tile wastes 2-4x of its MFMA work there and its 256-position tiles pay the
@@ -2208,8 +2415,23 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
 #undef LAUNCH_S2SM
       return true;
     }
+    // two anti-phased teams per 1024-thread workgroup (see conv_s2duo_kernel): plain epilogue only, whole tiles, an even number of them
+    if (g_s2duo && !a.pre && !a.xs && !a.residual && c.w_part != 0 && a.w_bstride == 0 && (c.Hm % HT) == 0 && (c.Wm % HT) == 0 && ((c.B * a.tiles_x * a.tiles_y) & 1) == 0 &&
+        (g_s2duo >= 2 || (long long)c.B * a.tiles_x * a.tiles_y * a.nblocks >= 2 * 256) && a.nsplit == 1) {     // (option 26 = 2: small grids too -- tests)
+      constexpr size_t DUO_SMEM = 2 * (size_t)42 * 1024 + 2 * (size_t)9 * 4096;        // 156 KB (the epilogue's 2 x 70 KB fit inside)
+      const dim3 dgrid((unsigned)(c.B * a.tiles_x * a.tiles_y / 2) * a.nblocks, 1, 1);
+#define LAUNCH_DUO(EP)                                                                                                  \
+  {                                                                                                                     \
+    static bool set = false;                                                                                            \
+    if (!set) { hipFuncSetAttribute((const void*)conv_s2duo_kernel<EP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
+    hipLaunchKernelGGL((conv_s2duo_kernel<EP>), dgrid, dim3(1024), DUO_SMEM, s, a);                                     \
+  }
+      if (a.mask_out) { g_mask_written = true; LAUNCH_DUO(4) } else LAUNCH_DUO(0)
+#undef LAUNCH_DUO
+      return true;
+    }
     if (single && !a.pre) {                                               // one stage per workgroup, two workgroups per CU
-      const size_t dsm1 = std::max(S2_SMEM / 2, HALO_EPI_SMEM);
+      const size_t dsm1 = (g_dbg_no_atomics & 32) ? (size_t)100 * 1024 : std::max(S2_SMEM / 2, HALO_EPI_SMEM);   // (option 3, bit 32: ONE workgroup per CU -- load and compute phases of a stage then do not overlap at all: the timing experiment behind DESIGN section 5's per-CU fill-rate model)
 #define LAUNCH_S2S(EP)                                                                                                  \
   {                                                                                                                     \
     static bool set = false;                                                                                            \
@@ -3330,6 +3552,7 @@ int lcgan_set_option(int option, int value) {
   if (option == 23) { const int old = g_flow_wgrad; g_flow_wgrad = value; return old; }
   if (option == 24) { const int old = g_halo_phase_x; g_halo_phase_x = value; return old; }
   if (option == 25) { const int old = g_wgrad_slab_bf16; g_wgrad_slab_bf16 = value; return old; }
+  if (option == 26) { const int old = g_s2duo; g_s2duo = value; return old; }
   if (option == 17) { const int old = g_wgrad_prescale_mb; g_wgrad_prescale_mb = value; return old; }
   if (option == 18) { const int old = g_halo_wmod_mb; g_halo_wmod_mb = value; return old; }
   return LCGAN_EINVAL;

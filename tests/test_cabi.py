@@ -53,12 +53,12 @@ def test_every_entry_point_cites_the_reference():
 
 
 def test_routing_switches_round_trip_and_reject_unknown():
-    """lcgan_set_option is host-only: each of the 26 switches the header lists returns its previous value, an unknown one LCGAN_EINVAL"""
+    """lcgan_set_option is host-only: each of the 27 switches the header lists returns its previous value, an unknown one LCGAN_EINVAL"""
     from lcgan_amd import _lib, build
     build.build(verbose=False)
     lib = _lib.load()
     hdr = re.sub(r"\s*\n\s*\*\s*", " ", open(os.path.join(ROOT, "include", "lcgan_hip.h")).read())
-    n_opt = 26
+    n_opt = 27
     assert f"; {n_opt - 1} " in hdr and f"; {n_opt} " not in hdr[hdr.index("tuning switches"):hdr.index("int lcgan_set_option")]
     for opt in range(n_opt):
         old = lib.lcgan_set_option(opt, 1)

@@ -1137,3 +1137,34 @@ def test_activation_sign_masks(H, case):
     a = H.box3_actbwd(gy, y, 1, 1.4, Co, True)
     b = H.box3_actbwd(gy, y, 1, 1.4, Co, True, mask=mask)
     assert torch.equal(a[0], b[0]) and torch.allclose(a[1], b[1], rtol=1e-5, atol=1e-5 * float(a[1].abs().max()))
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 128, 256), (4, 32, 32, 256, 512), (2, 64, 32, 64, 128), (6, 32, 32, 512, 128)])
+def test_conv_s2duo_kernel(H, case):
+    """conv_s2duo_kernel (two anti-phased teams per 1024-thread workgroup, option 26) against the one-stage stride-2 kernel it replaces:
+    the same operand images, tap order and accumulation order, hence bit-identical outputs and masks; plus the emulation."""
+    B, Hh, W, Ci, Co = case
+    dtype, k = torch.bfloat16, 3
+    x = feat((B, Hh, W, ceil8(Ci)), dtype, 1, Ci)
+    w = torch.randn(Co, Ci, k, k, generator=torch.Generator().manual_seed(2))
+    bias = torch.randn(Co, generator=torch.Generator().manual_seed(3))
+    scale = 1 / math.sqrt(Ci * k * k)
+    pw, _ = H.prep_weight(w.cuda(), scale, False, False)
+    pw_e, _ = E.prep_weight(w, scale, False, False)
+    old6 = H.lib.lcgan_set_option(6, 1)
+    outs = {}
+    try:
+        for duo in (0, 2):
+            old26 = H.lib.lcgan_set_option(26, duo)
+            try:
+                outs[duo] = (H.conv_fwd(x.cuda(), pw, Co, k, 2, bias=bias.cuda(), bias_scale=0.5, act=1, gain=1.4, want_mask=True),
+                             H.conv_fwd(x.cuda(), pw, Co, k, 2))
+            finally:
+                H.lib.lcgan_set_option(26, old26)
+    finally:
+        H.lib.lcgan_set_option(6, old6)
+    (ya, ma), pa = outs[0]
+    (yb, mb), pb = outs[2]
+    assert torch.equal(ya, yb) and torch.equal(pa, pb)
+    assert (ma is None) == (mb is None) and (ma is None or torch.equal(ma, mb))
+    check(yb, E.conv_fwd(x, pw_e, Co, k, 2, bias=bias, bias_scale=0.5, act=1, gain=1.4), dtype, "duo vs emulation")
