@@ -188,7 +188,7 @@ class WORKER(object):
         rand2 = self._randn(self.args.app_noise_dim)
         odd = epoch % 2 == 1
 
-        if config.batched_passes() and (epoch % 8 != 1 or self._r1_batched()):
+        if self._can_batch(2 if odd else 4) and (epoch % 8 != 1 or self._r1_batched()):
             return self._train_discriminator_batched(epoch, image, geometry_change, appearance_change, rand1, rand2)
         # (1) everything that only needs D's parameters: the real-image passes.  With N > 1 these overlap G's gradient all-reduce.
         if odd:
@@ -218,6 +218,14 @@ class WORKER(object):
         d_loss.backward()
         self._after_backward("d", self.discriminator, self.d_optimizer)
         return LazyLoss(d_loss)
+
+    def _can_batch(self, n_sub: int) -> bool:
+        """n_sub calls as one batch only while the largest feature map of the merged pass (n_sub x local batch x R^2 x the full-resolution
+        channel count, cnn.py:17,54) stays addressable by the fast kernels' 32-bit element offsets (and the warp kernels' 4 GB): at
+        1024 x 1024 / batch 32 on ONE GPU three generator calls would be 3.2e9 elements -- those configurations keep the reference's
+        separate calls"""
+        res = self.args.img_resolution
+        return config.batched_passes() and n_sub * self.local_batch_size * res * res * cnn._base_nf(res) < (1 << 31) - (1 << 24)
 
     def _r1_batched(self) -> bool:
         """R1 iterations too evaluate [real | fake] as one discriminator batch when the local batch is small enough that the step is bound
@@ -269,7 +277,7 @@ class WORKER(object):
         resample2 = self._randn(self.args.app_noise_dim)
 
         # G forwards need only G's parameters: with N > 1 they overlap the all-reduce of the previous D step's gradients
-        batched = config.batched_passes() and epoch % 2 == 0
+        batched = epoch % 2 == 0 and self._can_batch(3)
         if epoch % 2 == 1:
             images = (self.generator(rand1, rand2),)
         elif batched:

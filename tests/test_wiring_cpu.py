@@ -389,3 +389,31 @@ def test_inputs_only_flag_rejects_an_overlapping_backward_pass():
     w.grad = None
     y2.backward()                                                       # outside the flag: ordinary backward, weight gradient formed
     assert w.grad is not None
+
+
+def test_batched_passes_are_bounded_by_addressable_size():
+    """the merged pass of n_sub calls must keep its largest feature map under the fast kernels' 32-bit element offsets: the single-GPU
+    high-resolution recipes (1024 x 1024 / batch 32: 3.2e9 elements for three generator calls) keep the reference's separate calls"""
+    from lcgan_amd import worker
+    def can(res, local_batch, n_sub):
+        w = worker.WORKER.__new__(worker.WORKER)
+        w.args, w.local_batch_size = type("A", (), {"img_resolution": res})(), local_batch
+        return w._can_batch(n_sub)
+    assert can(256, 32, 4) and can(512, 32, 3) and can(512, 8, 4) and can(1024, 4, 4)
+    assert not can(512, 32, 4) and not can(1024, 32, 2) and not can(1024, 32, 3)
+
+
+def test_bench_quotes_pmc_traffic_only_for_the_profiled_sources(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic comes from profiles/r04_pmc_traffic.json and is null unless the kernel sources of the running build hash
+    to what the profiled build hashed to"""
+    import json, bench
+    from lcgan_amd.build import source_hash
+    (tmp_path / "profiles").mkdir()
+    fam = {"families": {"conv_halo": {"launches": 246, "bytes_per_launch": 5.0e8}}, "amplification": {"conv fwd/dgrad": {"total_over_algorithmic": 1.26}}, "_commit": "abc"}
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    json.dump({**fam, "_srchash": source_hash()}, open(tmp_path / "profiles" / "r04_pmc_traffic.json", "w"))
+    t = bench.committed_traffic()
+    assert t["bytes_per_launch"] == 5.0e8 and t["same_kernel_sources_as_this_build"] and t["total_over_algorithmic_bytes"] == 1.26
+    json.dump({**fam, "_srchash": "stale"}, open(tmp_path / "profiles" / "r04_pmc_traffic.json", "w"))
+    t = bench.committed_traffic()
+    assert t["bytes_per_launch"] is None and t["stale_bytes_per_launch"] == 5.0e8 and not t["same_kernel_sources_as_this_build"]
