@@ -1600,9 +1600,19 @@ int lcgan_warp_fwd(const void* x, const void* flow, void* y, int B, int H, int W
   hipStream_t s = (hipStream_t)stream;
   if ((C & 7) || H < 2 || W < 2) return LCGAN_EINVAL;
   const long long n = (long long)B * H * W * (C / 8);
+  const size_t esz = dtype == DT_BF16 ? 2 : 4;
+  if ((long long)W * C * 4 >= (1 << 24)) return LCGAN_EINVAL;    // 24-bit factors of the tap addressing
+  if ((double)n * 8 * esz >= 4294967296.0 || (long long)B * H >= (1 << 24)) {
+    // 32-bit byte offsets: a batch of 4 GB or more goes in two halves (samples are independent), recursively
+    if (B < 2) return LCGAN_EINVAL;
+    const int B1 = B / 2;
+    const size_t o = (size_t)B1 * H * W;
+    const int rc = lcgan_warp_fwd(x, flow, y, B1, H, W, C, scale, dtype, stream);
+    if (rc != LCGAN_OK) return rc;
+    return lcgan_warp_fwd((const char*)x + o * C * esz, (const char*)flow + o * 8 * esz, (char*)y + o * C * esz, B - B1, H, W, C, scale, dtype, stream);
+  }
   Tag tg("warp_fwd", B, H, W, C);
-  ProfScope p(KID_WARP_FWD, 0, (double)n * 8 * 2 * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
-  if ((double)n * 8 * (dtype == DT_BF16 ? 2 : 4) >= 4294967296.0 || (long long)W * C * 4 >= (1 << 24) || (long long)B * H >= (1 << 24)) return LCGAN_EINVAL;     // 32-bit byte offsets, 24-bit factors
+  ProfScope p(KID_WARP_FWD, 0, (double)n * 8 * 2 * esz, s, tg.s);
   const WarpDims dm = warp_dims(C, H, W);
   DISPATCH_T(dtype, hipLaunchKernelGGL(warp_fwd_kernel<T>, grid1d(n), dim3(TPB), 0, s, (const T*)x, (const T*)flow, (T*)y, B, H, W, C, scale, dm));
   return launch_status();
@@ -1617,11 +1627,20 @@ int lcgan_warp_bwd(const void* gy, const void* x, const void* flow, void* gx, vo
                    int* ws_cnt, int* ws_off, int* ws_tiles, void* ws_ent,
                    int B, int H, int W, int C, float scale, int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if ((C & 7) || !pow2_le64(C / 8) || H < 2 || W < 2 || (long long)B * H * W * 16 >= (1ll << 31)) return LCGAN_EINVAL;
+  if ((C & 7) || !pow2_le64(C / 8) || H < 2 || W < 2 || (long long)W * C * 4 >= (1 << 24)) return LCGAN_EINVAL;
   const long long npix = (long long)B * H * W, n = npix * (C / 8);
   const double eb = dtype == DT_BF16 ? 2 : 4;
-  // 32-bit byte offsets and 24-bit multiplies in the tap addressing (see warp_fwd_kernel)
-  if ((double)n * 8 * eb >= 4294967296.0 || (long long)W * C * 4 >= (1 << 24) || (long long)B * H >= (1 << 24)) return LCGAN_EINVAL;
+  // 32-bit byte offsets and list indices: a batch beyond them goes in two halves (samples are independent; the workspaces are reused,
+  // the launches are stream-ordered), recursively
+  if ((double)n * 8 * eb >= 4294967296.0 || (long long)B * H >= (1 << 24) || npix * 16 >= (1ll << 31)) {
+    if (B < 2) return LCGAN_EINVAL;
+    const int B1 = B / 2;
+    const size_t o = (size_t)B1 * H * W, es = (size_t)eb;
+    const int rc = lcgan_warp_bwd(gy, x, flow, gx, gflow, ws_cnt, ws_off, ws_tiles, ws_ent, B1, H, W, C, scale, dtype, stream);
+    if (rc != LCGAN_OK) return rc;
+    return lcgan_warp_bwd((const char*)gy + o * C * es, (const char*)x + o * C * es, (const char*)flow + o * 8 * es, (char*)gx + o * C * es,
+                          (char*)gflow + o * 8 * es, ws_cnt, ws_off, ws_tiles, ws_ent, B - B1, H, W, C, scale, dtype, stream);
+  }
   const WarpDims dm = warp_dims(C, H, W);
   Tag tg("warp_bwd", B, H, W, C);
   ProfScope p(KID_WARP_BWD, 0, (double)n * 8 * 4 * eb + (double)npix * 16 * 8 * 2, s, tg.s);

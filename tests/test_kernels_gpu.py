@@ -1168,3 +1168,23 @@ def test_conv_s2duo_kernel(H, case):
     assert torch.equal(ya, yb) and torch.equal(pa, pb)
     assert (ma is None) == (mb is None) and (ma is None or torch.equal(ma, mb))
     check(yb, E.conv_fwd(x, pw_e, Co, k, 2, bias=bias, bias_scale=0.5, act=1, gain=1.4), dtype, "duo vs emulation")
+
+
+def test_warp_of_4_gb_and_more_goes_in_halves(H):
+    """a feature map of 4 GB or more is beyond the warp kernels' 32-bit byte offsets: the entry points process the batch in halves (samples are
+    independent) instead of refusing it; the result equals the per-sample calls"""
+    B, R, C = 4, 1024, 512                                    # 4 x 1024 x 1024 x 512 bf16 = exactly 4 GiB (the backward takes at most 512 channels)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(B, R, R, C, device="cuda", dtype=torch.bfloat16, generator=g)
+    flow = torch.zeros(B, R, R, 8, device="cuda", dtype=torch.bfloat16)
+    flow[..., :2] = torch.randn(B, R, R, 2, device="cuda", generator=g).clamp(-1, 1).bfloat16()
+    y = H.warp_fwd(x, flow, 0.1)
+    for b in range(B):
+        assert torch.equal(y[b:b + 1], H.warp_fwd(x[b:b + 1].contiguous(), flow[b:b + 1].contiguous(), 0.1))
+    gy = torch.randn(B, R, R, C, device="cuda", dtype=torch.bfloat16, generator=g)
+    gx, gflow = H.warp_bwd(gy, x, flow, 0.1)
+    for b in range(B):
+        gx1, gf1 = H.warp_bwd(gy[b:b + 1].contiguous(), x[b:b + 1].contiguous(), flow[b:b + 1].contiguous(), 0.1)
+        assert torch.equal(gflow[b:b + 1], gf1)
+        # (the transposed lists of one sample are filled through integer atomics: their ORDER, hence the fp32 summation order, differs from run to run)
+        assert float((gx[b:b + 1].float() - gx1.float()).abs().max()) <= 2.0 ** -6 * float(gx1.float().abs().max())
