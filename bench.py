@@ -129,6 +129,8 @@ def main():
     ap.add_argument("--cpu-baseline-cycle", action="store_true", help="time a full warmed 8-iteration cycle of the CPU oracle at batch 4 (~4 minutes) instead of one iteration per type")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--launch-table", default="", help="write the per-launch table (HIP events, conv geometry tags) of one more iteration here")
+    ap.add_argument("--h2d", action="store_true", help="PCIe-inclusive variant: the three views of every iteration come from pinned host memory "
+                    "(async copy one iteration ahead, worker.SyntheticHostTriples) instead of being resident in HBM; never the headline value")
     ap.add_argument("--no-cycle", action="store_true", help="skip the extra 8-iteration cycle (epoch 8..15) reported beside the R1 line")
     a = ap.parse_args()
 
@@ -166,6 +168,8 @@ def main():
     assert kernels.backend_name() == "hip" or not on_gpu
     extra = dict(freezeD_start=0, freezeD_layer=a.freezeD_layer) if a.freezeD_layer >= 0 else {}
     args = make_args(a.res, a.batch, **extra)
+    if a.h2d:
+        args.dataset_path = "synthetic-host"
     torch.manual_seed(0)                                   # identical reference-style init on every rank
     w = worker.WORKER(args, local_rank, world, device=dev)
     torch.manual_seed(1 + rank)                            # different latents per rank
@@ -198,7 +202,7 @@ def main():
     out = {
         "metric": "images/sec (G+D step)", "value": value, "unit": "images/sec", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "vs_baseline": None, "dtype": a.dtype, "data": "synthetic, views copied from pinned host memory every iteration" if a.h2d else "synthetic",
         "config": {"workload": f"LC-GAN G+D iteration ({a.epoch_type}: train_generator + ema + train_discriminator"
                                f"{' with R1' if a.epoch_type == 'r1' else ''}), {a.res}x{a.res}, global batch {a.batch}"
                                f"{f', freezeD_layer {a.freezeD_layer}' if a.freezeD_layer >= 0 else ''}",

@@ -100,6 +100,47 @@ class SyntheticTriples:
         return item
 
 
+class SyntheticHostTriples:
+    """The same batches held in PINNED HOST memory and copied to the device per iteration, as the reference's three `.to(device)` of a
+    DataLoader batch do (worker.py:141-143): the copy of batch i + 1 runs on a side stream while iteration i computes (two device
+    buffers in turn), `next()` makes the compute stream wait for the copy it hands out.  `--dataset_path synthetic-host`; the
+    PCIe-inclusive bench line (`bench.py --h2d`)."""
+
+    def __init__(self, batch, res, device, seed=1234, pool=4):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        self.device = torch.device(device)
+        cuda = self.device.type == "cuda"
+        self.hosts = [tuple((torch.rand(batch, 3, res, res, generator=g) * 2 - 1) for _ in range(3)) for _ in range(pool)]
+        if cuda:
+            self.hosts = [tuple(t.pin_memory() for t in item) for item in self.hosts]
+        self.copy_stream = torch.cuda.Stream(device=self.device) if cuda else None
+        self.i = 0
+        self._ahead = None
+        self._submit()
+
+    def _submit(self):
+        item = self.hosts[self.i % len(self.hosts)]
+        self.i += 1
+        if self.copy_stream is None:
+            self._ahead = (tuple(t.clone() for t in item), None)
+            return
+        with torch.cuda.stream(self.copy_stream):
+            dev = tuple(t.to(self.device, non_blocking=True) for t in item)
+            done = torch.cuda.Event()
+            done.record(self.copy_stream)
+        self._ahead = (dev, done)
+
+    def next(self):
+        dev, done = self._ahead
+        if done is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(done)
+            for t in dev:
+                t.record_stream(cur)                     # allocated on the copy stream, consumed on the compute stream
+        self._submit()
+        return dev
+
+
 class WORKER(object):
     def __init__(self, args, local_rank, gpus_per_node, device=None):
         self.args = args
@@ -143,6 +184,8 @@ class WORKER(object):
     # ---- data -----------------------------------------------------------------------------------------------------
     def prepare_training_dataset(self):
         path = str(getattr(self.args, "dataset_path", "synthetic"))
+        if path == "synthetic-host":
+            return SyntheticHostTriples(self.local_batch_size, self.args.img_resolution, self.device, seed=1234 + self.local_rank)
         if path.startswith("synthetic"):
             return SyntheticTriples(self.local_batch_size, self.args.img_resolution, self.device, seed=1234 + self.local_rank)
         from .data import FolderTriples                                            # custom_dataset.py:10-100, worker.py:44-73

@@ -417,3 +417,12 @@ def test_bench_quotes_pmc_traffic_only_for_the_profiled_sources(tmp_path, monkey
     json.dump({**fam, "_srchash": "stale"}, open(tmp_path / "profiles" / "r04_pmc_traffic.json", "w"))
     t = bench.committed_traffic()
     assert t["bytes_per_launch"] is None and t["stale_bytes_per_launch"] == 5.0e8 and not t["same_kernel_sources_as_this_build"]
+
+
+def test_host_resident_synthetic_source_hands_out_the_resident_batches():
+    """`--dataset_path synthetic-host` (bench.py --h2d): the batches of the resident source, in the same order, through the copy-ahead path"""
+    from lcgan_amd.worker import SyntheticHostTriples, SyntheticTriples
+    a, b = SyntheticTriples(2, 8, "cpu", seed=7, pool=3), SyntheticHostTriples(2, 8, "cpu", seed=7, pool=3)
+    for _ in range(5):
+        for x, y in zip(a.next(), b.next()):
+            assert torch.equal(x, y)
