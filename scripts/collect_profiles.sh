@@ -12,3 +12,8 @@ cp gpurun_out/pmc_traffic.txt profiles/r04_pmc_traffic.txt
 cp gpurun_out/sq_counters.txt profiles/r04_sq_counters.txt
 cp gpurun_out/parity_achieved.json profiles/r04_parity_achieved.json
 (for f in v_odd v_even v_fp8 v_f32 v_c3rank v_c4rank b16 b8 b4 b4cycle b512 b1024; do echo "# $f"; tail -1 gpurun_out/$f.log; done) > profiles/r04_bench_variants.txt
+if [ -f gpurun_out/h2d_on.json ]; then      # the PCIe-inclusive A/B (bench.py --h2d), when that call was made
+  (echo; echo "# PCIe-inclusive variant (bench.py --h2d: the three views of every iteration copied from pinned host memory one iteration ahead on a side stream,"
+   echo "# worker.SyntheticHostTriples = the reference's three .to(device) of worker.py:141-143), A/B on ONE box; never the headline value"
+   for f in off on off_b4 on_b4; do echo -n "h2d_$f: "; tail -1 gpurun_out/h2d_$f.json; done) >> profiles/r04_bench_variants.txt
+fi
