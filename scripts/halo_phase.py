@@ -1,6 +1,8 @@
-"""Do the two workgroups a CU holds run conv_halo_kernel's main loop at the same time?  Per stagger setting (option 27) the launch
-time and -- with a -DHALO_STAMPS build -- per CU the share of the launch with two / one / no workgroup inside its main loop.
-  python scripts/halo_phase.py <lib.so> [stagger values in 0.1 us ...]"""
+"""Do the two workgroups a CU holds run conv_halo_kernel's main loop at the same time?  With a -DHALO_STAMPS build: per CU the share of
+the launch with two / one / no workgroup inside its main loop.  (The round-4 experiment that delayed the second workgroup of every CU --
+`lcgan_set_option(27, tenths of a microsecond)`, profiles/r04_halo_phase_stagger.txt -- is not in the tree: a library without that
+option runs the undelayed case only.)
+  python scripts/halo_phase.py <lib.so> [start delays in 0.1 us ...]"""
 import ctypes as C, math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -20,7 +22,8 @@ for (kind, Hh, Ci, Co, st) in cases:
     fn = (lambda: K.conv_bwd_data(g, pw, Ci, 3, st)) if kind == "tconv" else (lambda: K.conv_fwd(x, pw, Co, 3, st, act=1, gain=1.4))
     ref = None
     for v in vals:
-        K.lib.lcgan_set_option(27, v)
+        if K.lib.lcgan_set_option(27, v) < 0 and v != 0:
+            continue
         for _ in range(3):
             y = fn()
         torch.cuda.synchronize()
@@ -37,7 +40,7 @@ for (kind, Hh, Ci, Co, st) in cases:
         buf = (C.c_ulonglong * (16384 * 5))()
         if has_life and K.lib.lcgan_halo_life(buf) == 0:
             a = np.array(buf[:], dtype=np.float64).reshape(16384, 5)
-            idx = np.nonzero(a[:, 0] > 0)[0]
+            idx = np.nonzero(a[:, 0] >= a[:, 3].max() - 2 * np.median(ts) * 100)[0]      # this launch's entries (the buffer is never cleared)
             a = a[idx]
             t0, t1 = a[:, 0].min(), a[:, 3].max()
             cu = (idx & 7) * 256 + ((a[:, 4].astype(np.int64) >> 8) & 0xff)          # 1-D launches: XCD = block id mod 8
