@@ -110,6 +110,11 @@ int lcgan_act_bwd_reduce(const void* gy, const void* y, void* gz, const float* b
  * channel 8 v + j; needs act == leaky ReLU and gdq == NULL; y may then be NULL.  mask == NULL: lcgan_act_bwd_reduce. */
 int lcgan_act_bwd_reduce_m(const void* gy, const void* y, const void* mask, void* gz, const float* bias, float bias_scale,
                            float* gbias, float* gdq, int B, int HW, int C, int Clog, int act, float gain, int dtype, void* stream);
+/* ... storing gz * oscale[b][c] (oscale: [B][C] fp32; needs gz and gdq) while gbias / gdq reduce the unscaled gz: a ModulatedConv2d's
+ * data- and weight-gradient launches both consume d[b,o] * gz (the demodulation of custom_layers.py:72-76 read backwards) and then take
+ * their operand without a per-sample scale.  oscale == NULL: lcgan_act_bwd_reduce_m. */
+int lcgan_act_bwd_reduce_s(const void* gy, const void* y, const void* mask, void* gz, const float* oscale, const float* bias, float bias_scale,
+                           float* gbias, float* gdq, int B, int HW, int C, int Clog, int act, float gain, int dtype, void* stream);
 /* style gradient: gs[b,c] += sum_p x*u ; u <- s[b,c]*u in place   (autograd of custom_layers.py:62-64) */
 int lcgan_scale_reduce(void* u, const void* x, const float* s, float* gs, int B, int HW, int C, int dtype, void* stream);
 /* ... with u <- s*u + res (res may be NULL): the data gradient another consumer of the same tensor already produced joins here
@@ -152,6 +157,10 @@ int lcgan_rgb_expand_bwd_r(const void* gy, const void* y, const float* img, cons
 int lcgan_rgb_reduce_bwd_act(const float* gimg, const void* y, const float* wm, const float* bias, float bias_scale, void* gz,
                              float* gbias, float* gdq, float* gwm, int B, int HW, int C, int Clog, int per_sample, int act, float gain,
                              int dtype, void* stream);
+/* ... storing gz * oscale[b][c] (oscale [B][C] fp32 or NULL), the reductions unscaled: see lcgan_act_bwd_reduce_s */
+int lcgan_rgb_reduce_bwd_act_s(const float* gimg, const void* y, const float* wm, const float* bias, float bias_scale, void* gz, const float* oscale,
+                               float* gbias, float* gdq, float* gwm, int B, int HW, int C, int Clog, int per_sample, int act, float gain,
+                               int dtype, void* stream);
 /* the 2-channel flow layer of a SynthesisBlock (ModulatedConv2d(Cin -> 2, k 3, up 2), custom_layers.py:123,149-151; F.conv_transpose2d
  * :73-80) as a 1x1 convolution Cin -> 18 on the low-resolution grid (lcgan_conv_fwd with the [18][Cin] weight (ky*3+kx)*2+o) followed by
  * lcgan_flow_col2im: u[b,2i-1+ky,2j-1+kx,o] += d[b,o] * t[b,i,j,(ky*3+kx)*2+o] (+ bias[o]); lcgan_flow_im2col is its adjoint

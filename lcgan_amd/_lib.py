@@ -33,6 +33,7 @@ SIGNATURES = {
     "lcgan_avgpool2_bwd": [P, P, I, I, I, I, I, P],
     "lcgan_act_bwd_reduce": [P, P, P, P, F, P, P, I, I, I, I, I, F, I, P],
     "lcgan_act_bwd_reduce_m": [P, P, P, P, P, F, P, P, I, I, I, I, I, F, I, P],
+    "lcgan_act_bwd_reduce_s": [P, P, P, P, P, P, F, P, P, I, I, I, I, I, F, I, P],
     "lcgan_scale_reduce": [P, P, P, P, I, I, I, I, P],
     "lcgan_scale_reduce_res": [P, P, P, P, P, I, I, I, I, P],
     "lcgan_warp_fwd": [P, P, P, I, I, I, I, F, I, P],
@@ -47,6 +48,7 @@ SIGNATURES = {
     "lcgan_rgb_expand_bwd": [P, P, P, P, P, P, P, I, I, I, I, I, I, F, I, P],
     "lcgan_rgb_expand_bwd_r": [P, P, P, P, P, F, I, P, P, P, I, I, I, I, I, I, F, I, P],
     "lcgan_rgb_reduce_bwd_act": [P, P, P, P, F, P, P, P, P, I, I, I, I, I, I, F, I, P],
+    "lcgan_rgb_reduce_bwd_act_s": [P, P, P, P, F, P, P, P, P, P, I, I, I, I, I, I, F, I, P],
     "lcgan_flow_col2im": [P, P, P, P, I, I, I, I, I, P],
     "lcgan_flow_im2col": [P, P, P, I, I, I, I, I, P],
     "lcgan_nchw_to_nhwc": [P, P, I, I, I, I, I, I, P],

@@ -63,6 +63,18 @@ def act_masks() -> bool:
     return _act_masks
 
 
+_gz_demod = _os.environ.get("LCGAN_GZ_DEMOD", "1") != "0"     # A/B switch: a modulated convolution's activation backward stores d[b,o] * gz, so that its data- and weight-gradient launches run without a per-sample operand scale (ops._modconv_backward)
+
+
+def gz_demod() -> bool:
+    return _gz_demod
+
+
+def set_gz_demod(on: bool) -> None:
+    global _gz_demod
+    _gz_demod = bool(on)
+
+
 def set_act_masks(on: bool) -> None:
     global _act_masks
     _act_masks = bool(on)

@@ -340,7 +340,7 @@ __global__ void avgpool2_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx
 // accumulator set nor its arithmetic (128 -> fewer registers, one more wave per SIMD).
 template <typename T, bool GDQ>
 __global__ void act_bwd_reduce_kernel(const T* __restrict__ gy, const T* __restrict__ y, const unsigned char* __restrict__ mask, T* __restrict__ gz,
-                                      const float* __restrict__ bias, float bias_scale,
+                                      const float* __restrict__ oscale, const float* __restrict__ bias, float bias_scale,
                                       float* __restrict__ gbias, float* __restrict__ gdq,
                                       int HW, int C, int Clog, int act, float gain, int P) {
   __shared__ float red[GDQ ? 2 : 1][TPB * 8];
@@ -350,12 +350,18 @@ __global__ void act_bwd_reduce_kernel(const T* __restrict__ gy, const T* __restr
   const int b = blockIdx.y;
   const int p0 = blockIdx.x * P, p1 = min(p0 + P, HW);
   const bool active = grp < groups;
-  float sb[8], sq[8], bv[8];
+  float sb[8], sq[8], bv[8], ov[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { sb[j] = 0.f; sq[j] = 0.f; bv[j] = 0.f; }
+  for (int j = 0; j < 8; ++j) { sb[j] = 0.f; sq[j] = 0.f; bv[j] = 0.f; ov[j] = 1.f; }
   if (GDQ && active && bias) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) bv[j] = (v * 8 + j < Clog) ? bias[v * 8 + j] * bias_scale : 0.f;
+  }
+  // oscale [B][C] (GDQ instantiation): the STORED gradient is gz * oscale[b, c] -- a modulated convolution's data- and weight-gradient
+  // launches both consume d[b, o] * gz, which they otherwise form per sample while staging -- the reductions see the unscaled gz
+  if (GDQ && active && oscale) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ov[j] = oscale[(size_t)b * C + v * 8 + j];
   }
   if (active) {
     const bool need_y = act != ACT_NONE || GDQ;
@@ -370,6 +376,7 @@ __global__ void act_bwd_reduce_kernel(const T* __restrict__ gy, const T* __restr
           float t = yo.v[j] * inv_gain;
           if (act == ACT_LRELU && t < 0.f) t *= (1.f / LRELU_SLOPE);
           sq[j] += z.v[j] * (t - bv[j]);
+          z.v[j] *= ov[j];
         }
       }
       if (gz) Feat<T>::store(gz + off, z);
@@ -1340,7 +1347,7 @@ __global__ void rgb_expand_bwd_kernel(const T* __restrict__ gy, const T* __restr
 //   gwm[bw,o,c] += sum_p gimg[b,o,p] y[b,p,c]
 template <typename T>
 __global__ void rgb_reduce_bwd_act_kernel(const float* __restrict__ gimg, const T* __restrict__ y, const float* __restrict__ wm,
-                                          const float* __restrict__ bias, float bias_scale, T* __restrict__ gz,
+                                          const float* __restrict__ bias, float bias_scale, T* __restrict__ gz, const float* __restrict__ oscale,
                                           float* __restrict__ gbias, float* __restrict__ gdq, float* __restrict__ gwm,
                                           int HW, int C, int Clog, int per_sample, int act, float gain, int P) {
   __shared__ float red[5][TPB * 8];
@@ -1350,13 +1357,14 @@ __global__ void rgb_reduce_bwd_act_kernel(const float* __restrict__ gimg, const 
   const int b = blockIdx.y;
   const bool active = grp < groups;
   const float* wb = wm + (per_sample ? (size_t)b * 3 * C : 0);
-  float w0[8], w1[8], w2[8], a0[8], a1[8], a2[8], sb[8], sq[8], bv[8];
+  float w0[8], w1[8], w2[8], a0[8], a1[8], a2[8], sb[8], sq[8], bv[8], ov[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = v * 8 + j;
     const bool ok = active && c < Clog;
     w0[j] = ok ? wb[c] : 0.f; w1[j] = ok ? wb[C + c] : 0.f; w2[j] = ok ? wb[2 * C + c] : 0.f;
     bv[j] = (ok && bias) ? bias[c] * bias_scale : 0.f;
+    ov[j] = (active && oscale) ? oscale[(size_t)b * C + c] : 1.f;           // the stored gz carries it, the reductions do not (see act_bwd_reduce_kernel)
     a0[j] = 0.f; a1[j] = 0.f; a2[j] = 0.f; sb[j] = 0.f; sq[j] = 0.f;
   }
   const int p0 = blockIdx.x * P, p1 = min(p0 + P, HW);
@@ -1388,6 +1396,7 @@ __global__ void rgb_reduce_bwd_act_kernel(const float* __restrict__ gimg, const 
           if (act == ACT_LRELU && t < 0.f) t *= (1.f / LRELU_SLOPE);
           sq[j] += z.v[j] * (t - bv[j]);
           a0[j] += im[u][0] * yo[u].v[j]; a1[j] += im[u][1] * yo[u].v[j]; a2[j] += im[u][2] * yo[u].v[j];
+          z.v[j] *= ov[j];
         }
         Feat<T>::store(gz + ((size_t)b * HW + pb + u * groups) * C + v * 8, z);
       }
@@ -1465,6 +1474,11 @@ int lcgan_rgb_expand_bwd_r(const void* gy, const void* y, const float* img, cons
                            float* gimg, float* gw, float* gbias, int B, int HW, int C, int Clog, int per_sample, int act, float gain, int dtype, void* stream);
 int lcgan_act_bwd_reduce_m(const void* gy, const void* y, const void* mask, void* gz, const float* bias, float bias_scale,
                            float* gbias, float* gdq, int B, int HW, int C, int Clog, int act, float gain, int dtype, void* stream);
+int lcgan_act_bwd_reduce_s(const void* gy, const void* y, const void* mask, void* gz, const float* oscale, const float* bias, float bias_scale,
+                           float* gbias, float* gdq, int B, int HW, int C, int Clog, int act, float gain, int dtype, void* stream);
+int lcgan_rgb_reduce_bwd_act_s(const float* gimg, const void* y, const float* wm, const float* bias, float bias_scale, void* gz, const float* oscale,
+                               float* gbias, float* gdq, float* gwm, int B, int HW, int C, int Clog, int per_sample, int act, float gain,
+                               int dtype, void* stream);
 int lcgan_box3_actbwd_reduce_m(const void* gy, const void* y, const void* mask, void* gz, float* gbias, int B, int H, int W, int C, int Clog,
                                int act, float gain, int dtype, void* stream);
 
@@ -1565,9 +1579,16 @@ int lcgan_act_bwd_reduce(const void* gy, const void* y, void* gz, const float* b
 // ... with the activation's sign mask (lcgan_conv_fwd_m) instead of y: mask != NULL needs act == leaky ReLU and no gdq; y may then be NULL
 int lcgan_act_bwd_reduce_m(const void* gy, const void* y, const void* mask, void* gz, const float* bias, float bias_scale,
                            float* gbias, float* gdq, int B, int HW, int C, int Clog, int act, float gain, int dtype, void* stream) {
+  return lcgan_act_bwd_reduce_s(gy, y, mask, gz, nullptr, bias, bias_scale, gbias, gdq, B, HW, C, Clog, act, gain, dtype, stream);
+}
+// ... storing gz * oscale[b][c] (oscale: [B][C] fp32, needs gz and gdq) while gbias / gdq reduce the unscaled gz: the gradient a modulated
+// convolution's backward launches consume already carries the demodulation factor (custom_layers.py:72-76 read backwards)
+int lcgan_act_bwd_reduce_s(const void* gy, const void* y, const void* mask, void* gz, const float* oscale, const float* bias, float bias_scale,
+                           float* gbias, float* gdq, int B, int HW, int C, int Clog, int act, float gain, int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if ((C & 7) || C / 8 > TPB || Clog > C) return LCGAN_EINVAL;
   if (mask && (act != ACT_LRELU || gdq)) return LCGAN_EINVAL;
+  if (oscale && (!gz || !gdq)) return LCGAN_EINVAL;
   const int P = reduce_P(HW, B);
   dim3 grid(cdiv(HW, P), B);
   const unsigned char* mk = (const unsigned char*)mask;
@@ -1575,9 +1596,9 @@ int lcgan_act_bwd_reduce_m(const void* gy, const void* y, const void* mask, void
   const double esz = dtype == DT_BF16 ? 2 : 4;
   ProfScope p(KID_ACT_BWD, 0, (double)B * HW * C * ((gz ? 2 : 1) * esz + (mask ? 0.125 : esz)), s, tg.s);
   if (gdq) { DISPATCH_T(dtype, hipLaunchKernelGGL((act_bwd_reduce_kernel<T, true>), grid, dim3(TPB), 0, s, (const T*)gy, (const T*)y, mk, (T*)gz,
-                                                 bias, bias_scale, gbias, gdq, HW, C, Clog, act, gain, P)); }
+                                                 oscale, bias, bias_scale, gbias, gdq, HW, C, Clog, act, gain, P)); }
   else { DISPATCH_T(dtype, hipLaunchKernelGGL((act_bwd_reduce_kernel<T, false>), grid, dim3(TPB), 0, s, (const T*)gy, (const T*)y, mk, (T*)gz,
-                                              bias, bias_scale, gbias, gdq, HW, C, Clog, act, gain, P)); }
+                                              oscale, bias, bias_scale, gbias, gdq, HW, C, Clog, act, gain, P)); }
   return launch_status();
 }
 
@@ -1791,13 +1812,19 @@ int lcgan_rgb_expand_bwd_r(const void* gy, const void* y, const float* img, cons
 int lcgan_rgb_reduce_bwd_act(const float* gimg, const void* y, const float* wm, const float* bias, float bias_scale, void* gz,
                              float* gbias, float* gdq, float* gwm, int B, int HW, int C, int Clog, int per_sample, int act, float gain,
                              int dtype, void* stream) {
+  return lcgan_rgb_reduce_bwd_act_s(gimg, y, wm, bias, bias_scale, gz, nullptr, gbias, gdq, gwm, B, HW, C, Clog, per_sample, act, gain, dtype, stream);
+}
+// ... storing gz * oscale[b][c] (oscale [B][C] fp32 or NULL; see lcgan_act_bwd_reduce_s)
+int lcgan_rgb_reduce_bwd_act_s(const float* gimg, const void* y, const float* wm, const float* bias, float bias_scale, void* gz, const float* oscale,
+                               float* gbias, float* gdq, float* gwm, int B, int HW, int C, int Clog, int per_sample, int act, float gain,
+                               int dtype, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if ((C & 7) || C / 8 > TPB || Clog > C || !gwm || !gz) return LCGAN_EINVAL;
   const int P = reduce_P(HW, B);
   dim3 grid(cdiv(HW, P), B);
   Tag tg("rgb_reduce_bwd_act", B, HW, 1, C);
   ProfScope p(KID_RGB, 0, (double)B * HW * C * 2 * (dtype == DT_BF16 ? 2 : 4), s, tg.s);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(rgb_reduce_bwd_act_kernel<T>, grid, dim3(TPB), 0, s, gimg, (const T*)y, wm, bias, bias_scale, (T*)gz,
+  DISPATCH_T(dtype, hipLaunchKernelGGL(rgb_reduce_bwd_act_kernel<T>, grid, dim3(TPB), 0, s, gimg, (const T*)y, wm, bias, bias_scale, (T*)gz, oscale,
                                        gbias, gdq, gwm, HW, C, Clog, per_sample, act, gain, P));
   return launch_status();
 }

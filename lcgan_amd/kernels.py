@@ -340,15 +340,18 @@ class HipKernels:
 
     def act_bwd_reduce(self, gy: Tensor, y: Optional[Tensor], act: int, gain: float, clog: int, want_gz: bool = True,
                        bias: Optional[Tensor] = None, bias_scale: float = 1.0, want_gbias: bool = False, want_gdq: bool = False,
-                       mask: Optional[Tensor] = None):
-        """-> (gz | None, gbias [clog] | None, gdq [B, C] | None); mask: the activation's sign bits read instead of y (no gdq)"""
-        self._chk(gy, y, bias, mask)
+                       mask: Optional[Tensor] = None, out_scale: Optional[Tensor] = None):
+        """-> (gz | None, gbias [clog] | None, gdq [B, C] | None); mask: the activation's sign bits read instead of y (no gdq);
+        out_scale [B, C] fp32 (needs want_gz and want_gdq): the returned gz is gz * out_scale, the reductions are of the unscaled gz"""
+        self._chk(gy, y, bias, mask, out_scale)
         B, H, W, Cc = gy.shape
         gz = torch.empty_like(gy) if want_gz else None
         gbias = self._zeros.take((clog,), gy.device) if want_gbias else None
         gdq = self._zeros.take((B, Cc), gy.device) if want_gdq else None
-        self._call("lcgan_act_bwd_reduce_m", gy.data_ptr(), _p(y), _p(mask if not want_gdq else None), _p(gz), _p(bias), float(bias_scale), _p(gbias), _p(gdq),
-                   B, H * W, Cc, clog, act, float(gain), dt_code(gy.dtype), self._stream())
+        if out_scale is not None:
+            assert want_gz and want_gdq and out_scale.shape == (B, Cc) and out_scale.dtype == torch.float32
+        self._call("lcgan_act_bwd_reduce_s", gy.data_ptr(), _p(y), _p(mask if not want_gdq else None), _p(gz), _p(out_scale), _p(bias), float(bias_scale),
+                   _p(gbias), _p(gdq), B, H * W, Cc, clog, act, float(gain), dt_code(gy.dtype), self._stream())
         return gz, gbias, gdq
 
     def scale_reduce(self, u: Tensor, x: Tensor, s: Tensor) -> Tuple[Tensor, Tensor]:
@@ -451,16 +454,18 @@ class HipKernels:
         return gimg, gw, gbias
 
     def rgb_reduce_bwd_act(self, gimg: Tensor, y: Tensor, wm: Tensor, bias: Optional[Tensor], bias_scale: float, act: int, gain: float,
-                           clog: int, want_gbias: bool = True, want_gdq: bool = True):
-        """image gradient -> pre-activation gradient of the conv in front of rgb_reduce: (gz, gbias [clog] | None, gdq [B,C] | None, gwm [Bw,3,C])"""
-        self._chk(gimg, y, wm, bias)
+                           clog: int, want_gbias: bool = True, want_gdq: bool = True, out_scale: Optional[Tensor] = None):
+        """image gradient -> pre-activation gradient of the conv in front of rgb_reduce: (gz, gbias [clog] | None, gdq [B,C] | None, gwm [Bw,3,C]);
+        out_scale [B, C] fp32: the returned gz is gz * out_scale (reductions unscaled), as in act_bwd_reduce"""
+        self._chk(gimg, y, wm, bias, out_scale)
         B, H, W, Cc = y.shape
         per_sample = wm.shape[0] > 1
         gz = torch.empty_like(y)
         gbias = self._zeros.take((clog,), y.device) if want_gbias else None
         gdq = self._zeros.take((B, Cc), y.device) if want_gdq else None
         gwm = self._zeros.take((B if per_sample else 1, 3, Cc), y.device)
-        self._call("lcgan_rgb_reduce_bwd_act", gimg.data_ptr(), y.data_ptr(), wm.data_ptr(), _p(bias), float(bias_scale), gz.data_ptr(),
+        assert out_scale is None or (out_scale.shape == (B, Cc) and out_scale.dtype == torch.float32)
+        self._call("lcgan_rgb_reduce_bwd_act_s", gimg.data_ptr(), y.data_ptr(), wm.data_ptr(), _p(bias), float(bias_scale), gz.data_ptr(), _p(out_scale),
                    _p(gbias), _p(gdq), gwm.data_ptr(), B, H * W, Cc, clog, int(per_sample), act, float(gain), dt_code(y.dtype), self._stream())
         return gz, gbias, gdq, gwm
 

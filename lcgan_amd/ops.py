@@ -206,6 +206,11 @@ def _prep(w: Tensor, scale: float, transpose: bool, need_lo: bool, want_wsq: boo
     return hit
 
 
+def _gz_demod() -> bool:
+    from . import config
+    return config.gz_demod()
+
+
 def _act_masks() -> bool:
     from . import config
     return config.act_masks()
@@ -861,30 +866,34 @@ def _modconv_backward(x, w, bias, s, d, wsq, y, up, act, gain, c_eq, gy, residua
     """backward of ModConvFn: (gx [+ residual], gw, gbias, gs)"""
     # activation backward + bias gradient + demod statistic  gdq[b,o] = sum_p gz * (ypre - bias)
     gy = gy.contiguous()
+    # where the pass writes gz anyway it writes d[b,o] * gz (one rounding of the fp32 product), the operand both launches of the tail want
+    demod = act != ACT_NONE and _gz_demod()
     gz, gb, gdq = _K().act_bwd_reduce(gy, y, act, gain, w.shape[0], want_gz=(act != ACT_NONE), bias=bias, bias_scale=1.0,
-                                      want_gbias=True, want_gdq=True)
+                                      want_gbias=True, want_gdq=True, out_scale=d if demod else None)
     if gz is None:
         gz = gy
-    gx, gw, gs = _modconv_bwd_tail(x, w, s, d, wsq, gz, gdq, up, c_eq, residual)
+    gx, gw, gs = _modconv_bwd_tail(x, w, s, d, wsq, gz, gdq, up, c_eq, residual, gz_has_d=demod)
     return gx, gw, gb, gs
 
 
-def _modconv_bwd_tail(x, w, s, d, wsq, gz, gdq, up, c_eq, residual=None):
+def _modconv_bwd_tail(x, w, s, d, wsq, gz, gdq, up, c_eq, residual=None, gz_has_d=False):
     """from the pre-activation gradient gz of a modulated convolution to (gx [+ residual], gw, gs); residual: the gradient another
-    consumer of x already produced -- it joins in the data-gradient launch's epilogue instead of an add pass of autograd's"""
+    consumer of x already produced -- it joins in the data-gradient launch's epilogue instead of an add pass of autograd's;
+    gz_has_d: gz is already d[b,o] * gz (lcgan_act_bwd_reduce_s / lcgan_rgb_reduce_bwd_act_s): no per-sample scale on that operand"""
     K = _K()
     O, Cin, k, _ = w.shape
     pwT, _ = _prep(w, c_eq, True, _need_lo(x))                               # [t][Cin][O]
+    dz = None if gz_has_d else d
     # data gradient u = conv^T(d * gz); gx = s * u and gs = sum_p x * u leave the same launch (epilogue of the conv kernel)
     if up == 2:
-        gx, gs = K.conv_fwd(gz, pwT, Cin, k, 2, pre=d, post=s, xs=x, residual=residual)         # adjoint of the transposed conv
+        gx, gs = K.conv_fwd(gz, pwT, Cin, k, 2, pre=dz, post=s, xs=x, residual=residual)         # adjoint of the transposed conv
     else:
-        gx, gs = K.conv_bwd_data(gz, pwT, Cin, k, 1, pre=d, post=s, xs=x, residual=residual)
+        gx, gs = K.conv_bwd_data(gz, pwT, Cin, k, 1, pre=dz, post=s, xs=x, residual=residual)
     gwsq = K.demod_bwd(gdq, d, s, wsq, gs)                                   # gs += demod path
     if up == 2:
-        gw = K.conv_wgrad_unprep(gz, x, Cin, O, k, 2, c_eq, transposed=True, pre_x=d, pre_g=s, w=w, gwsq=gwsq)    # gwp [t][Cin][O]
+        gw = K.conv_wgrad_unprep(gz, x, Cin, O, k, 2, c_eq, transposed=True, pre_x=dz, pre_g=s, w=w, gwsq=gwsq)    # gwp [t][Cin][O]
     else:
-        gw = K.conv_wgrad_unprep(x, gz, O, Cin, k, 1, c_eq, transposed=False, pre_x=s, pre_g=d, w=w, gwsq=gwsq)   # gwp [t][O][Cin]
+        gw = K.conv_wgrad_unprep(x, gz, O, Cin, k, 1, c_eq, transposed=False, pre_x=s, pre_g=dz, w=w, gwsq=gwsq)   # gwp [t][O][Cin]
     return gx, gw, gs
 
 
@@ -920,8 +929,9 @@ class ModConvRGBFn(Function):
         x, w, bias, s, d, wsq, y, wm = ctx.saved_tensors
         act, gain, c_eq, rgb_bias_scale, has_rgb_bias = ctx.cfg
         gimg = gimg.contiguous()
-        gz, gb, gdq, gwm = K.rgb_reduce_bwd_act(gimg, y, wm, bias, 1.0, act, gain, w.shape[0])
-        gx, gw, gs = _modconv_bwd_tail(x, w, s, d, wsq, gz, gdq, 1, c_eq)
+        demod = _gz_demod()
+        gz, gb, gdq, gwm = K.rgb_reduce_bwd_act(gimg, y, wm, bias, 1.0, act, gain, w.shape[0], out_scale=d if demod else None)
+        gx, gw, gs = _modconv_bwd_tail(x, w, s, d, wsq, gz, gdq, 1, c_eq, gz_has_d=demod)
         grb = gimg.sum(dim=(0, 2, 3)) * rgb_bias_scale if (has_rgb_bias and ctx.needs_input_grad[5]) else None     # 3 numbers
         return gx, gw, gb, gs, gwm, grb, None, None, None
 

@@ -257,7 +257,8 @@ class EmulatedKernels:
     def avgpool2_bwd(self, gy):
         return nhwc(F.interpolate(nchw(gy), scale_factor=2, mode="nearest") * 0.25, gy.dtype)
 
-    def act_bwd_reduce(self, gy, y, act, gain, clog, want_gz=True, bias=None, bias_scale=1.0, want_gbias=False, want_gdq=False, mask=None):
+    def act_bwd_reduce(self, gy, y, act, gain, clog, want_gz=True, bias=None, bias_scale=1.0, want_gbias=False, want_gdq=False, mask=None,
+                       out_scale=None):
         g = gy.float()
         yo = y.float() if y is not None else None
         if mask is not None and not want_gdq:
@@ -265,7 +266,8 @@ class EmulatedKernels:
             z = g * torch.where(mask, 1.0, SLOPE) * gain
         else:
             z = g * act_grad_from_out(yo, act, gain) if act != ACT_NONE else g * gain
-        gz = z.to(gy.dtype) if want_gz else None
+        zs = z * out_scale[:, None, None, :] if out_scale is not None else z        # the stored gradient carries out_scale, the reductions do not
+        gz = zs.to(gy.dtype) if want_gz else None
         gbias = z.sum(dim=(0, 1, 2))[:clog].contiguous() if want_gbias else None
         gdq = None
         if want_gdq:
@@ -375,7 +377,7 @@ class EmulatedKernels:
         gbias = z.sum(dim=(0, 1, 2))[:clog].contiguous() if want_gbias else None
         return gimg, gw, gbias
 
-    def rgb_reduce_bwd_act(self, gimg, y, wm, bias, bias_scale, act, gain, clog, want_gbias=True, want_gdq=True):
+    def rgb_reduce_bwd_act(self, gimg, y, wm, bias, bias_scale, act, gain, clog, want_gbias=True, want_gdq=True, out_scale=None):
         """lcgan_rgb_reduce_bwd_act"""
         B, H, W, Cc = y.shape
         per_sample = wm.shape[0] > 1
@@ -397,6 +399,8 @@ class EmulatedKernels:
         gwm = torch.einsum("bohw,bhwc->boc", gimg.float(), yo)
         gwm[..., clog:] = 0
         gwm = gwm.contiguous() if per_sample else gwm.sum(0, keepdim=True).contiguous()
+        if out_scale is not None:
+            z = z * out_scale[:, None, None, :]
         return z.to(y.dtype), gbias, gdq, gwm
 
     # ---- flow layer as 1x1 GEMM + scatter (csrc/stencil.hip: flow_col2im / flow_im2col) ---------------------------------

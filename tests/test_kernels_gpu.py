@@ -671,6 +671,15 @@ def test_act_bwd_reduce_and_scale_reduce(H, dtype, shape, clog):
         check(g[0], r[0], dtype, "gz")
         check(g[1], r[1], torch.float32, "gbias")
         check(g[2], r[2], torch.float32, "gdq")
+        # the stored gradient with a per-(sample, channel) factor (a modulated convolution's demodulation): reductions unchanged bit for bit
+        osc = vec((B, C), 47) + 1.5
+        rs = E.act_bwd_reduce(gy, y, act, gain, clog, True, bias, 0.7, True, True, out_scale=osc)
+        gs_ = H.act_bwd_reduce(gy.cuda(), y.cuda(), act, gain, clog, True, bias.cuda(), 0.7, True, True, out_scale=osc.cuda())
+        check(gs_[0], rs[0], dtype, "gz * out_scale")
+        check(gs_[1], r[1], torch.float32, "gbias (out_scale)")
+        check(gs_[2], r[2], torch.float32, "gdq (out_scale)")
+        one = H.act_bwd_reduce(gy.cuda(), y.cuda(), act, gain, clog, True, bias.cuda(), 0.7, True, True, out_scale=torch.ones(B, C).cuda())
+        assert torch.equal(one[0], g[0]), "out_scale == 1 must store the plain gz"
     u, x = feat(shape, dtype, 44), feat(shape, dtype, 45)
     s = vec((B, C), 46)
     u_ref, gs_ref = E.scale_reduce(u.clone(), x, s)
@@ -825,6 +834,11 @@ def test_rgb_fused_backward(H, dtype, per_sample, shape):
     check(got[0], ref[0], dtype, "reduce_bwd_act gz")
     for name, g, r in zip(("gbias", "gdq", "gwm"), got[1:], ref[1:]):
         check(g, r, f32ish, f"reduce_bwd_act {name}")
+    osc = vec((B, C), 80) + 1.5
+    gots = H.rgb_reduce_bwd_act(gimg_in.cuda(), y.cuda(), w.cuda(), bias.cuda(), 1.0, 1, 1.3, clog, out_scale=osc.cuda())
+    check(gots[0], E.rgb_reduce_bwd_act(gimg_in, y, w, bias, 1.0, 1, 1.3, clog, out_scale=osc)[0], dtype, "reduce_bwd_act gz * out_scale")
+    for name, g, r in zip(("gbias", "gdq", "gwm"), gots[1:], ref[1:]):
+        check(g, r, f32ish, f"reduce_bwd_act {name} (out_scale)")
     gfeat = H.rgb_expand(gimg_in.cuda(), w.cuda(), None, 0.0, clog, 0, 1.0, dtype)
     gz2, gb2, gdq2 = H.act_bwd_reduce(gfeat, y.cuda(), 1, 1.3, clog, want_gz=True, bias=bias.cuda(), bias_scale=1.0, want_gbias=True, want_gdq=True)
     check(got[0], gz2.cpu(), dtype, "reduce_bwd_act vs composition: gz", l2_scale=2.0)     # (the composition rounds gfeat to bf16 in between)
@@ -880,6 +894,41 @@ def test_flow_layer_gemm_vs_generic(dtype, shape):
     for name, a, b in zip(("u", "gx", "gs", "gw", "gb"), *outs):
         # two different roundings of the same sums in bf16 (t is stored per tap before the scatter): twice the single-kernel tolerance
         check(a, b.cpu(), dtype if name in ("u", "gx") else (torch.float32 if dtype == torch.float32 else dtype), f"flow {name}", l2_scale=3.0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 64), (3, 32, 32, 128, 128), (2, 64, 64, 128, 72)])
+def test_modconv_backward_with_demodulated_gradient(dtype, shape):
+    """ops.ModConvFn's backward with the activation backward storing d * gz (config.gz_demod: the data- and weight-gradient launches then
+    carry no per-sample scale on that operand) against the per-sample-scale form: every gradient, both on the HIP kernels"""
+    from lcgan_amd import config, ops
+    from tests.helpers import install_backend
+    install_backend(None)
+    B, Hh, W, Cin, O = shape
+    g = torch.Generator().manual_seed(141)
+    x = feat((B, Hh, W, Cin), dtype, 142).cuda()
+    w = torch.nn.Parameter(torch.randn(O, Cin, 3, 3, generator=g).cuda())
+    bias = torch.nn.Parameter((torch.randn(O, generator=g) * 0.1).cuda())
+    s0 = (torch.rand(B, Cin, generator=g) + 0.5).cuda()
+    go = feat((B, Hh, W, ceil8(O)), dtype, 143, O).cuda()
+    outs = []
+    was = config.gz_demod()
+    try:
+        with config.feature_dtype_as(dtype):
+            for on in (True, False):
+                config.set_gz_demod(on)
+                xx, ss = x.clone().requires_grad_(True), s0.clone().requires_grad_(True)
+                w.grad = bias.grad = None
+                y = ops.ModConvFn.apply(xx, w, bias, ss, 1, 1, 1.4)
+                (y.float() * go.float()).sum().backward()
+                outs.append((xx.grad, ss.grad, w.grad.clone(), bias.grad.clone()))
+    finally:
+        config.set_gz_demod(was)
+    # the bias gradient reduces the UNSCALED gz in both forms: equal up to the order of its float atomics
+    assert torch.allclose(outs[0][3], outs[1][3], rtol=1e-4, atol=1e-5 * float(outs[1][3].abs().max())), "gbias"
+    for name, a, b in zip(("gx", "gs", "gw"), *outs):
+        # bf16: d enters once as a rounding of the fp32 product instead of on the staged bf16 operand -- two roundings of the same sums
+        check(a, b.cpu(), dtype if name == "gx" else (torch.float32 if dtype == torch.float32 else dtype), f"modconv {name}", l2_scale=3.0)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
