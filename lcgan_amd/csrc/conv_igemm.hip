@@ -2480,7 +2480,9 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   for (int p = 0; p < nphase; ++p) dma_ok = dma_ok && a.hh[p] <= DMA_HROWS && a.hw[p] <= DMA_HP && a.hw[p] - HT <= 2;
   if (dma_ok) {
     const int tp = mod ? (g_halo_dma_mod == 2 ? 2 : 1) : (g_halo_dma == 2 ? 2 : 1);
-    const size_t dsmem = std::max((size_t)(2 * DMA_HBUF + 2 * tp * DMA_BBUF) + (mod ? (size_t)c.Cin * sizeof(float) : 0), HALO_EPI_SMEM);
+    // (option 3, bit 64: ONE workgroup per CU -- the timing experiment behind DESIGN section 5's lone-workgroup figure)
+    const size_t dsmem = (g_dbg_no_atomics & 64) ? (size_t)100 * 1024
+                                                 : std::max((size_t)(2 * DMA_HBUF + 2 * tp * DMA_BBUF) + (mod ? (size_t)c.Cin * sizeof(float) : 0), HALO_EPI_SMEM);
 #define LAUNCH_DMA(EP, TPV, MD)                                                                                         \
   {                                                                                                                     \
     static bool set = false;                                                                                            \
