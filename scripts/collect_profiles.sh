@@ -17,3 +17,7 @@ if [ -f gpurun_out/h2d_on.json ]; then      # the PCIe-inclusive A/B (bench.py -
    echo "# worker.SyntheticHostTriples = the reference's three .to(device) of worker.py:141-143), A/B on ONE box; never the headline value"
    for f in off on off_b4 on_b4; do echo -n "h2d_$f: "; tail -1 gpurun_out/h2d_$f.json; done) >> profiles/r04_bench_variants.txt
 fi
+if [ -f gpurun_out/cpucycle.log ]; then      # the CPU oracle's full warmed 8-iteration cycle (bench.py --cpu-baseline-cycle), when that step ran
+  (echo; echo "# cpu_baseline as SURVEY 8(d) words it: one warm-up cycle, then one timed 8-iteration cycle of the CPU oracle at 256x256, batch 4 (bench.py --cpu-baseline-cycle)"
+   tail -1 gpurun_out/cpucycle.log) >> profiles/r04_bench_variants.txt
+fi

@@ -43,6 +43,7 @@ for s in "$@"; do
              step v_c4rank 400 python bench.py --steps 5 --warmup 2 --res 1024 --batch 4 --freezeD-layer 5 --no-cpu-baseline --no-cycle --no-roofline ;;
     hires)   step b512 400 python bench.py --steps 5 --warmup 2 --res 512 --no-cpu-baseline --no-cycle
              step b1024 400 python bench.py --steps 5 --warmup 2 --res 1024 --freezeD-layer 5 --no-cpu-baseline --no-cycle ;;
+    cpucycle) step cpucycle 700 python bench.py --steps 5 --warmup 2 --no-cycle --no-roofline --cpu-baseline-cycle ;;
     h2d)     for v in off on; do
                f=""; [ $v = on ] && f="--h2d"
                step h2d_$v 400 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline $f; tail -1 gpurun_out/h2d_$v.log > gpurun_out/h2d_$v.json
