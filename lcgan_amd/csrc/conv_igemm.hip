@@ -105,6 +105,8 @@ struct TapTable { int n; int dy[9]; int dx[9]; int wt[9]; };
   } while (0)
 #define SLAB_CONSUME_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup")
 
+inline int log2_exact(long long v) { int s = 0; while ((1ll << s) < v) ++s; return (1ll << s) == v ? s : -1; }   // log2 of a power of two, else -1
+
 struct ConvArgs {
   const void* x; const __bf16* w; size_t w_part; void* y;   // w: [P][taps][N][Kpad], w_part = elements per part
   const float* pre; const float* post; const float* bias; const void* residual;
@@ -117,6 +119,7 @@ struct ConvArgs {
   float bias_scale, gain; int act;
   const void* xs; float* gs;                 // fused style-gradient reduction: gs[b,n] += sum_pixels xs[b,p,n] * acc  (xs: [B,Hout,Wout,Cout]; y = post * acc)
   int res_half;                              // residual is [B,Hout/2,Wout/2,Cout]: add 0.25 * residual[oy/2][ox/2] (avg_pool2d adjoint)
+  int lw, lh;                                // log2 of Wout / Hout where they are powers of two, else -1 (the half-resolution residual's index without two divisions per ELEMENT)
   void* pool_out;                            // optional by-product [B,Hout/2,Wout/2,Cout] = avg_pool2d(y, 2) (the next DiscriminatorBlock's skip input)
   unsigned* mask_out;                        // optional by-product [B*Hout*Wout][Cout/32] words: bit c%32 of word c/32 = (pre-activation > 0), what the activation backward needs of y
   int nsplit; float* ws;                     // split-K: blockIdx.z = phase * nsplit + split; raw fp32 partials are atomically added to ws [M_out pixels][Cout]
@@ -414,7 +417,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const size_t off = (size_t)ro * a.Cout + n;
         if (res) {
           if (a.res_half) {
-            const int ox = ro % a.Wout, t = ro / a.Wout, oy = t % a.Hout, bb = t / a.Hout;
+            int ox, oy, bb;
+            if (a.lw >= 0 && a.lh >= 0) { ox = ro & (a.Wout - 1); const int t = ro >> a.lw; oy = t & (a.Hout - 1); bb = t >> a.lh; }
+            else { ox = ro % a.Wout; const int t = ro / a.Wout; oy = t % a.Hout; bb = t / a.Hout; }
             v += 0.25f * Feat<T>::ld1(res + ((size_t)(bb * (a.Hout >> 1) + (oy >> 1)) * (a.Wout >> 1) + (ox >> 1)) * a.Cout + n);
           } else {
             v += Feat<T>::ld1(res + off);
@@ -622,7 +627,9 @@ __global__ __launch_bounds__(512) void conv_igemm8_kernel(ConvArgs a) {
       const size_t off = (size_t)ro * a.Cout + n;
       if (res) {
         if (a.res_half) {
-          const int ox = ro % a.Wout, t = ro / a.Wout, oy = t % a.Hout, bb = t / a.Hout;
+          int ox, oy, bb;
+          if (a.lw >= 0 && a.lh >= 0) { ox = ro & (a.Wout - 1); const int t = ro >> a.lw; oy = t & (a.Hout - 1); bb = t >> a.lh; }
+          else { ox = ro % a.Wout; const int t = ro / a.Wout; oy = t % a.Hout; bb = t / a.Hout; }
           v += 0.25f * Feat<T>::ld1(res + ((size_t)(bb * (a.Hout >> 1) + (oy >> 1)) * (a.Wout >> 1) + (ox >> 1)) * a.Cout + n);
         } else {
           v += Feat<T>::ld1(res + off);
@@ -662,13 +669,23 @@ struct HaloArgs {
   // split of the input-channel range over blockIdx.y (stride-1 LDS-DMA structure only; launches that would leave most CUs idle): every
   // split runs its share of the 32-channel chunks; partial tiles and the finish as in conv_igemm8_kernel (slab + arrival counter)
   int nsplit; float* slab; int* cnt;
+  // workgroup -> tile decode without integer divisions: every wave of every workgroup did ten of them (each ~25 dependent scalar / v_rcp
+  // instructions) before its first load -- 2.4 us of a workgroup's 4.2-us prologue (scripts/halo_life.py).  Host-side: the tile count and,
+  // per divisor of the decode, its log2 when it is a power of two (else -1: that step divides)
+  // (one contiguous block, copies of nblocks / nb_group / nph_x / tiles_x / tiles_y / dbg included, read by ONE wide scalar load at kernel
+  //  entry: as scattered fields the decode took a dozen dependent s_load_dword round trips)
+  struct Decode { int ntile, sh_per, sh_grp, sh_nph, sh_tx, sh_ty, nblocks, nb_group, nph_x, tiles_x, tiles_y, dbg; } dec;
 };
+__device__ __forceinline__ void divmod_sh(unsigned n, int d, int sh, int& q, int& r) {      // wave-uniform operands
+  if (sh >= 0) { q = (int)(n >> sh); r = (int)(n & ((1u << sh) - 1u)); }
+  else { q = (int)(n / (unsigned)d); r = (int)(n - (unsigned)q * (unsigned)d); }
+}
 
 #ifdef HALO_STAMPS
 // diagnostic build (scripts/halo_stamps.py; never the shipped library): per wave of the first 2048 workgroups, cycle sums of the four
 // segments of a main-loop step -- [barrier exit -> fragments landed] [MFMA issue] [tile store -> barrier arrival] [barrier wait]
 __device__ unsigned long long g_halo_stamps[2048 * 8 * 5];
-__device__ unsigned long long g_halo_life[16384 * 5];        // per workgroup (wave 0): s_memrealtime at kernel entry, main-loop start, main-loop end, last store issued; HW_ID
+__device__ unsigned long long g_halo_life[16384 * 9];        // per workgroup (wave 0): s_memrealtime at kernel entry, main-loop start, main-loop end, stores acknowledged; HW_ID; first DMA issued, first stage landed, output tile in LDS, stores issued
 __device__ unsigned long long g_halo_clock[2048 * 8 * 2];     // per wave: (s_memtime, s_memrealtime [100 MHz]) deltas over the main loop -> the clock the chip held
 #define STAMP_RT(var)                                                                                               \
   __builtin_amdgcn_sched_barrier(0);                                                                                \
@@ -696,7 +713,7 @@ constexpr int DMA_BBUF = 128 * 64;                               // bytes per we
 typedef __attribute__((address_space(3))) void lds_void;
 
 template <int IN_MUL, bool M16, int EPI_, int DMA = 0, bool MOD = false>
-__global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) void conv_halo_kernel(HaloArgs a) {
+__global__ __launch_bounds__(512, (IN_MUL == 1 || DMA == 4) ? 4 : 2) void conv_halo_kernel(HaloArgs a) {   // (4 waves per SIMD = two workgroups per CU: at most 128 VGPRs)
   // EPI_ == 4: the plain epilogue (0) that also leaves the activation's sign mask (a.mask_out).  Its own instantiation: as a run-time
   // branch of the plain epilogue the four mask words cost EVERY plain launch 6 VGPRs and ~40 spilled SGPRs, and the modulated
   // instantiations (123 -> 129 VGPRs) their second workgroup per CU (+30 % on the 512-channel generator layers, measured).
@@ -720,7 +737,7 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
 #ifdef HALO_STAMPS
-  unsigned long long life0 = 0, life1 = 0, life2 = 0, life3 = 0;
+  unsigned long long life0 = 0, life1 = 0, life2 = 0, life3 = 0, lifeA = 0, lifeB = 0, lifeC = 0, lifeD = 0;
   STAMP_RT(life0)
 #endif
   // the 4 sub-pixel phases of a transposed conv have 1/2/2/4 taps: dispatch the long ones first (shorter tail)
@@ -736,23 +753,28 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
   // there, 25 % LONGER on the 512-channel layers: these launches are not bound by what crosses the fabric but by the per-workgroup fixed
   // cost paid four times per tile (a 1-tap phase is 8 steps of main loop); eight workgroups asking for the same lines at the same moment
   // costs more than the Infinity Cache hits it saves.  Off by default.
-  const int nph = a.nph_x, ntile = gridDim.x / (a.nblocks * nph);
+  const HaloArgs::Decode dc = a.dec;
+  const int nph = dc.nph_x, ntile = dc.ntile;
   int tile, nb;
-  if (!(a.dbg & 8) && (ntile & 7) == 0) {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, grp = a.nb_group * nph, per = (ntile >> 3) * grp;
-    const int nbo = slot / per, rem = slot - nbo * per;
-    tile = xcd * (ntile >> 3) + rem / grp;
-    const int r2 = rem % grp;
-    nb = nbo * a.nb_group + r2 / nph;
-    if (nph > 1) phase = nph - 1 - r2 % nph;
+  if (!(dc.dbg & 8) && (ntile & 7) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, grp = dc.nb_group * nph, per = (ntile >> 3) * grp;
+    int nbo, rem, tq, r2, bq, ph;
+    divmod_sh((unsigned)slot, per, dc.sh_per, nbo, rem);
+    divmod_sh((unsigned)rem, grp, dc.sh_grp, tq, r2);
+    tile = xcd * (ntile >> 3) + tq;
+    divmod_sh((unsigned)r2, nph, dc.sh_nph, bq, ph);
+    nb = nbo * dc.nb_group + bq;
+    if (nph > 1) phase = nph - 1 - ph;
   } else {
     tile = blockIdx.x % ntile;
     const int t2 = blockIdx.x / ntile;
-    nb = t2 % a.nblocks;
-    if (nph > 1) phase = nph - 1 - t2 / a.nblocks;
+    nb = t2 % dc.nblocks;
+    if (nph > 1) phase = nph - 1 - t2 / dc.nblocks;
   }
   const int n0 = nb * BN;
-  const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
+  int tx, ty, b, trow;
+  divmod_sh((unsigned)tile, dc.tiles_x, dc.sh_tx, trow, tx);
+  divmod_sh((unsigned)trow, dc.tiles_y, dc.sh_ty, b, ty);
   // channel-range split: this workgroup runs chunks [cb, cb + nchunks) -- as a shift of both operand bases, so the main loop below
   // counts from 0 as ever
   constexpr bool CAN_SPLIT = IN_MUL == 1 && (DMA == 1 || DMA == 2) && !M16 && EPI != 3 && !MOD;
@@ -768,7 +790,7 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
   float ep_bias = 0.f, ep_post = 1.f;
   if (TR && tid < BN) {
     const int n = n0 + tid;
-    if (a.bias && n < a.N) ep_bias = a.bias[n] * a.bias_scale;
+    if (a.bias && n < a.N) ep_bias = a.bias[n];                   // (the RAW value: multiplied by bias_scale here, the load was WAITED for here -- a memory round trip in every workgroup's prologue; the scale is applied where the value is staged for the epilogue)
     if (a.post && n < a.Cout) ep_post = a.post[(size_t)b * a.Cout + n];
   }
   // LDS pitch of a halo ROW in elements: a multiple of 256 bytes.  A wave's 32 fragment rows are 2 image rows of 16 pixels; with the
@@ -1096,6 +1118,11 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
     dma_halo(0, 0);
     dma_b(0, 0, 0);
     advance();
+#ifdef HALO_STAMPS
+    STAMP_RT(lifeA)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP_RT(lifeB)
+#endif
     if constexpr (MOD) {                                         // (the sample's scales are fetched while the first tiles are in flight)
       for (int i = tid; i < a.Cin; i += 512) dpsc[i] = a.pre[(size_t)b * a.Cin + i];
       __syncthreads();
@@ -1507,7 +1534,8 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
   float* cpost = cbias + BN;
   const __bf16* side = SR ? a.xs : a.residual;                     // the tile that meets the accumulators: residual, or xs
   if (SR && tid < BN) colbuf[tid] = 0.f;
-  if (TR && tid < BN) { cbias[tid] = ep_bias; cpost[tid] = ep_post; }
+  if (TR && tid < BN) { cbias[tid] = ep_bias * a.bias_scale; cpost[tid] = ep_post; }
+  const float ep_slope = a.act == ACT_LRELU ? LRELU_SLOPE : 1.f;
   // half-resolution residual under a stride-1 geometry (TR layout): the 4 lanes that share a source pixel read its 8-byte channel
   // groups straight from global memory (L1 hits) in the loop below -- no staging pass, no 4x-redundant 16-byte loads
   const bool quarter = TR && EPI == 2 && a.out_mul == 1;
@@ -1569,26 +1597,31 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           const int row = wm * 64 + mi * 32 + (lane & 31);                     // this lane's pixel
-          f32x4 v;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float t = acc[mi][ni][4 * g + j] * pv[j] + bv[j];
-            v[j] = (a.act == ACT_LRELU ? (t > 0.f ? t : t * LRELU_SLOPE) : t) * a.gain;
-            // (MK) "not positive" bits by integer arithmetic on the float's bits -- bits(t) - 1 has its top bit set exactly for t <= +0 and
+          // The epilogue is VALU work -- 64 elements per lane, the two waves of a SIMD at once: 3.4-3.9 us of a workgroup's life as ~10
+          // instructions per element (scripts/halo_life.py) -- so it is written on 4-vectors (packed fma / mul, two-element bf16 converts) and
+          // leaky ReLU is max(t, 0.2 t) (slope 1 without activation): the same values as compare + select, bit for bit
+          const f32x4 av = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+          const f32x4 t = av * pv + bv;
+          const f32x4 u = t * ep_slope;
+          f32x4 v = {fmaxf(t[0], u[0]), fmaxf(t[1], u[1]), fmaxf(t[2], u[2]), fmaxf(t[3], u[3])};
+          v = v * a.gain;
+          if (MK) {
+            // (the elements' bits through ONE cast of the whole vector: __builtin_bit_cast of t[j] inside the unrolled loop was compiled to the
+            //  bits of t[0] for every j -- caught by test_activation_sign_masks)
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 tb = __builtin_bit_cast(u32x4, t);
+            // "not positive" bits by integer arithmetic on the float's bits -- bits(t) - 1 has its top bit set exactly for t <= +0 and
             //  for negative t other than -0, which fp32 accumulation from +0 never produces -- instead of 64 compares, each holding an SGPR pair
-            if (MK) mw[mi][ni] |= ((__builtin_bit_cast(unsigned, t) - 1u) >> 31) << (8 * g + 4 * (lane >> 5) + j);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mw[mi][ni] |= ((tb[j] - 1u) >> 31) << (8 * g + j);           // (the lane's half -- 4 more -- is applied once, below)
           }
           if (EPI != 0) {
             bf16x4 rr = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
             if (!quarter) rr = *(const bf16x4*)(ot + row * OROW + ch);
             else rr = __builtin_bit_cast(bf16x4, rq[mi][ni][g]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += res_scale * (float)rr[j];
+            v = v + res_scale * __builtin_convertvector(rr, f32x4);
           }
-          bf16x4 o;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
-          *(bf16x4*)(ot + row * OROW + ch) = o;
+          *(bf16x4*)(ot + row * OROW + ch) = __builtin_convertvector(v, bf16x4);
         }
       }
     if (MK) {
@@ -1599,7 +1632,8 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-          const unsigned wv = ~(mw[mi][ni] | (unsigned)__shfl_xor((int)mw[mi][ni], 32, 64));      // (the lanes collected the COMPLEMENT)
+          const unsigned mh = mw[mi][ni] << (4 * (lane >> 5));
+          const unsigned wv = ~(mh | (unsigned)__shfl_xor((int)mh, 32, 64));      // (the lanes collected the COMPLEMENT)
           const int row = wm * 64 + mi * 32 + (lane & 31);
           const int py = ty * HT + (row >> 4), px = tx * HT + (row & 15);
           const int wi = (n0 >> 5) + wn * 2 + ni;
@@ -1615,7 +1649,7 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
     };
     auto emit = [&](int row, int nl, float accv, float bv, float pv, float& cs) {
       float v = accv * pv + bv;
-      v = (a.act == ACT_LRELU ? (v > 0.f ? v : v * LRELU_SLOPE) : v) * a.gain;
+      v = fmaxf(v, v * ep_slope) * a.gain;
       if (SR) cs += accv * (float)ot[row * OROW + nl];               // style-gradient partial: x * (unscaled data gradient)
       else if (EPI != 0) v += res_scale * (float)ot[row * OROW + nl];     // same thread reads and rewrites this element: one rounding
       ot[row * OROW + nl] = (__bf16)v;
@@ -1652,6 +1686,9 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
     }
   }
   __syncthreads();
+#ifdef HALO_STAMPS
+  STAMP_RT(lifeC)
+#endif
   if (SR && tid < BN && n0 + tid < a.Cout) atomicAdd(a.gs + (size_t)b * a.Cout + n0 + tid, colbuf[tid]);
   if (SR && a.residual) {
     // style-gradient epilogue + a full-resolution residual: the gradient another consumer of the same tensor has already produced
@@ -1681,18 +1718,26 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
       *(bf16x8*)((char*)a.y + ro[k]) = o;
     }
   } else {
+    // 256 rows x 16 vectors, thread t: vector t & 15 of the rows (t >> 4) + 32 k -- the same tile column, two tile rows further per k:
+    // ONE byte offset per thread, the k-th store adds k strides; a row / column / channel outside the output gets offset 0xffffffff and is
+    // dropped by the buffer's range check.  (As eight 64-bit addresses the loop was ~150 vector instructions, 1.4 us per workgroup.  The
+    // stride goes into the VECTOR offset: passed as the instruction's scalar offset -- an SGPR the compiler also used for the lane mask of the
+    // row test just before -- a few stores per launch went astray; test_conv_fwd_pooled_byproduct caught it.)
+    typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)(2u * (unsigned)(a.B * a.Hout * a.Wout * a.Cout)), 0x00020000);
+    const int r0 = tid >> 4, vv = tid & 15;
+    const int py0 = ty * HT + (r0 >> 4), px = tx * HT + (r0 & 15), n = n0 + vv * 8;
+    const unsigned off0 = 2u * (unsigned)(((b * a.Hout + py0 * a.out_mul + (phase >> 1)) * a.Wout + px * a.out_mul + (phase & 1)) * a.Cout + n);
+    const unsigned kstride = 4u * (unsigned)(a.out_mul * a.Wout * a.Cout);          // bytes between the rows of k and k + 1
+    const bool colok = px < a.Wm && n < a.Cout;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int idx = tid + k * 512;                                 // 256 rows x 16 vectors
-    const int row = idx >> 4, vv = idx & 15;
-    const int py = ty * HT + (row >> 4), px = tx * HT + (row & 15);
-    const int n = n0 + vv * 8;
-    if (py >= a.Hm || px >= a.Wm || n >= a.Cout) continue;
-    const int oy = py * a.out_mul + (phase >> 1), ox = px * a.out_mul + (phase & 1);
-    *(bf16x8*)(a.y + ((size_t)(b * a.Hout + oy) * a.Wout + ox) * a.Cout + n) = *(const bf16x8*)(ot + row * OROW + vv * 8);
-  }
+    for (int k = 0; k < 8; ++k) {
+      const bool ok = colok && py0 + 2 * k < a.Hm;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, *(const bf16x8*)(ot + (r0 + 32 * k) * OROW + vv * 8)), yres, ok ? off0 + k * kstride : 0xffffffffu, 0, 0);
+    }
   }
 #ifdef HALO_STAMPS
+  STAMP_RT(lifeD)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the tile's stores have been acknowledged
   STAMP_RT(life3)
   if (tid == 0) {
@@ -1700,8 +1745,8 @@ __global__ __launch_bounds__(512, ((IN_MUL == 1 && M16) || DMA == 4) ? 4 : 2) vo
     if (wgid < 16384) {
       unsigned hwid;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-      unsigned long long* o = g_halo_life + wgid * 5;
-      o[0] = life0; o[1] = life1; o[2] = life2; o[3] = life3; o[4] = hwid;
+      unsigned long long* o = g_halo_life + wgid * 9;
+      o[0] = life0; o[1] = life1; o[2] = life2; o[3] = life3; o[4] = hwid; o[5] = lifeA; o[6] = lifeB; o[7] = lifeC; o[8] = lifeD;
     }
   }
 #endif
@@ -1761,26 +1806,31 @@ __global__ __launch_bounds__(1024) void conv_s2duo_kernel(HaloArgs a) {
   char* wst = smem + 2 * S2_H;                                  // two weight stages
 
   // workgroup -> (pair of tiles, channel block), XCD-contiguous like conv_halo_kernel; team t owns tile 2 pair + t
-  const int npair = gridDim.x / a.nblocks;
+  const HaloArgs::Decode dc = a.dec;
+  const int npair = dc.ntile;                                   // (this kernel's launch passes its PAIR count and the matching shifts)
   int pair, nb;
   if ((npair & 7) == 0) {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = (npair >> 3) * a.nb_group;
-    const int nbo = slot / per, rem = slot - nbo * per;
-    pair = xcd * (npair >> 3) + rem / a.nb_group;
-    nb = nbo * a.nb_group + rem % a.nb_group;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = (npair >> 3) * dc.nb_group;
+    int nbo, rem, pq, br;
+    divmod_sh((unsigned)slot, per, dc.sh_per, nbo, rem);
+    divmod_sh((unsigned)rem, dc.nb_group, dc.sh_grp, pq, br);
+    pair = xcd * (npair >> 3) + pq;
+    nb = nbo * dc.nb_group + br;
   } else {
     pair = blockIdx.x % npair;
     nb = blockIdx.x / npair;
   }
   const int tile = 2 * pair + team;
   const int n0 = nb * BN;
-  const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
+  int tx, ty, b, trow;
+  divmod_sh((unsigned)tile, dc.tiles_x, dc.sh_tx, trow, tx);
+  divmod_sh((unsigned)trow, dc.tiles_y, dc.sh_ty, b, ty);
   const int gy0 = ty * HT * 2 - 1, gx0 = tx * HT * 2 - 1;       // input pixel of plane record (0, 0): halo origin (-1, -1)
   const TapTable& tt = a.taps[0];
   float ep_bias = 0.f, ep_post = 1.f;
   if (ltid < BN) {
     const int n = n0 + ltid;
-    if (a.bias && n < a.N) ep_bias = a.bias[n] * a.bias_scale;
+    if (a.bias && n < a.N) ep_bias = a.bias[n];                   // (the RAW value: multiplied by bias_scale here, the load was WAITED for here -- a memory round trip in every workgroup's prologue; the scale is applied where the value is staged for the epilogue)
     if (a.post && n < a.Cout) ep_post = a.post[(size_t)b * a.Cout + n];
   }
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(2u * (unsigned)(a.B * a.Hin * a.Win * a.Cin)), 0x00020000);
@@ -1883,7 +1933,8 @@ __global__ __launch_bounds__(1024) void conv_s2duo_kernel(HaloArgs a) {
   __bf16* ot = (__bf16*)(smem + teamu * TEAM_EPI);
   float* cbias = (float*)((char*)ot + 256 * OROW * sizeof(__bf16));
   float* cpost = cbias + BN;
-  if (ltid < BN) { cbias[ltid] = ep_bias; cpost[ltid] = ep_post; }
+  if (ltid < BN) { cbias[ltid] = ep_bias * a.bias_scale; cpost[ltid] = ep_post; }
+  const float ep_slope = a.act == ACT_LRELU ? LRELU_SLOPE : 1.f;
   __syncthreads();
   {
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -1897,13 +1948,18 @@ __global__ __launch_bounds__(1024) void conv_s2duo_kernel(HaloArgs a) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           const int row = wm * 64 + mi * 32 + (lane & 31);
-          bf16x4 o;
+          const f32x4 av = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+          const f32x4 t = av * pv + bv;                            // (4-vectors, max(t, slope t): see conv_halo_kernel's epilogue)
+          const f32x4 u = t * ep_slope;
+          f32x4 v = {fmaxf(t[0], u[0]), fmaxf(t[1], u[1]), fmaxf(t[2], u[2]), fmaxf(t[3], u[3])};
+          v = v * a.gain;
+          if (MK) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 tb = __builtin_bit_cast(u32x4, t);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float t = acc[mi][ni][4 * g + j] * pv[j] + bv[j];
-            o[j] = (__bf16)((a.act == ACT_LRELU ? (t > 0.f ? t : t * LRELU_SLOPE) : t) * a.gain);
-            if (MK) mw[mi][ni] |= ((__builtin_bit_cast(unsigned, t) - 1u) >> 31) << (8 * g + 4 * (lane >> 5) + j);
+            for (int j = 0; j < 4; ++j) mw[mi][ni] |= ((tb[j] - 1u) >> 31) << (8 * g + j);           // (the lane's half -- 4 more -- is applied once, below)
           }
+          const bf16x4 o = __builtin_convertvector(v, bf16x4);
 #ifdef DUO_DIRECT                                                 // timing experiment (measured +3.5 ... +4.5 % per launch, not shipped): 8-byte stores straight from the accumulator layout, no LDS tile
           {
             const int py = ty * HT + (row >> 4), px = tx * HT + (row & 15);
@@ -1920,7 +1976,8 @@ __global__ __launch_bounds__(1024) void conv_s2duo_kernel(HaloArgs a) {
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-          const unsigned wv = ~(mw[mi][ni] | (unsigned)__shfl_xor((int)mw[mi][ni], 32, 64));
+          const unsigned mh = mw[mi][ni] << (4 * (lane >> 5));
+          const unsigned wv = ~(mh | (unsigned)__shfl_xor((int)mh, 32, 64));
           const int row = wm * 64 + mi * 32 + (lane & 31);
           const int py = ty * HT + (row >> 4), px = tx * HT + (row & 15);
           const int wi = (n0 >> 5) + wn * 2 + ni;
@@ -1931,14 +1988,19 @@ __global__ __launch_bounds__(1024) void conv_s2duo_kernel(HaloArgs a) {
   }
 #ifndef DUO_DIRECT
   __syncthreads();
+  {                                                               // (one offset per thread + k strides: see conv_halo_kernel)
+    typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)(2u * (unsigned)(a.B * a.Hout * a.Wout * a.Cout)), 0x00020000);
+    const int r0 = ltid >> 4, vv = ltid & 15;
+    const int py0 = ty * HT + (r0 >> 4), px = tx * HT + (r0 & 15), n = n0 + vv * 8;
+    const unsigned off0 = 2u * (unsigned)(((b * a.Hout + py0) * a.Wout + px) * a.Cout + n);
+    const unsigned kstride = 4u * (unsigned)(a.Wout * a.Cout);
+    const bool colok = px < a.Wm && n < a.Cout;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int idx = ltid + k * 512;                              // 256 rows x 16 vectors
-    const int row = idx >> 4, vv = idx & 15;
-    const int py = ty * HT + (row >> 4), px = tx * HT + (row & 15);
-    const int n = n0 + vv * 8;
-    if (py >= a.Hm || px >= a.Wm || n >= a.Cout) continue;
-    *(bf16x8*)(a.y + ((size_t)(b * a.Hout + py) * a.Wout + px) * a.Cout + n) = *(const bf16x8*)(ot + row * OROW + vv * 8);
+    for (int k = 0; k < 8; ++k) {
+      const bool ok = colok && py0 + 2 * k < a.Hm;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, *(const bf16x8*)(ot + (r0 + 32 * k) * OROW + vv * 8)), yres, ok ? off0 + k * kstride : 0xffffffffu, 0, 0);
+    }
   }
 #endif
 }
@@ -2396,6 +2458,11 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
   dim3 grid(c.B * a.tiles_x * a.tiles_y * a.nblocks, a.nsplit, nphase);
   a.nph_x = 1;
   if (nphase == 4 && g_halo_phase_x) { a.nph_x = 4; grid = dim3(grid.x * 4, a.nsplit, 1); }
+  {
+    const int ntile = c.B * a.tiles_x * a.tiles_y;
+    a.dec = {ntile, log2_exact((long long)(ntile >> 3) * a.nb_group * a.nph_x), log2_exact(a.nb_group * a.nph_x), log2_exact(a.nph_x),
+             log2_exact(a.tiles_x), log2_exact(a.tiles_y), a.nblocks, a.nb_group, a.nph_x, a.tiles_x, a.tiles_y, a.dbg};
+  }
 #define LAUNCH_HALO(IM, MM, EP)                                                                                         \
   {                                                                                                                     \
     static bool set = false;                                                                                            \
@@ -2429,6 +2496,8 @@ bool try_launch_halo(const ConvArgs& c, int nphase, int in_mul, hipStream_t s) {
         (g_s2duo >= 2 || (long long)c.B * a.tiles_x * a.tiles_y * a.nblocks >= 2 * 256) && a.nsplit == 1) {     // (option 26 = 2: small grids too -- tests)
       constexpr size_t DUO_SMEM = 2 * (size_t)42 * 1024 + 2 * (size_t)9 * 4096;        // 156 KB (the epilogue's 2 x 70 KB fit inside)
       const dim3 dgrid((unsigned)(c.B * a.tiles_x * a.tiles_y / 2) * a.nblocks, 1, 1);
+      a.dec.ntile = c.B * a.tiles_x * a.tiles_y / 2;                          // pairs of tiles
+      a.dec.sh_per = log2_exact((long long)(a.dec.ntile >> 3) * a.nb_group); a.dec.sh_grp = log2_exact(a.nb_group);
 #define LAUNCH_DUO(EP)                                                                                                  \
   {                                                                                                                     \
     static bool set = false;                                                                                            \
@@ -3571,7 +3640,7 @@ int lcgan_set_option(int option, int value) {
 
 #ifdef HALO_STAMPS
 int lcgan_halo_life(unsigned long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_life), sizeof(unsigned long long) * 16384 * 5) == hipSuccess ? LCGAN_OK : LCGAN_ELAUNCH;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_life), sizeof(unsigned long long) * 16384 * 9) == hipSuccess ? LCGAN_OK : LCGAN_ELAUNCH;
 }
 int lcgan_halo_clock(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_halo_clock), sizeof(unsigned long long) * 2048 * 8 * 2) == hipSuccess ? LCGAN_OK : LCGAN_ELAUNCH;
@@ -3657,6 +3726,7 @@ int lcgan_conv_fwd_m(const void* x, const void* wp, void* y,
   a.Hout = (Hin + stride - 1) / stride; a.Wout = (Win + stride - 1) / stride; a.Cout = Cout;
   a.Hm = a.Hout; a.Wm = a.Wout;
   if (a.res_half && ((a.Hout | a.Wout) & 1)) return LCGAN_EINVAL;
+  a.lw = log2_exact(a.Wout); a.lh = log2_exact(a.Hout);
   const long long M = (long long)B * a.Hm * a.Wm;
   if (M <= 0 || M >= (1ll << 31) || (long long)B * Hin * Win >= (1ll << 31)) return LCGAN_EINVAL;
   a.M = (int)M; a.N = N; a.Kpad = (Cin + 31) / 32 * 32; a.kc_per_tap = a.Kpad / BK;
@@ -3702,6 +3772,7 @@ int lcgan_conv_bwd_data(const void* g, const void* wpT, void* gx,
   a.Hout = Hg * stride; a.Wout = Wg * stride; a.Cout = Cout;
   a.Hm = Hg; a.Wm = Wg;
   if (a.res_half && ((a.Hout | a.Wout) & 1)) return LCGAN_EINVAL;
+  a.lw = log2_exact(a.Wout); a.lh = log2_exact(a.Hout);
   const long long M = (long long)B * a.Hm * a.Wm;
   if (M <= 0 || (long long)B * a.Hout * a.Wout >= (1ll << 31)) return LCGAN_EINVAL;
   a.M = (int)M; a.N = N; a.Kpad = (Cg + 31) / 32 * 32; a.kc_per_tap = a.Kpad / BK;

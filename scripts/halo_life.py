@@ -21,10 +21,10 @@ for (kind, Hh, Ci, Co, st) in cases:
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); fn(); e1.record(); torch.cuda.synchronize()
-    buf = (C.c_ulonglong * (16384 * 5))()
+    buf = (C.c_ulonglong * (16384 * 9))()
     assert K.lib.lcgan_halo_life(buf) == 0
-    a = np.array(buf[:], dtype=np.float64).reshape(16384, 5)
-    a = a[a[:, 0] > 0]
+    a = np.array(buf[:], dtype=np.float64).reshape(16384, 9)
+    a = a[a[:, 0] >= a[:, 3].max() - 2 * e0.elapsed_time(e1) * 1e5]      # this launch's entries (100 MHz ticks; the buffer is never cleared)
     t0 = a[:, 0].min()
     us = (a[:, :4] - t0) / 100.0                                   # 100 MHz ticks -> us
     pro, loop, epi = us[:, 1] - us[:, 0], us[:, 2] - us[:, 1], us[:, 3] - us[:, 2]
@@ -34,6 +34,10 @@ for (kind, Hh, Ci, Co, st) in cases:
     nxt = np.searchsorted(starts, ends, side="left")
     gaps = starts[np.minimum(nxt, len(starts) - 1)] - ends
     gaps = gaps[(nxt < len(starts)) & (gaps >= 0)]
+    if a[:, 5].max() > 0:                                          # LDS-DMA structure: the finer stamps
+        sub = (a[:, [5, 6, 7, 8]] - t0) / 100.0
+        print(f"    prologue: entry -> first DMA issued {np.median(sub[:, 0] - us[:, 0]):.2f}, -> landed {np.median(sub[:, 1] - sub[:, 0]):.2f}, -> loop {np.median(us[:, 1] - sub[:, 1]):.2f};  "
+              f"epilogue: loop end -> output tile in LDS {np.median(sub[:, 2] - us[:, 2]):.2f}, -> stores issued {np.median(sub[:, 3] - sub[:, 2]):.2f}, -> acknowledged {np.median(us[:, 3] - sub[:, 3]):.2f}")
     print(f"{kind} {Hh}^2 {Ci}->{Co} s{st}: kernel {e0.elapsed_time(e1) * 1e3:.0f} us, {len(a)} workgroups sampled; median us per workgroup: "
           f"prologue {np.median(pro):.2f}  main loop {np.median(loop):.2f}  epilogue (to stores acknowledged) {np.median(epi):.2f}  "
           f"life {np.median(us[:, 3] - us[:, 0]):.2f};  earliest entry after a workgroup's end: median {np.median(gaps):.2f} us (p90 {np.percentile(gaps, 90):.2f})")

@@ -37,9 +37,9 @@ for (kind, Hh, Ci, Co, st) in cases:
             e0.record(); fn(); e1.record(); torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) * 1e3)
         line = f"{kind} {Hh}^2 {Ci}->{Co} s{st} stagger {v / 10:5.1f} us: launch {np.median(ts):7.1f} us (min {min(ts):7.1f})"
-        buf = (C.c_ulonglong * (16384 * 5))()
+        buf = (C.c_ulonglong * (16384 * 9))()
         if has_life and K.lib.lcgan_halo_life(buf) == 0:
-            a = np.array(buf[:], dtype=np.float64).reshape(16384, 5)
+            a = np.array(buf[:], dtype=np.float64).reshape(16384, 9)
             idx = np.nonzero(a[:, 0] >= a[:, 3].max() - 2 * np.median(ts) * 100)[0]      # this launch's entries (the buffer is never cleared)
             a = a[idx]
             t0, t1 = a[:, 0].min(), a[:, 3].max()
