@@ -107,6 +107,12 @@ struct TapTable { int n; int dy[9]; int dx[9]; int wt[9]; };
 
 inline int log2_exact(long long v) { int s = 0; while ((1ll << s) < v) ++s; return (1ll << s) == v ? s : -1; }   // log2 of a power of two, else -1
 
+// quotient and remainder by a launch constant: a shift where the host found a power of two (sh = its log2), else the division
+__device__ __forceinline__ void divmod_sh(unsigned n, int d, int sh, int& q, int& r) {
+  if (sh >= 0) { q = (int)(n >> sh); r = (int)(n & ((1u << sh) - 1u)); }
+  else { q = (int)(n / (unsigned)d); r = (int)(n - (unsigned)q * (unsigned)d); }
+}
+
 struct ConvArgs {
   const void* x; const __bf16* w; size_t w_part; void* y;   // w: [P][taps][N][Kpad], w_part = elements per part
   const float* pre; const float* post; const float* bias; const void* residual;
@@ -120,6 +126,7 @@ struct ConvArgs {
   const void* xs; float* gs;                 // fused style-gradient reduction: gs[b,n] += sum_pixels xs[b,p,n] * acc  (xs: [B,Hout,Wout,Cout]; y = post * acc)
   int res_half;                              // residual is [B,Hout/2,Wout/2,Cout]: add 0.25 * residual[oy/2][ox/2] (avg_pool2d adjoint)
   int lw, lh;                                // log2 of Wout / Hout where they are powers of two, else -1 (the half-resolution residual's index without two divisions per ELEMENT)
+  int l_hwm, l_wm, l_kc;                     // the same for Hm * Wm, Wm and kc_per_tap (conv_igemm8_kernel: row decode, and the tap of a chunk once per main-loop stage)
   void* pool_out;                            // optional by-product [B,Hout/2,Wout/2,Cout] = avg_pool2d(y, 2) (the next DiscriminatorBlock's skip input)
   unsigned* mask_out;                        // optional by-product [B*Hout*Wout][Cout/32] words: bit c%32 of word c/32 = (pre-activation > 0), what the activation backward needs of y
   int nsplit; float* ws;                     // split-K: blockIdx.z = phase * nsplit + split; raw fp32 partials are atomically added to ws [M_out pixels][Cout]
@@ -451,8 +458,9 @@ __global__ __launch_bounds__(512) void conv_igemm8_kernel(ConvArgs a) {
     const int m = m0 + tid;
     const bool ok = m < a.M;
     const int mm = ok ? m : 0;
-    const int b = mm / HWm, rem = mm - b * HWm;
-    const int iy = rem / a.Wm, ix = rem - iy * a.Wm;
+    int b, rem, iy, ix;
+    divmod_sh((unsigned)mm, HWm, a.l_hwm, b, rem);
+    divmod_sh((unsigned)rem, a.Wm, a.l_wm, iy, ix);
     const int oy = iy * a.out_mul + (phase >> 1), ox = ix * a.out_mul + (phase & 1);
     row_off[tid] = ok ? ((b * a.Hout + oy) * a.Wout + ox) : -1;
     row_b[tid] = b;
@@ -477,8 +485,10 @@ __global__ __launch_bounds__(512) void conv_igemm8_kernel(ConvArgs a) {
     const int m = m0 + row;
     const bool ok = m < a.M;
     const int mm = ok ? m : 0;
-    const int b = mm / HWm, rem = mm - b * HWm;
-    const int iy = (rem / a.Wm) * a.in_mul, ix = (rem % a.Wm) * a.in_mul;
+    int b, rem, iy, ix;
+    divmod_sh((unsigned)mm, HWm, a.l_hwm, b, rem);
+    divmod_sh((unsigned)rem, a.Wm, a.l_wm, iy, ix);
+    iy *= a.in_mul; ix *= a.in_mul;
     aiy = ok ? iy : -0x40000000; aix = ix;
     abase = 2 * (((b * a.Hin + iy) * a.Win + ix) * a.Cin + ch);
     const int n = n0 + row;
@@ -489,7 +499,9 @@ __global__ __launch_bounds__(512) void conv_igemm8_kernel(ConvArgs a) {
     for (int h = 0; h < 2; ++h) {
       const bool live = q + h < nq;
       const int qq = live ? q + h : q;
-      const int tap = qq / a.kc_per_tap, c0 = (qq - tap * a.kc_per_tap) * BK;
+      int tap, c0;
+      divmod_sh((unsigned)qq, a.kc_per_tap, a.l_kc, tap, c0);        // (was a scalar division -- ~25 dependent instructions -- twice per main-loop stage)
+      c0 *= BK;
       const int dy = tt.dy[tap], dx = tt.dx[tap];
       const int tofs = 2 * ((dy * a.Win + dx) * a.Cin + c0);
       char* S = smem + buf * SB + h * 2 * QT;
@@ -676,10 +688,6 @@ struct HaloArgs {
   //  entry: as scattered fields the decode took a dozen dependent s_load_dword round trips)
   struct Decode { int ntile, sh_per, sh_grp, sh_nph, sh_tx, sh_ty, nblocks, nb_group, nph_x, tiles_x, tiles_y, dbg; } dec;
 };
-__device__ __forceinline__ void divmod_sh(unsigned n, int d, int sh, int& q, int& r) {      // wave-uniform operands
-  if (sh >= 0) { q = (int)(n >> sh); r = (int)(n & ((1u << sh) - 1u)); }
-  else { q = (int)(n / (unsigned)d); r = (int)(n - (unsigned)q * (unsigned)d); }
-}
 
 #ifdef HALO_STAMPS
 // diagnostic build (scripts/halo_stamps.py; never the shipped library): per wave of the first 2048 workgroups, cycle sums of the four
@@ -3730,6 +3738,7 @@ int lcgan_conv_fwd_m(const void* x, const void* wp, void* y,
   const long long M = (long long)B * a.Hm * a.Wm;
   if (M <= 0 || M >= (1ll << 31) || (long long)B * Hin * Win >= (1ll << 31)) return LCGAN_EINVAL;
   a.M = (int)M; a.N = N; a.Kpad = (Cin + 31) / 32 * 32; a.kc_per_tap = a.Kpad / BK;
+  a.l_hwm = log2_exact((long long)a.Hm * a.Wm); a.l_wm = log2_exact(a.Wm); a.l_kc = log2_exact(a.kc_per_tap);
   a.w_part = (size_t)k * k * N * a.Kpad;
   a.in_mul = stride; a.out_mul = 1; a.pre_stride = Cin; a.post_stride = Cout;
   a.bias_scale = bias_scale; a.gain = gain; a.act = act;
@@ -3776,6 +3785,7 @@ int lcgan_conv_bwd_data(const void* g, const void* wpT, void* gx,
   const long long M = (long long)B * a.Hm * a.Wm;
   if (M <= 0 || (long long)B * a.Hout * a.Wout >= (1ll << 31)) return LCGAN_EINVAL;
   a.M = (int)M; a.N = N; a.Kpad = (Cg + 31) / 32 * 32; a.kc_per_tap = a.Kpad / BK;
+  a.l_hwm = log2_exact((long long)a.Hm * a.Wm); a.l_wm = log2_exact(a.Wm); a.l_kc = log2_exact(a.kc_per_tap);
   a.w_part = (size_t)k * k * N * a.Kpad;
   a.in_mul = 1; a.out_mul = stride; a.pre_stride = Cg; a.post_stride = Cout;
   a.bias_scale = bias_scale; a.gain = gain; a.act = act;
