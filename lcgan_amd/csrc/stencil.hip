@@ -37,6 +37,24 @@ struct Tag {
 // off the HBM roofline).
 // Rows per thread: 16 on the big maps (the two halo rows of a strip are re-read from L2: 25 % extra loads at 8 rows, 12 % at 16;
 // -3..-8 % at >= 64 x 64 x 512, batch 32), 8 below 4M channel vectors, where 16 leaves too few threads (+30 % at 32 x 32 x 512).
+// Thread index -> (vector v, column x, row y, sample b) of a [B][Hh][Ww][nvec] grid, gid = ((b Hh + y) Ww + x) nvec + v.  As four 64-bit
+// divisions this was the larger part of the instructions of the one-output-vector-per-thread kernels (up2box, the pooling kernels); where
+// the three extents are powers of two and the grid has fewer than 2^31 vectors -- every launch of the networks -- it is shifts and masks.
+__device__ __forceinline__ void decode_vxyb(long long gid, long long total, int nvec, int Ww, int Hh, int& v, int& x, int& y, int& b) {
+  const bool p2 = total < (1ll << 31) && !(nvec & (nvec - 1)) && !(Ww & (Ww - 1)) && !(Hh & (Hh - 1));      // (kernel-uniform)
+  if (p2) {
+    unsigned g = (unsigned)gid;
+    v = (int)(g & (unsigned)(nvec - 1)); g >>= __builtin_ctz((unsigned)nvec);
+    x = (int)(g & (unsigned)(Ww - 1)); g >>= __builtin_ctz((unsigned)Ww);
+    y = (int)(g & (unsigned)(Hh - 1)); b = (int)(g >> __builtin_ctz((unsigned)Hh));
+  } else {
+    v = (int)(gid % nvec);
+    long long t = gid / nvec;
+    x = (int)(t % Ww); t /= Ww;
+    y = (int)(t % Hh); b = (int)(t / Hh);
+  }
+}
+
 int box_rh(long long nvectors) { return nvectors >= (1ll << 22) ? 16 : 8; }
 template <typename T>
 __global__ void box3_act_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int act, float gain,
@@ -46,10 +64,8 @@ __global__ void box3_act_kernel(const T* __restrict__ x, T* __restrict__ y, int 
   const long long total = (long long)B * strips * W * nvec;
   const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
   if (gid >= total) return;
-  const int v = (int)(gid % nvec);
-  long long t = gid / nvec;
-  const int w = (int)(t % W); t /= W;
-  const int strip = (int)(t % strips), b = (int)(t / strips);
+  int v, w, strip, b;
+  decode_vxyb(gid, total, nvec, W, strips, v, w, strip, b);
   const int h0 = strip * BOX_RH, h1 = min(h0 + BOX_RH, H);
   const T* xb = x + (size_t)b * H * W * C + v * 8;
   // branch-free taps: the column neighbours are clamped and masked once per thread, a row outside the image contributes zero
@@ -102,10 +118,8 @@ __global__ void box3_actbwd_reduce_kernel(const T* __restrict__ gy, const T* __r
   for (int j = 0; j < 8; ++j) sb[j] = 0.f;
   int v = 0;
   if (gid < total) {
-    v = (int)(gid % nvec);
-    long long t = gid / nvec;
-    const int w = (int)(t % W); t /= W;
-    const int strip = (int)(t % strips), b = (int)(t / strips);
+    int w, strip, b;
+    decode_vxyb(gid, total, nvec, W, strips, v, w, strip, b);
     const int h0 = strip * BOXB_RH, h1 = min(h0 + BOXB_RH, H);
     const T* gb = gy + (size_t)b * H * W * C + v * 8;
     const int xl = max(w - 1, 0) * C, xc = w * C, xr = min(w + 1, W - 1) * C;     // branch-free column taps (see box3_act_kernel)
@@ -169,10 +183,8 @@ __global__ void box3_act_bwd_kernel(const T* __restrict__ gy, const T* __restric
   const long long gid0 = (long long)blockIdx.x * TPB + threadIdx.x;
   const bool live = gid0 < total;
   const long long gid = live ? gid0 : total - 1;                     // (dead lanes of the last wave stay in step for the shuffles)
-  const int v = (int)(gid % nvec);
-  long long t = gid / nvec;
-  const int w = (int)(t % W); t /= W;
-  const int strip = (int)(t % strips), b = (int)(t / strips);
+  int v, w, strip, b;
+  decode_vxyb(gid, total, nvec, W, strips, v, w, strip, b);
   const int h0 = strip * BOX_RH, h1 = min(h0 + BOX_RH, H);
   const size_t base = (size_t)b * H * W * C + v * 8;
   const int xo[3] = {max(w - 1, 0), w, min(w + 1, W - 1)};          // branch-free column taps (see box3_act_kernel)
@@ -234,9 +246,8 @@ __global__ void up2box_kernel(const T* __restrict__ x, const T* __restrict__ res
   const long long total = (long long)B * H2 * W2 * nvec;
   const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
   if (gid >= total) return;
-  const int v = (int)(gid % nvec);
-  const long long pix = gid / nvec;
-  const int X = (int)(pix % W2), Y = (int)((pix / W2) % H2), b = (int)(pix / ((long long)W2 * H2));
+  int v, X, Y, b;
+  decode_vxyb(gid, total, nvec, W2, H2, v, X, Y, b);
   // output row Y=2i: (x[i-1] + 2 x[i]) / 3 ; Y=2i+1: (2 x[i] + x[i+1]) / 3
   const int i = Y >> 1, j = X >> 1;
   const int i2 = (Y & 1) ? i + 1 : i - 1, j2 = (X & 1) ? j + 1 : j - 1;
@@ -250,7 +261,7 @@ __global__ void up2box_kernel(const T* __restrict__ x, const T* __restrict__ res
 #pragma unroll
   for (int q = 0; q < 8; ++q)
     s.v[q] = (2.f / 3.f) * ((2.f / 3.f) * t00.v[q] + wx2 * t01.v[q]) + wy2 * ((2.f / 3.f) * t10.v[q] + wx2 * t11.v[q]);
-  const size_t off = (size_t)pix * C + v * 8;
+  const size_t off = (size_t)gid * 8;
   if (res) {
     const F8 r = Feat<T>::load(res + off);
 #pragma unroll
@@ -266,9 +277,8 @@ __global__ void up2box_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, 
   const long long total = (long long)B * H * W * nvec;
   const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
   if (gid >= total) return;
-  const int v = (int)(gid % nvec);
-  const long long pix = gid / nvec;
-  const int j = (int)(pix % W), i = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+  int v, j, i, b;
+  decode_vxyb(gid, total, nvec, W, H, v, j, i, b);
   F8 s = f8_zero();
 #pragma unroll
   for (int a = -1; a <= 2; ++a) {
@@ -285,7 +295,7 @@ __global__ void up2box_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, 
       for (int q = 0; q < 8; ++q) s.v[q] += t.v[q] * wgt;
     }
   }
-  Feat<T>::store(gx + (size_t)pix * C + v * 8, s);
+  Feat<T>::store(gx + (size_t)gid * 8, s);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -297,9 +307,8 @@ __global__ void avgpool2_kernel(const T* __restrict__ x, T* __restrict__ y, int 
   const long long total = (long long)B * Ho * Wo * nvec;
   const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
   if (gid >= total) return;
-  const int v = (int)(gid % nvec);
-  const long long pix = gid / nvec;
-  const int j = (int)(pix % Wo), i = (int)((pix / Wo) % Ho), b = (int)(pix / ((long long)Wo * Ho));
+  int v, j, i, b;
+  decode_vxyb(gid, total, nvec, Wo, Ho, v, j, i, b);
   F8 s = f8_zero();
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -311,7 +320,7 @@ __global__ void avgpool2_kernel(const T* __restrict__ x, T* __restrict__ y, int 
     }
 #pragma unroll
   for (int q = 0; q < 8; ++q) s.v[q] *= 0.25f;
-  Feat<T>::store(y + (size_t)pix * C + v * 8, s);
+  Feat<T>::store(y + (size_t)gid * 8, s);
 }
 
 template <typename T>
@@ -320,13 +329,12 @@ __global__ void avgpool2_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx
   const long long total = (long long)B * H * W * nvec;
   const long long gid = (long long)blockIdx.x * TPB + threadIdx.x;
   if (gid >= total) return;
-  const int v = (int)(gid % nvec);
-  const long long pix = gid / nvec;
-  const int X = (int)(pix % W), Y = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+  int v, X, Y, b;
+  decode_vxyb(gid, total, nvec, W, H, v, X, Y, b);
   F8 t = Feat<T>::load(gy + (((size_t)b * Ho + (Y >> 1)) * Wo + (X >> 1)) * C + v * 8);
 #pragma unroll
   for (int q = 0; q < 8; ++q) t.v[q] *= 0.25f;
-  Feat<T>::store(gx + (size_t)pix * C + v * 8, t);
+  Feat<T>::store(gx + (size_t)gid * 8, t);
 }
 
 // ------------------------------------------------------------------------------------------------------------
