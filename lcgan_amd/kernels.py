@@ -64,11 +64,16 @@ class _ZeroPool:
         n = 1
         for d in shape:
             n *= int(d)
+        device = torch.device(device)
         if n > self.SLAB // 4:
             return torch.zeros(shape, dtype=torch.float32, device=device)
         if self.buf is None or self.off + n > self.SLAB or self.buf.device != device:
             self.buf, self.off = torch.zeros(self.SLAB, dtype=torch.float32, device=device), 0
-        v = self.buf[self.off:self.off + n].view(shape)
+        # A tensor of its own over the slab's storage, NOT a view of `buf`: views share one version counter, and the slices are both saved
+        # for backward (demodulation vectors) and mutated in place by autograd (a stolen gradient that a second backward accumulates
+        # into) -- as views, an in-place add on one slice made autograd reject every saved slice of the slab ("modified by an inplace
+        # operation"): two backward passes without zero_grad() in between were enough.
+        v = torch.empty(0, dtype=torch.float32, device=device).set_(self.buf.untyped_storage(), self.off, tuple(int(d) for d in shape))
         self.off += (n + 63) // 64 * 64                     # keep every slice 256-byte aligned
         return v
 

@@ -931,6 +931,30 @@ def test_modconv_backward_with_demodulated_gradient(dtype, shape):
         check(a, b.cpu(), dtype if name == "gx" else (torch.float32 if dtype == torch.float32 else dtype), f"modconv {name}", l2_scale=3.0)
 
 
+def test_gradient_accumulation_over_two_backward_passes():
+    """Two forward / backward passes of a modulated convolution WITHOUT zero_grad() in between: the second backward accumulates in place into
+    gradients autograd took over from the first -- slices of the zero pool's slab, like the demodulation vector the second forward saved.
+    (As views of one slab they shared a version counter and the second backward raised "modified by an inplace operation".)"""
+    from lcgan_amd import config, ops
+    from tests.helpers import install_backend
+    install_backend(None)
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(151)
+    x = feat((2, 16, 16, 64), dtype, 152).cuda()
+    w = torch.nn.Parameter(torch.randn(64, 64, 3, 3, generator=g).cuda())
+    bias = torch.nn.Parameter((torch.randn(64, generator=g) * 0.1).cuda())
+    s0 = (torch.rand(2, 64, generator=g) + 0.5).cuda()
+    with config.feature_dtype_as(dtype):
+        grads = []
+        for it in range(2):
+            ss = s0.clone().requires_grad_(True)
+            y = ops.ModConvFn.apply(x, w, bias, ss, 1, 1, 1.4)
+            y.float().sum().backward()
+            grads.append((w.grad.clone(), bias.grad.clone()))
+    assert torch.allclose(grads[1][0], 2 * grads[0][0], rtol=1e-3, atol=1e-3 * float(grads[0][0].abs().max()))
+    assert torch.allclose(grads[1][1], 2 * grads[0][1], rtol=1e-3, atol=1e-3 * float(grads[0][1].abs().max()))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_layout(H, dtype):
     src = torch.randn(3, 13, 4, 4, generator=torch.Generator().manual_seed(81))

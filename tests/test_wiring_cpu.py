@@ -426,3 +426,20 @@ def test_host_resident_synthetic_source_hands_out_the_resident_batches():
     for _ in range(5):
         for x, y in zip(a.next(), b.next()):
             assert torch.equal(x, y)
+
+
+def test_zero_pool_slices_do_not_share_a_version_counter():
+    """kernels._ZeroPool: slices of one slab are saved for backward (demodulation vectors) AND mutated in place by autograd (gradient
+    accumulation over two backward passes): an in-place op on one slice must not invalidate a saved neighbour"""
+    from lcgan_amd.kernels import _ZeroPool
+    pool = _ZeroPool()
+    a, b = pool.take((4, 128), torch.device("cpu")), pool.take((4, 128), "cpu")
+    assert a.data_ptr() != b.data_ptr() and float(a.abs().sum() + b.abs().sum()) == 0.0
+    assert a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()           # one slab
+    x = torch.ones(4, 128, requires_grad=True)
+    y = (x * a).sum()                              # `a` is saved for backward
+    va = a._version
+    b.add_(1.0)                                    # what AccumulateGrad does to a stolen gradient slice
+    assert a._version == va
+    y.backward()                                   # (raised "modified by an inplace operation" when the slices were views of the slab)
+    assert float(b.sum()) == 4 * 128 and float(a.abs().sum()) == 0.0
