@@ -762,6 +762,14 @@ __global__ __launch_bounds__(512, (IN_MUL == 1 || DMA == 4) ? 4 : 2) void conv_h
   // cost paid four times per tile (a 1-tap phase is 8 steps of main loop); eight workgroups asking for the same lines at the same moment
   // costs more than the Infinity Cache hits it saves.  Off by default.
   const HaloArgs::Decode dc = a.dec;
+  {
+    // the scalars the prologue needs, requested together at kernel entry: left to the compiler they were loaded one by one where each is
+    // first used -- eight dependent scalar-load round trips between the decode and the first DMA
+    const void *p0 = a.x, *p1 = a.w, *p2 = a.bias, *p3 = a.post;
+    const long long q0 = a.w_bstride;
+    const int i0 = a.B, i1 = a.Hin, i2 = a.Win, i3 = a.Cin, i4 = a.Cout, i5 = a.N, i6 = a.Kpad, i7 = a.kc_per_tap, i8 = a.nsplit, i9 = a.halo_elems;
+    asm volatile("" ::"s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(q0), "s"(i0), "s"(i1), "s"(i2), "s"(i3), "s"(i4), "s"(i5), "s"(i6), "s"(i7), "s"(i8), "s"(i9));
+  }
   const int nph = dc.nph_x, ntile = dc.ntile;
   int tile, nb;
   if (!(dc.dbg & 8) && (ntile & 7) == 0) {
@@ -1815,6 +1823,11 @@ __global__ __launch_bounds__(1024) void conv_s2duo_kernel(HaloArgs a) {
 
   // workgroup -> (pair of tiles, channel block), XCD-contiguous like conv_halo_kernel; team t owns tile 2 pair + t
   const HaloArgs::Decode dc = a.dec;
+  {                                                             // (the prologue's scalars in one batch of loads: see conv_halo_kernel)
+    const void *p0 = a.x, *p1 = a.w, *p2 = a.bias, *p3 = a.post;
+    const int i0 = a.B, i1 = a.Hin, i2 = a.Win, i3 = a.Cin, i4 = a.Cout, i5 = a.N, i6 = a.Kpad, i7 = a.Hm, i8 = a.Wm;
+    asm volatile("" ::"s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(i0), "s"(i1), "s"(i2), "s"(i3), "s"(i4), "s"(i5), "s"(i6), "s"(i7), "s"(i8));
+  }
   const int npair = dc.ntile;                                   // (this kernel's launch passes its PAIR count and the matching shifts)
   int pair, nb;
   if ((npair & 7) == 0) {
